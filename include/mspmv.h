@@ -1,0 +1,157 @@
+/*
+ * mspmv.h -- C ABI of the MI355X-native merge-based CsrMV (libmspmv.so).
+ *
+ * This is the drop-in boundary for the reference's device API
+ *     cub::DeviceSpmv::CsrMV(d_temp_storage, temp_storage_bytes, d_values,
+ *         d_row_offsets, d_column_indices, d_vector_x, d_vector_y,
+ *         num_rows, num_cols, num_nonzeros, stream, debug_synchronous)
+ * (reference cub/device/device_spmv.cuh:129-164, instantiated for float and
+ * double with int offsets at gpu_spmv.cu:730,734).  Plain pointers and sizes
+ * only; no C++ or torch types.  A header-only C++ shim with the reference's
+ * spelling lives in merge_spmv_amd/host/device_spmv.hpp.
+ *
+ * Conventions kept from the reference:
+ *   - two-phase temp storage: d_temp == NULL -> *temp_bytes receives the size
+ *     needed, no work is done, returns 0 (dispatch_spmv_orig.cuh:651-655);
+ *     otherwise *temp_bytes < needed -> hipErrorInvalidValue
+ *     (util_device.cuh:90-93);
+ *   - the caller owns every buffer including temp; the callee allocates
+ *     nothing and keeps no state between calls;
+ *   - all array pointers are DEVICE pointers; d_row_offsets has rows+1 entries
+ *     ([0]=0, [rows]=nnz, non-decreasing), 0-based int32 column indices,
+ *     duplicates allowed (sparse_matrix.h:645-650,666-728);
+ *   - y is fully overwritten: y = A*x (alpha=1, beta=0 as
+ *     device_spmv.cuh:155-156 forces); rows without entries get exactly 0;
+ *   - asynchronous on `stream` unless debug_sync != 0 (then every kernel is
+ *     followed by a stream sync and a launch-config line on stdout, like
+ *     dispatch_spmv_orig.cuh:685-739);
+ *   - return value: 0 (hipSuccess) or the first hipError_t as int.
+ * Deliberate differences (the reference's out-of-bounds habits, SURVEY.md
+ * Appendix B, are NOT inherited): nothing outside [0,rows] of d_row_offsets,
+ * [0,nnz) of values/columns, [0,cols) of x or [0,rows) of y is touched.
+ * Requires rows >= 0, cols >= 0, nnz >= 0 and rows + nnz < 2^31.
+ */
+#ifndef MSPMV_H_
+#define MSPMV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t passed as an opaque pointer so that C/ctypes/cgo callers need
+ * no HIP headers (NULL = the default stream). */
+typedef void *mspmv_stream_t;
+
+#define MSPMV_VERSION 100 /* 0.1.0 */
+int mspmv_version(void);
+
+/* hipGetErrorString for codes returned by this library. */
+const char *mspmv_error_string(int status);
+
+/* ---- the drop-in pair: replaces cub::DeviceSpmv::CsrMV<float|double> ---- */
+int mspmv_csrmv_f32(void *d_temp, size_t *temp_bytes, const float *d_values,
+                    const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                    const float *d_x, float *d_y, int32_t rows, int32_t cols,
+                    int32_t nnz, mspmv_stream_t stream, int debug_sync);
+
+int mspmv_csrmv_f64(void *d_temp, size_t *temp_bytes, const double *d_values,
+                    const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                    const double *d_x, double *d_y, int32_t rows, int32_t cols,
+                    int32_t nnz, mspmv_stream_t stream, int debug_sync);
+
+/* ---- extension: y = alpha*A*x + beta*y.  The reference
+ * parses --alpha/--beta (gpu_spmv.cu:721-722) and carries them in SpmvParams
+ * (agent_spmv_orig.cuh:109-110) but its CsrMV forces 1/0.  With beta == 0 the
+ * old contents of y are ignored (never read), as in BLAS. ---- */
+int mspmv_csrmv_axpby_f32(void *d_temp, size_t *temp_bytes, const float *d_values,
+                          const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                          const float *d_x, float *d_y, int32_t rows, int32_t cols,
+                          int32_t nnz, float alpha, float beta,
+                          mspmv_stream_t stream, int debug_sync);
+
+int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_values,
+                          const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                          const double *d_x, double *d_y, int32_t rows, int32_t cols,
+                          int32_t nnz, double alpha, double beta,
+                          mspmv_stream_t stream, int debug_sync);
+
+/* ---- introspection (the counterpart of the reference's debug_synchronous
+ * launch log, dispatch_spmv_orig.cuh:685-739, as data) ---- */
+typedef struct mspmv_launch_info {
+    int32_t block_threads;     /* threads per merge tile                      */
+    int32_t items_per_thread;  /* merge items per thread                      */
+    int32_t tile_items;        /* block_threads * items_per_thread            */
+    int32_t num_tiles;         /* ceil((rows+nnz) / tile_items)               */
+    int32_t fixup_chunk;       /* carry pairs per fix-up block                */
+    int32_t fixup_levels;      /* fix-up launches (0 when num_tiles <= 1)     */
+    int32_t flags;             /* MSPMV_TUNE_* bits in effect                 */
+    int32_t reserved;
+    uint64_t temp_bytes;       /* what the size query returns                 */
+    uint64_t coords_offset;    /* byte offsets of regions inside temp         */
+    uint64_t carries_offset;
+} mspmv_launch_info_t;
+
+/* value_bytes = 4 (float) or 8 (double). */
+int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes,
+                          mspmv_launch_info_t *info);
+
+/* Copy the tile coordinates ((num_tiles+1) x {row, nonzero}) and the per-tile
+ * carry pairs (num_tiles keys + values of value_bytes each) that the last
+ * csrmv call left in d_temp back to HOST arrays (synchronises `stream`).
+ * They correspond to d_tile_coordinates / d_tile_carry_pairs of
+ * dispatch_spmv_orig.cuh:643-646 and are what the parity tests pin against
+ * the oracle.  Any output pointer may be NULL. */
+int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
+                           int32_t value_bytes, int32_t *h_coords,
+                           int32_t *h_carry_keys, void *h_carry_values,
+                           mspmv_stream_t stream);
+
+/* Tuning override for experiments (process-global; 0 = library default):
+ * selects one of the compiled tile shapes for value_bytes.  Returns 0, or
+ * hipErrorInvalidValue if that shape was not compiled in. */
+#define MSPMV_TUNE_XCD_REMAP  1   /* contiguous tile ranges per XCD            */
+#define MSPMV_TUNE_ATOMIC_FIX 2   /* single-launch atomicAdd fix-up (non-deterministic) */
+#define MSPMV_TUNE_FUSED_SEARCH 4 /* tiles search their own coordinates (no search launch) */
+int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
+                     int32_t items_per_thread, int32_t flags);
+
+/* ---- multi-GPU merge partitioning (new design, the reference
+ * has no multi-device code: its claim is README.md:5).  Host-side, 64-bit. --
+ *
+ * The global merge path (rows + nnz items) is cut at `parts` equally spaced
+ * diagonals; part g owns rows-ending [row_split[g], row_split[g+1]) and
+ * nonzeros [nz_split[g], nz_split[g+1]).  Seen locally, part g is an ordinary
+ * CSR matrix with  local_rows = row_split[g+1]-row_split[g] + 1  rows: its
+ * first row may be the tail of a row begun on an earlier part, and its extra
+ * LAST row is the open row cut by the part's right boundary, so the local
+ * y[local_rows-1] IS the carry for global row row_split[g+1].
+ * h_row_offsets: HOST int64 [rows+1].  row_split/nz_split: HOST int64
+ * [parts+1]. */
+int mspmv_mg_partition(const int64_t *h_row_offsets, int64_t rows, int64_t nnz,
+                       int32_t parts, int64_t *row_split, int64_t *nz_split);
+
+/* Fill the local int32 row_offsets (local_rows+1 entries, rebased by
+ * -nz_split[g]) of part g. Returns hipErrorInvalidValue if the part does not
+ * fit int32. */
+int mspmv_mg_local_offsets(const int64_t *h_row_offsets, int64_t rows,
+                           int64_t row_begin, int64_t row_end_,
+                           int64_t nz_begin, int64_t nz_end_,
+                           int32_t *h_local_offsets);
+
+/* After the one exchange (all-gather of every part's carry value into
+ * d_carries[parts]): add to d_y_local[0] every carry of parts j < part whose
+ * key row_split[j+1] equals row_split[part] ... i.e. the rows this part owns
+ * that were begun earlier.  keys are given by the HOST array row_split.
+ * Deterministic (rank order).  value_bytes = 4 or 8. */
+int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries,
+                           const int64_t *row_split, int32_t parts,
+                           int32_t part, int32_t value_bytes,
+                           mspmv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSPMV_H_ */

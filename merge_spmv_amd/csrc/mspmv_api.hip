@@ -1,0 +1,332 @@
+// mspmv_api.hip -- the C ABI of include/mspmv.h: host dispatch for the
+// merge-based CsrMV kernels.  Replaces the reference's DeviceSpmv::CsrMV
+// (cub/device/device_spmv.cuh:129-164) and DispatchSpmv::Dispatch
+// (cub/device/dispatch/dispatch_spmv_orig.cuh:544-752) -- without that
+// dispatcher's per-call device-attribute / occupancy queries and texture
+// bind/unbind (all inside the reference's timed loop): grid shapes here are
+// pure arithmetic on (rows, nnz), so a call is three kernel launches and
+// nothing else.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mspmv.h"
+#include "mspmv_kernels.hpp"
+
+namespace mspmv {
+
+constexpr int SEARCH_BLOCK = 256;
+constexpr int FIX_BLOCK = 256;
+constexpr int FIX_IPT = 8;
+constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
+
+static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
+
+// Tile shapes compiled in.  The first entry per value type is the default.
+struct Shape { int block, ipt; };
+static const Shape kShapesF32[] = {{256, 7}, {256, 5}, {256, 9}, {256, 11}, {128, 7}, {512, 7}, {256, 15}};
+static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128, 5}, {512, 5}, {256, 11}};
+
+struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}; };
+static Tuning g_tune[2];  // [0] = 4-byte values, [1] = 8-byte values
+
+static Shape pick_shape(int value_bytes, int &flags)
+{
+    Tuning &t = g_tune[value_bytes == 8];
+    flags = t.flags.load();
+    const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
+    Shape s = tab[0];
+    if (t.block.load() > 0) { s.block = t.block.load(); s.ipt = t.ipt.load(); }
+    return s;
+}
+
+struct Layout {
+    Shape shape; int flags;
+    int num_tiles;
+    int fix_n[3];          // pairs entering fix-up level i (fix_n[0] == num_tiles)
+    int fix_levels;
+    uint64_t coords_off, carries_off, fix_off[2], total;
+};
+
+static Layout make_layout(int rows, int nnz, int value_bytes)
+{
+    Layout L; memset(&L, 0, sizeof(L));
+    L.shape = pick_shape(value_bytes, L.flags);
+    const long long total = (long long) rows + nnz;
+    const int tile = L.shape.block * L.shape.ipt;
+    L.num_tiles = (int) ((total + tile - 1) / tile);
+    const uint64_t pair = value_bytes == 8 ? 16 : 8;
+    uint64_t off = 0;
+    L.coords_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(Coord));
+    L.carries_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * pair);
+    // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
+    L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
+    if (L.num_tiles > 1) {
+        int n = L.num_tiles; int lvl = 0;
+        for (;;) {
+            const int blocks = (n + FIX_CHUNK - 1) / FIX_CHUNK;
+            ++lvl;
+            if (blocks == 1 || (L.flags & MSPMV_TUNE_ATOMIC_FIX)) break;
+            n = 2 * blocks;
+            L.fix_n[lvl] = n;
+            L.fix_off[lvl - 1] = off; off = align256(off + uint64_t(n) * pair);
+        }
+        L.fix_levels = lvl;    // <= 3 for rows+nnz < 2^31 (2^31/1280 tiles -> 1640 -> 2 -> done)
+    }
+    L.total = off > 0 ? off : 256;
+    return L;
+}
+
+#define MSPMV_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *name, unsigned grid, unsigned block)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (debug_sync) {
+        printf("mspmv: %s<<<%u, %u>>>\n", name, grid, block); fflush(stdout);
+        e = hipStreamSynchronize(stream);
+    }
+    return e;
+}
+
+template <typename V, int BLOCK, int IPT>
+static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, bool axpby, hipStream_t stream,
+                            int debug_sync)
+{
+    char *base = static_cast<char *>(d_temp);
+    Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off);
+    Carry<V> *carries = reinterpret_cast<Carry<V> *>(base + L.carries_off);
+    const int tile_items = BLOCK * IPT;
+
+    // 1. tile boundary search
+    {
+        const unsigned grid = (unsigned) ((L.num_tiles + 1 + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE));
+        hipLaunchKernelGGL((search_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows,
+                           p.nnz, tile_items, L.num_tiles, coords);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "search_kernel", grid, SEARCH_BLOCK));
+    }
+    // 2. tiles
+    {
+        const unsigned grid = (unsigned) L.num_tiles;
+        const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
+        if (axpby) {
+            if (remap) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+            else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        } else {
+            if (remap) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+            else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        }
+        MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel", grid, BLOCK));
+    }
+    // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair)
+    if (L.num_tiles > 1) {
+        if (L.flags & MSPMV_TUNE_ATOMIC_FIX) {
+            const unsigned grid = (unsigned) ((L.num_tiles + FIX_BLOCK - 1) / FIX_BLOCK);
+            hipLaunchKernelGGL((fixup_atomic_kernel<V, FIX_BLOCK>), dim3(grid), dim3(FIX_BLOCK), 0, stream, carries,
+                               L.num_tiles, p.y, p.rows, p.alpha);
+            MSPMV_CHECK(after_launch(stream, debug_sync, "fixup_atomic_kernel", grid, FIX_BLOCK));
+        } else {
+            const Carry<V> *in = carries;
+            for (int lvl = 0; lvl < L.fix_levels; ++lvl) {
+                const int n = L.fix_n[lvl];
+                const unsigned grid = (unsigned) ((n + FIX_CHUNK - 1) / FIX_CHUNK);
+                Carry<V> *out = grid > 1 ? reinterpret_cast<Carry<V> *>(base + L.fix_off[lvl]) : nullptr;
+                hipLaunchKernelGGL((fixup_kernel<V, FIX_BLOCK, FIX_IPT>), dim3(grid), dim3(FIX_BLOCK), 0, stream, in, n,
+                                   out, p.y, p.rows, p.alpha);
+                MSPMV_CHECK(after_launch(stream, debug_sync, "fixup_kernel", grid, FIX_BLOCK));
+                in = out;
+            }
+        }
+    }
+    return hipSuccess;
+}
+
+template <typename V>
+static hipError_t dispatch_shape(const Layout &L, void *d_temp, const Params<V> &p, bool axpby, hipStream_t stream,
+                                 int debug_sync);
+
+#define MSPMV_SHAPE_CASE(V, B, I) \
+    if (L.shape.block == B && L.shape.ipt == I) return run_shape<V, B, I>(L, d_temp, p, axpby, stream, debug_sync);
+
+template <>
+hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<float> &p, bool axpby, hipStream_t stream,
+                                 int debug_sync)
+{
+    MSPMV_SHAPE_CASE(float, 256, 7)
+    MSPMV_SHAPE_CASE(float, 256, 5)
+    MSPMV_SHAPE_CASE(float, 256, 9)
+    MSPMV_SHAPE_CASE(float, 256, 11)
+    MSPMV_SHAPE_CASE(float, 128, 7)
+    MSPMV_SHAPE_CASE(float, 512, 7)
+    MSPMV_SHAPE_CASE(float, 256, 15)
+    return hipErrorInvalidValue;
+}
+
+template <>
+hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<double> &p, bool axpby,
+                                  hipStream_t stream, int debug_sync)
+{
+    MSPMV_SHAPE_CASE(double, 256, 5)
+    MSPMV_SHAPE_CASE(double, 256, 3)
+    MSPMV_SHAPE_CASE(double, 256, 7)
+    MSPMV_SHAPE_CASE(double, 256, 9)
+    MSPMV_SHAPE_CASE(double, 128, 5)
+    MSPMV_SHAPE_CASE(double, 512, 5)
+    MSPMV_SHAPE_CASE(double, 256, 11)
+    return hipErrorInvalidValue;
+}
+
+template <typename V>
+static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets,
+                      const int32_t *d_cols, const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha,
+                      V beta, bool axpby, mspmv_stream_t stream_, int debug_sync)
+{
+    if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
+    if ((long long) rows + nnz > 0x7fffffffLL) return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, (int) sizeof(V));
+    if (d_temp == nullptr) {                      // size query (dispatch_spmv_orig.cuh:651-655)
+        *temp_bytes = (size_t) L.total;
+        return hipSuccess;
+    }
+    if (*temp_bytes < L.total) return hipErrorInvalidValue;   // util_device.cuh:90-93
+    if (rows == 0) return hipSuccess;             // nothing to write
+    if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    Params<V> p;
+    p.values = d_values; p.row_end = d_row_offsets + 1; p.cols = d_cols; p.x = d_x; p.y = d_y;
+    p.rows = rows; p.nnz = nnz; p.alpha = alpha; p.beta = beta;
+    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync);
+}
+
+}  // namespace mspmv
+
+using namespace mspmv;
+
+extern "C" {
+
+int mspmv_version(void) { return MSPMV_VERSION; }
+
+const char *mspmv_error_string(int status) { return hipGetErrorString((hipError_t) status); }
+
+int mspmv_csrmv_f32(void *d_temp, size_t *temp_bytes, const float *d_values, const int32_t *d_row_offsets,
+                    const int32_t *d_column_indices, const float *d_x, float *d_y, int32_t rows, int32_t cols,
+                    int32_t nnz, mspmv_stream_t stream, int debug_sync)
+{
+    return csrmv_impl<float>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
+                             1.0f, 0.0f, false, stream, debug_sync);
+}
+
+int mspmv_csrmv_f64(void *d_temp, size_t *temp_bytes, const double *d_values, const int32_t *d_row_offsets,
+                    const int32_t *d_column_indices, const double *d_x, double *d_y, int32_t rows, int32_t cols,
+                    int32_t nnz, mspmv_stream_t stream, int debug_sync)
+{
+    return csrmv_impl<double>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
+                              1.0, 0.0, false, stream, debug_sync);
+}
+
+int mspmv_csrmv_axpby_f32(void *d_temp, size_t *temp_bytes, const float *d_values, const int32_t *d_row_offsets,
+                          const int32_t *d_column_indices, const float *d_x, float *d_y, int32_t rows, int32_t cols,
+                          int32_t nnz, float alpha, float beta, mspmv_stream_t stream, int debug_sync)
+{
+    return csrmv_impl<float>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
+                             alpha, beta, true, stream, debug_sync);
+}
+
+int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_values, const int32_t *d_row_offsets,
+                          const int32_t *d_column_indices, const double *d_x, double *d_y, int32_t rows, int32_t cols,
+                          int32_t nnz, double alpha, double beta, mspmv_stream_t stream, int debug_sync)
+{
+    return csrmv_impl<double>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
+                              alpha, beta, true, stream, debug_sync);
+}
+
+int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)
+{
+    if (!info || (value_bytes != 4 && value_bytes != 8) || rows < 0 || nnz < 0 ||
+        (long long) rows + nnz > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, value_bytes);
+    memset(info, 0, sizeof(*info));
+    info->block_threads = L.shape.block;
+    info->items_per_thread = L.shape.ipt;
+    info->tile_items = L.shape.block * L.shape.ipt;
+    info->num_tiles = L.num_tiles;
+    info->fixup_chunk = FIX_CHUNK;
+    info->fixup_levels = L.fix_levels;
+    info->flags = L.flags;
+    info->temp_bytes = L.total;
+    info->coords_offset = L.coords_off;
+    info->carries_offset = L.carries_off;
+    return hipSuccess;
+}
+
+int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes, int32_t *h_coords,
+                           int32_t *h_carry_keys, void *h_carry_values, mspmv_stream_t stream_)
+{
+    if (!d_temp || (value_bytes != 4 && value_bytes != 8)) return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, value_bytes);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    MSPMV_CHECK(hipStreamSynchronize(stream));
+    const char *base = static_cast<const char *>(d_temp);
+    if (h_coords)
+        MSPMV_CHECK(hipMemcpy(h_coords, base + L.coords_off, sizeof(Coord) * size_t(L.num_tiles + 1),
+                              hipMemcpyDeviceToHost));
+    if ((h_carry_keys || h_carry_values) && L.num_tiles > 0) {
+        const size_t pair = value_bytes == 8 ? 16 : 8;
+        std::vector<char> tmp(pair * size_t(L.num_tiles));
+        MSPMV_CHECK(hipMemcpy(tmp.data(), base + L.carries_off, tmp.size(), hipMemcpyDeviceToHost));
+        for (int t = 0; t < L.num_tiles; ++t) {
+            const char *rec = tmp.data() + pair * size_t(t);
+            if (h_carry_keys) memcpy(&h_carry_keys[t], rec, 4);
+            if (h_carry_values)
+                memcpy(static_cast<char *>(h_carry_values) + size_t(value_bytes) * t, rec + (value_bytes == 8 ? 8 : 4),
+                       size_t(value_bytes));
+        }
+    }
+    return hipSuccess;
+}
+
+int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_per_thread, int32_t flags)
+{
+    if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
+    const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
+    const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX)) return hipErrorInvalidValue;  // FUSED_SEARCH: not built yet
+    Tuning &t = g_tune[value_bytes == 8];
+    if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
+    for (int i = 0; i < count; ++i)
+        if (tab[i].block == block_threads && tab[i].ipt == items_per_thread) {
+            t.block = block_threads; t.ipt = items_per_thread; t.flags = flags;
+            return hipSuccess;
+        }
+    return hipErrorInvalidValue;
+}
+
+int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries, const int64_t *row_split, int32_t parts,
+                           int32_t part, int32_t value_bytes, mspmv_stream_t stream_)
+{
+    if (!d_y_local || !d_carries || !row_split || parts < 1 || parts > 64 || part < 0 || part >= parts ||
+        (value_bytes != 4 && value_bytes != 8))
+        return hipErrorInvalidValue;
+    // this part owns y for global rows [row_split[part], row_split[part+1]); a
+    // carry of part j (key row_split[j+1]) lands here iff the key equals our
+    // first row and we own at least one row.
+    if (row_split[part + 1] <= row_split[part]) return hipSuccess;
+    unsigned long long mask = 0;
+    for (int j = 0; j < part; ++j)
+        if (row_split[j + 1] == row_split[part]) mask |= 1ull << j;
+    if (!mask) return hipSuccess;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (value_bytes == 8)
+        hipLaunchKernelGGL((mg_apply_kernel<double>), dim3(1), dim3(64), 0, stream, static_cast<double *>(d_y_local),
+                           static_cast<const double *>(d_carries), mask, parts);
+    else
+        hipLaunchKernelGGL((mg_apply_kernel<float>), dim3(1), dim3(64), 0, stream, static_cast<float *>(d_y_local),
+                           static_cast<const float *>(d_carries), mask, parts);
+    return (int) hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""Synthetic CSR workloads of BASELINE.json / SURVEY.md 8(d), generated with
+torch ops so they can be produced directly in HBM (or on the CPU for tests)
+from a counter-based RNG: element i of stream `seed` is splitmix64(seed + i),
+so a matrix is independent of device, chunking and GPU count.
+
+The reference has no random generators (its --dense/--grid2d/--grid3d/--wheel
+matrices, sparse_matrix.h:386-617, all carry 1.0 values and are reproduced in
+merge_spmv_amd/host/sparse_matrix.hpp); these are the "new" inputs SURVEY.md
+7(2) asks for: C2 uniform, C3 power-law / R-MAT stand-ins, C4 degenerate,
+C5 R-MAT.  Output layout is the reference's CSR (sparse_matrix.h:645-650):
+int32 row_offsets[rows+1], int32 column_indices[nnz] sorted by (row, col) with
+duplicates kept, values[nnz].
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+SEED_C2 = 0x5EED0002
+SEED_C3 = 0x5EED0003
+SEED_C4 = 0x5EED0004
+SEED_C5 = 0x5EED0005
+
+_M64 = (1 << 64) - 1
+
+
+def _i64(v: int) -> int:
+    """two's-complement int64 view of a 64-bit constant"""
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    """logical shift right on int64 lanes"""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def splitmix64(seed: int, index: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser of (seed + (index+1)*golden) as int64 bit patterns.
+    index: int64 tensor of counters."""
+    z = index * _i64(0x9E3779B97F4A7C15) + _i64(seed + 0x9E3779B97F4A7C15)
+    z = (z ^ _lsr(z, 30)) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _i64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def uniform01(seed: int, index: torch.Tensor) -> torch.Tensor:
+    """double in [0,1): top 53 bits of splitmix64"""
+    return _lsr(splitmix64(seed, index), 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+def uniform_pm1(seed: int, count: int, dtype, device, start: int = 0, chunk: int = 1 << 26) -> torch.Tensor:
+    """values uniform in [-1, 1) (cast from double), counters start..start+count"""
+    out = torch.empty(count, dtype=dtype, device=device)
+    for a in range(0, count, chunk):
+        b = min(a + chunk, count)
+        idx = torch.arange(start + a, start + b, dtype=torch.int64, device=device)
+        out[a:b] = (uniform01(seed, idx) * 2.0 - 1.0).to(dtype)
+    return out
+
+
+@dataclass
+class DeviceCsr:
+    rows: int
+    cols: int
+    row_offsets: torch.Tensor
+    column_indices: torch.Tensor
+    values: torch.Tensor
+
+    @property
+    def nnz(self) -> int:
+        return int(self.values.numel())
+
+
+def uniform_csr(rows: int, cols: int, nnz_per_row: int, dtype=torch.float32, device="cuda",
+                seed: int = SEED_C2, chunk_rows: int = 1 << 19) -> DeviceCsr:
+    """C2: exactly nnz_per_row entries per row, columns i.i.d. uniform over
+    [0, cols) sorted within the row (duplicates kept), values uniform [-1,1)
+    from stream seed+1.  (x for the run: uniform_pm1(seed + 2, cols, ...).)"""
+    nnz = rows * nnz_per_row
+    cols_out = torch.empty(nnz, dtype=torch.int32, device=device)
+    for r0 in range(0, rows, chunk_rows):
+        r1 = min(r0 + chunk_rows, rows)
+        idx = torch.arange(r0 * nnz_per_row, r1 * nnz_per_row, dtype=torch.int64, device=device)
+        c = (uniform01(seed, idx) * cols).to(torch.int64).clamp_(max=cols - 1)
+        c = c.view(r1 - r0, nnz_per_row).sort(dim=1).values
+        cols_out[r0 * nnz_per_row: r1 * nnz_per_row] = c.reshape(-1).to(torch.int32)
+    offsets = (torch.arange(rows + 1, dtype=torch.int64, device=device) * nnz_per_row).to(torch.int32)
+    return DeviceCsr(rows, cols, offsets, cols_out, uniform_pm1(seed + 1, nnz, dtype, device))
+
+
+def dense_csr(rows: int, cols: int, dtype=torch.float32, device="cuda", ones: bool = True,
+              seed: int = SEED_C2) -> DeviceCsr:
+    """The reference's --dense=<cols> matrix (InitDense, sparse_matrix.h:386-413)
+    built directly in CSR: every row holds columns 0..cols-1."""
+    nnz = rows * cols
+    offsets = (torch.arange(rows + 1, dtype=torch.int64, device=device) * cols).to(torch.int32)
+    c = torch.arange(cols, dtype=torch.int32, device=device).repeat(rows)
+    v = torch.ones(nnz, dtype=dtype, device=device) if ones else uniform_pm1(seed + 1, nnz, dtype, device)
+    return DeviceCsr(rows, cols, offsets, c, v)
+
+
+def degenerate_csr(rows: int = 1 << 24, giant_nnz: int = 1 << 26, every: int = 4096, dtype=torch.float32,
+                   device="cuda", ones: bool = True, seed: int = SEED_C4) -> DeviceCsr:
+    """C4: square `rows`; row rows/2 holds giant_nnz entries (columns k mod
+    cols); every `every`-th other row holds one entry (column = row); all
+    remaining rows are empty."""
+    cols = rows
+    giant = rows // 2
+    lens = torch.zeros(rows, dtype=torch.int64, device=device)
+    lens[::every] = 1
+    lens[giant] = giant_nnz
+    offsets64 = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=offsets64[1:])
+    nnz = int(offsets64[-1].item())
+    col = torch.empty(nnz, dtype=torch.int32, device=device)
+    single_rows = torch.arange(0, rows, every, dtype=torch.int64, device=device)
+    single_rows = single_rows[single_rows != giant]
+    col[offsets64[single_rows]] = single_rows.to(torch.int32)
+    g0 = int(offsets64[giant].item())
+    # within the giant row the reference's CSR order is sorted by column; with
+    # k mod cols and giant_nnz a multiple of cols each column appears
+    # giant_nnz/cols times consecutively
+    k = torch.arange(giant_nnz, dtype=torch.int64, device=device)
+    col[g0:g0 + giant_nnz] = ((k % cols).sort().values).to(torch.int32)
+    v = torch.ones(nnz, dtype=dtype, device=device) if ones else uniform_pm1(seed + 1, nnz, dtype, device)
+    return DeviceCsr(rows, cols, offsets64.to(torch.int32), col, v)
+
+
+def rmat_edges(scale: int, edge_begin: int, edge_end: int, device, seed: int,
+               a: float = 0.57, b: float = 0.19, c: float = 0.19):
+    """(row, col) int64 of R-MAT edges [edge_begin, edge_end): per level one
+    uniform draw from counter edge*scale+level picks the quadrant."""
+    n = edge_end - edge_begin
+    e = torch.arange(edge_begin, edge_end, dtype=torch.int64, device=device)
+    row = torch.zeros(n, dtype=torch.int64, device=device)
+    col = torch.zeros(n, dtype=torch.int64, device=device)
+    for level in range(scale):
+        u = uniform01(seed, e * scale + level)
+        rbit = (u >= a + b).to(torch.int64)                       # quadrants c, d
+        cbit = (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)   # quadrants b, d
+        row = row * 2 + rbit
+        col = col * 2 + cbit
+    return row, col
+
+
+def rmat_csr(scale: int, edges: int, dtype=torch.float64, device="cuda", seed: int = SEED_C5,
+             row_lo: int = 0, row_hi: Optional[int] = None, chunk: int = 1 << 25,
+             return_edge_ids: bool = False):
+    """R-MAT (a,b,c,d = .57,.19,.19,.05), duplicates kept, restricted to rows
+    [row_lo, row_hi) (default all): CSR sorted by (row, col, edge id); value of
+    edge e = uniform [-1,1) from stream seed+1 counter e.  rows = cols =
+    2^scale.  Generating a row range needs a full pass over all edge ids
+    (cheap hashing) but only keeps that range's edges, so ranks can build
+    disjoint row ranges independently of the GPU count."""
+    n = 1 << scale
+    row_hi = n if row_hi is None else row_hi
+    keep_r, keep_c, keep_e = [], [], []
+    for e0 in range(0, edges, chunk):
+        e1 = min(e0 + chunk, edges)
+        r, c = rmat_edges(scale, e0, e1, device, seed)
+        m = (r >= row_lo) & (r < row_hi)
+        if row_lo == 0 and row_hi == n:
+            keep_r.append(r); keep_c.append(c)
+            keep_e.append(torch.arange(e0, e1, dtype=torch.int64, device=device))
+        else:
+            keep_r.append(r[m]); keep_c.append(c[m])
+            keep_e.append(torch.arange(e0, e1, dtype=torch.int64, device=device)[m])
+    r = torch.cat(keep_r); c = torch.cat(keep_c); e = torch.cat(keep_e)
+    del keep_r, keep_c, keep_e
+    # edge ids are already increasing, so a stable sort by (row, col) keeps them ordered
+    key = (r - row_lo) * n + c
+    order = torch.sort(key, stable=True).indices
+    r = r[order]; c = c[order]; e = e[order]
+    lens = torch.bincount(r - row_lo, minlength=row_hi - row_lo)
+    offsets = torch.zeros(row_hi - row_lo + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=offsets[1:])
+    vals = (uniform01(seed + 1, e) * 2.0 - 1.0).to(dtype)
+    csr = DeviceCsr(row_hi - row_lo, n, offsets.to(torch.int32) if offsets[-1] < 2**31 else offsets,
+                    c.to(torch.int32), vals)
+    return (csr, e) if return_edge_ids else csr

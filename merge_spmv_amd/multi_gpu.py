@@ -1,0 +1,134 @@
+"""Multi-GPU merge-partitioned CsrMV -- one process per GPU.
+
+New design (the reference is single-device; its README.md:5 only claims the
+decomposition partitions recursively): the global merge path is cut at G
+equally spaced diagonals exactly as cpu_spmv.cpp:305-321 cuts it per OpenMP
+thread; each rank runs the ordinary single-GPU CsrMV (include/mspmv.h) on its
+swath, seen as a local CSR matrix with one extra "open" last row whose y IS
+the rank's carry; ONE collective (an all-gather of G scalars over RCCL/xGMI)
+exchanges the carries; each rank adds the carries addressed to its first row
+(cpu_spmv.cpp:348-352 lifted to ranks).  x is replicated, y stays row-sharded.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import load_library, _check, CsrMVWorkspace, DeviceSpmv, _stream_handle, _value_bytes
+
+
+def partition(row_offsets_i64: np.ndarray, parts: int):
+    """(row_split[parts+1], nz_split[parts+1]) -- mspmv_mg_partition."""
+    off = np.ascontiguousarray(row_offsets_i64, dtype=np.int64)
+    rows = off.size - 1
+    nnz = int(off[-1])
+    row_split = np.zeros(parts + 1, dtype=np.int64)
+    nz_split = np.zeros(parts + 1, dtype=np.int64)
+    _check(load_library().mspmv_mg_partition(off.ctypes.data_as(ctypes.c_void_p), rows, nnz, int(parts),
+                                             row_split.ctypes.data_as(ctypes.c_void_p),
+                                             nz_split.ctypes.data_as(ctypes.c_void_p)), "mspmv_mg_partition")
+    return row_split, nz_split
+
+
+def local_offsets(row_offsets_i64: np.ndarray, row_begin: int, row_end: int, nz_begin: int, nz_end: int) -> np.ndarray:
+    """int32 row_offsets of one part's local CSR (local_rows + 1 entries,
+    local_rows = row_end - row_begin + 1) -- mspmv_mg_local_offsets."""
+    off = np.ascontiguousarray(row_offsets_i64, dtype=np.int64)
+    out = np.zeros(int(row_end - row_begin) + 2, dtype=np.int32)
+    _check(load_library().mspmv_mg_local_offsets(off.ctypes.data_as(ctypes.c_void_p), off.size - 1, int(row_begin),
+                                                 int(row_end), int(nz_begin), int(nz_end),
+                                                 out.ctypes.data_as(ctypes.c_void_p)), "mspmv_mg_local_offsets")
+    return out
+
+
+@dataclass
+class Shard:
+    """One rank's swath of the global matrix, as an ordinary local CSR."""
+    part: int
+    parts: int
+    row_split: np.ndarray       # int64 [parts+1] (host)
+    nz_split: np.ndarray        # int64 [parts+1] (host)
+    row_offsets: "object"       # torch int32 [local_rows+1] (device)
+    column_indices: "object"    # torch int32 [local_nnz]
+    values: "object"            # torch f32/f64 [local_nnz]
+    num_cols: int
+
+    @property
+    def local_rows(self) -> int:
+        return int(self.row_split[self.part + 1] - self.row_split[self.part]) + 1
+
+    @property
+    def owned_rows(self) -> int:
+        return self.local_rows - 1
+
+    @property
+    def local_nnz(self) -> int:
+        return int(self.nz_split[self.part + 1] - self.nz_split[self.part])
+
+
+class ShardedCsrMV:
+    """y_owned = (A x)[row_split[p] : row_split[p+1]] on rank p.
+
+    `group` is a torch.distributed process group (backend "nccl" == RCCL on
+    ROCm; "gloo" works for the CPU-side protocol tests with `local_spmv`
+    overridden).  With parts == 1 no collective is issued.
+    """
+
+    def __init__(self, shard: Shard, group=None, local_spmv=None):
+        import torch
+        self.shard = shard
+        self.group = group
+        self.torch = torch
+        self.local_spmv = local_spmv
+        dev = shard.values.device
+        self.y_local = torch.empty(shard.local_rows, dtype=shard.values.dtype, device=dev)
+        self.carries = torch.zeros(shard.parts, dtype=shard.values.dtype, device=dev)
+        self.workspace = None
+        if local_spmv is None:
+            self.workspace = CsrMVWorkspace(shard.local_rows, shard.local_nnz, shard.values.dtype, device=dev)
+
+    def __call__(self, x):
+        torch, s = self.torch, self.shard
+        if self.local_spmv is not None:
+            self.local_spmv(s, x, self.y_local)
+        else:
+            st, _ = DeviceSpmv.CsrMV(self.workspace.buffer, self.workspace.bytes, s.values, s.row_offsets,
+                                     s.column_indices, x, self.y_local, s.local_rows, s.num_cols, s.local_nnz)
+            _check(st, "mspmv_csrmv (shard)")
+        if s.parts > 1:
+            import torch.distributed as dist
+            # the ONE exchange: every rank contributes its open-row partial
+            dist.all_gather_into_tensor(self.carries, self.y_local[s.local_rows - 1:], group=self.group)
+            self._apply_carries()
+        return self.y_local[: s.owned_rows]
+
+    def _apply_carries(self):
+        s = self.shard
+        if self.y_local.is_cuda:
+            _check(load_library().mspmv_mg_apply_carries(
+                ctypes.c_void_p(self.y_local.data_ptr()), ctypes.c_void_p(self.carries.data_ptr()),
+                s.row_split.ctypes.data_as(ctypes.c_void_p), int(s.parts), int(s.part),
+                _value_bytes(self.y_local), _stream_handle(None)), "mspmv_mg_apply_carries")
+        else:
+            # host mirror of mg_apply_kernel for the gloo protocol tests
+            if s.row_split[s.part + 1] > s.row_split[s.part]:
+                for j in range(s.part):
+                    if s.row_split[j + 1] == s.row_split[s.part]:
+                        self.y_local[0] += self.carries[j]
+
+
+def shard_from_host_csr(row_offsets: np.ndarray, column_indices: np.ndarray, values: np.ndarray, num_cols: int,
+                        part: int, parts: int, device="cuda") -> Shard:
+    """Cut a host CSR (any integer offset width) and upload rank `part`'s swath."""
+    import torch
+    off = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    row_split, nz_split = partition(off, parts)
+    lo = local_offsets(off, row_split[part], row_split[part + 1], nz_split[part], nz_split[part + 1])
+    a, b = int(nz_split[part]), int(nz_split[part + 1])
+    return Shard(part, parts, row_split, nz_split,
+                 torch.from_numpy(lo).to(device),
+                 torch.from_numpy(np.ascontiguousarray(column_indices[a:b], dtype=np.int32)).to(device),
+                 torch.from_numpy(np.ascontiguousarray(values[a:b])).to(device), int(num_cols))

@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: libmspmv.so loads and exports
+every symbol include/mspmv.h declares; the host-only entry points (size
+query, launch info, multi-GPU partitioner) behave.  No kernel is launched."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+import merge_spmv_amd as M
+from oracle import oracle as O
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mspmv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mspmv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = M.load_library()
+    names = declared_symbols()
+    assert "mspmv_csrmv_f32" in names and "mspmv_csrmv_f64" in names and len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.mspmv_version() == 100
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(M, "_lib", None)
+    monkeypatch.setattr(M, "_LIB_NAME", "libmspmv_does_not_exist.so")
+    with pytest.raises(M.MspmvError):
+        M.load_library()
+
+
+def test_size_query_two_phase_convention():
+    """d_temp == NULL -> size only, success, no work (dispatch_spmv_orig.cuh:651-655);
+    too small -> hipErrorInvalidValue (util_device.cuh:90-93)."""
+    lib = M.load_library()
+    for fn, vb in ((lib.mspmv_csrmv_f32, 4), (lib.mspmv_csrmv_f64, 8)):
+        size = ctypes.c_size_t(0)
+        st = fn(None, ctypes.byref(size), None, None, None, None, None, 1000, 1000, 50000, None, 0)
+        assert st == 0 and size.value > 0
+        info = M.launch_info(1000, 50000, vb)
+        assert info["temp_bytes"] == size.value
+        assert info["tile_items"] == info["block_threads"] * info["items_per_thread"]
+        assert info["num_tiles"] == -(-51000 // info["tile_items"])
+        small = ctypes.c_size_t(size.value - 1)
+        st = fn(ctypes.c_void_p(256), ctypes.byref(small), None, None, None, None, None, 1000, 1000, 50000, None, 0)
+        assert st == 1  # hipErrorInvalidValue
+        st = fn(None, ctypes.byref(size), None, None, None, None, None, -1, 5, 5, None, 0)
+        assert st == 1
+        st = fn(None, ctypes.byref(size), None, None, None, None, None, 2**30, 5, 2**30 + 5, None, 0)
+        assert st == 1  # rows + nnz must stay below 2^31
+
+
+def test_tuning_rejects_unknown_shapes():
+    M.set_tuning(4, 256, 9)
+    assert M.launch_info(10, 10, 4)["items_per_thread"] == 9
+    M.set_tuning(4)
+    assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
+    with pytest.raises(M.MspmvError):
+        M.set_tuning(4, 250, 7)
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])
+def test_mg_partition_matches_oracle_search(parts):
+    """The multi-GPU cut points are merge-path coordinates of equally spaced
+    diagonals (64-bit MergePathSearch), and the shards tile the matrix."""
+    from merge_spmv_amd import multi_gpu as MG
+    rng = np.random.default_rng(parts)
+    lens = rng.integers(0, 9, size=200)
+    lens[50] = 700                        # a row spanning several parts
+    lens[120:140] = 0
+    off = np.zeros(201, dtype=np.int64); np.cumsum(lens, out=off[1:])
+    rows, nnz = 200, int(off[-1])
+    row_split, nz_split = MG.partition(off, parts)
+    per = -(-(rows + nnz) // parts)
+    for g in range(parts + 1):
+        d = min(per * g, rows + nnz)
+        assert (row_split[g], nz_split[g]) == O.merge_path_search_i64(d, off[1:], rows, nnz)
+    assert (row_split[0], nz_split[0]) == (0, 0) and (row_split[-1], nz_split[-1]) == (rows, nnz)
+    # local CSR of every part: offsets rebased, one extra open row
+    for g in range(parts):
+        lo = MG.local_offsets(off, row_split[g], row_split[g + 1], nz_split[g], nz_split[g + 1])
+        assert lo[0] == 0 and lo[-1] == nz_split[g + 1] - nz_split[g]
+        assert lo.size == row_split[g + 1] - row_split[g] + 2
+        assert np.all(np.diff(lo) >= 0)

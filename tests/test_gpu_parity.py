@@ -1,0 +1,265 @@
+"""GPU parity tests (-m gpu): the HIP merge-path CsrMV, called through the
+C ABI (include/mspmv.h via merge_spmv_amd.DeviceSpmv.CsrMV), against the
+oracle on the same inputs.
+
+Bars: tile coordinates and carry keys are integers -> bit-exact vs the
+reference-pinned MergePathSearch; y is exact where the arithmetic is exact
+(the reference's own generators: values = x = 1.0 -> y = row length) and
+within the stated tolerance otherwise:
+    |y[r] - g[r]| <= c * eps * s[r],  g = fp64-accumulated gold, s = sum|val*x|,
+    c = 2*(ceil(log2(len_r+1)) + items_per_thread + 8), eps = 2^-24 | 2^-53,
+    empty rows exactly 0                      (SURVEY.md 8d / BASELINE.md 2).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import oracle as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+CASES = load_golden("matrices.json")["cases"]
+DT = {"f32": (np.float32, 4), "f64": (np.float64, 8)}
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")
+    import merge_spmv_amd as M_
+    M_.load_library()          # raises if the HIP extension is missing: no fallback
+    M_.set_tuning(4); M_.set_tuning(8)
+    return M_
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_gpu(M, csr, x, sentinel=True, **kw):
+    """One CsrMV through the C ABI; y pre-filled with NaN so unwritten rows show."""
+    vb = csr.values.dtype.itemsize
+    ws = M.CsrMVWorkspace(csr.rows, csr.nnz, torch.float32 if vb == 4 else torch.float64)
+    y = torch.full((csr.rows,), float("nan"), dtype=ws.dtype, device="cuda")
+    M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x.astype(csr.values.dtype)),
+            y=y, num_cols=csr.cols, workspace=ws, **kw)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), ws
+
+
+def check_strict(M, csr, x, y):
+    g, s = O.spmv_gold_acc64(csr, x.astype(csr.values.dtype))
+    ipt = M.launch_info(csr.rows, csr.nnz, csr.values.dtype.itemsize)["items_per_thread"]
+    ok, worst = O.strict_check(csr, y, g, s, items_per_thread=ipt)
+    assert ok, f"strict tolerance violated, worst ratio {worst}"
+    return worst
+
+
+def check_tiles(M, csr, x, ws):
+    """coords / carry keys bit-exact vs the oracle's tile emulation; carry values within tolerance."""
+    vb = csr.values.dtype.itemsize
+    info = M.launch_info(csr.rows, csr.nnz, vb)
+    coords, keys, vals = M.debug_read_tiles(ws.buffer, csr.rows, csr.nnz, vb)
+    want = O.tile_coords(csr, info["tile_items"])
+    assert np.array_equal(coords, want[: info["num_tiles"] + 1])
+    _, ck, cv = O.tiled_csrmv(csr, x.astype(csr.values.dtype), info["tile_items"])
+    assert np.array_equal(keys, ck)
+    assert np.allclose(vals, cv, rtol=1e-4 if vb == 4 else 1e-12, atol=1e-5 if vb == 4 else 1e-12)
+
+
+def test_known_answer_device_spmv(M, golden_kat):
+    """cub/device/device_spmv.cuh:90-123."""
+    k = golden_kat
+    for dtype in (np.float32, np.float64):
+        csr = O.Csr(k["rows"], k["cols"], np.asarray(k["row_offsets"], np.int32),
+                    np.asarray(k["column_indices"], np.int32), np.asarray(k["values"], dtype))
+        y, _ = run_gpu(M, csr, np.asarray(k["x"], dtype))
+        assert np.array_equal(y, np.asarray(k["y"], dtype))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["label"] for c in CASES])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_golden_matrices(M, case, prec):
+    dtype, vb = DT[prec]
+    args = [os.path.join(ROOT, case["args"][0])] if case["kind"] == "mtx" else case["args"]
+    csr = O.make(case["kind"], *args, dtype=dtype)
+    # the reference's protocol: x = 1 (gpu_spmv.cu:521-525) -> compare with SpmvGold
+    x = np.ones(csr.cols, dtype)
+    y, ws = run_gpu(M, csr, x)
+    gold = O.spmv_gold(csr, x)
+    assert O.compare_results(y, gold) == 0          # the reference's own PASS rule
+    check_strict(M, csr, x, y)
+    if case["kind"] != "mtx":
+        assert np.array_equal(y, gold)              # exact arithmetic: y = row length
+    check_tiles(M, csr, x, ws)
+    # a non-trivial x catches a wrong column gather (all-ones cannot)
+    x2 = np.arange(1, csr.cols + 1, dtype=dtype) * 0.5
+    y2, _ = run_gpu(M, csr, x2)
+    check_strict(M, csr, x2, y2)
+
+
+def random_csr(rng, rows, cols, lens, dtype):
+    off = np.zeros(rows + 1, dtype=np.int64); np.cumsum(lens, out=off[1:])
+    nnz = int(off[-1])
+    col = rng.integers(0, cols, size=nnz).astype(np.int32)
+    # sort columns within rows like CsrMatrix::Init (sparse_matrix.h:676)
+    rowid = np.repeat(np.arange(rows), lens)
+    order = np.lexsort((col, rowid))
+    col = col[order]
+    val = rng.uniform(-1, 1, size=nnz).astype(dtype)
+    return O.Csr(rows, cols, off.astype(np.int32), col, val)
+
+
+SHAPES = {
+    "uniform_short": lambda rng: (3000, 3000, rng.integers(0, 6, 3000)),
+    "uniform_32": lambda rng: (2000, 50000, np.full(2000, 32)),
+    "power_law": lambda rng: (5000, 5000, np.minimum((rng.pareto(1.2, 5000) * 3).astype(np.int64), 20000)),
+    "all_empty": lambda rng: (10000, 50, np.zeros(10000, np.int64)),
+    "leading_trailing_empty": lambda rng: (9000, 100, np.concatenate([np.zeros(4000, np.int64), rng.integers(1, 9, 1000), np.zeros(4000, np.int64)])),
+    "one_giant_row": lambda rng: (1, 777, np.array([200000])),
+    "giant_row_between_empties": lambda rng: (6001, 1000, np.concatenate([np.zeros(3000, np.int64), [150000], np.zeros(3000, np.int64)])),
+    "giant_plus_sprinkle": lambda rng: (40000, 40000, np.where(np.arange(40000) == 20000, 120000, (np.arange(40000) % 512 == 0).astype(np.int64))),
+    "single_col": lambda rng: (5000, 1, rng.integers(0, 3, 5000)),
+    "single_tile": lambda rng: (10, 10, rng.integers(0, 4, 10)),
+    "one_row_one_nnz": lambda rng: (1, 1, np.array([1])),
+    "exact_tile_multiple": lambda rng: (1792, 64, np.full(1792, 3)),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_random_and_degenerate_shapes(M, shape, prec):
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(abs(hash(shape)) % 2**32)
+    rows, cols, lens = SHAPES[shape](rng)
+    csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
+    x = rng.uniform(-1, 1, size=cols).astype(dtype)
+    y, ws = run_gpu(M, csr, x)
+    assert not np.isnan(y).any(), "a row was never written"
+    check_strict(M, csr, x, y)
+    check_tiles(M, csr, x, ws)
+    # bitwise reproducible (deterministic fix-up)
+    y_again, _ = run_gpu(M, csr, x)
+    assert np.array_equal(y, y_again)
+
+
+def test_empty_matrix_and_zero_rows(M):
+    for dtype in (np.float32, np.float64):
+        csr = O.Csr(0, 5, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, dtype))
+        y, _ = run_gpu(M, csr, np.ones(5, dtype))
+        assert y.size == 0
+        csr = O.Csr(7, 0, np.zeros(8, np.int32), np.zeros(0, np.int32), np.zeros(0, dtype))
+        y, _ = run_gpu(M, csr, np.ones(0, dtype))
+        assert np.array_equal(y, np.zeros(7, dtype))
+
+
+def test_all_ones_giant_row_is_exact(M):
+    """C4-style closed form: one row of 2^22 ones (exactly representable in fp32)."""
+    n = 1 << 22
+    lens = np.zeros(2049, np.int64); lens[1024] = n; lens[::256] += 1
+    rng = np.random.default_rng(3)
+    off = np.zeros(lens.size + 1, np.int64); np.cumsum(lens, out=off[1:])
+    nnz = int(off[-1])
+    csr = O.Csr(lens.size, 4096, off.astype(np.int32), (np.arange(nnz) % 4096).astype(np.int32), np.ones(nnz, np.float32))
+    y, _ = run_gpu(M, csr, np.ones(4096, np.float32))
+    assert np.array_equal(y, lens.astype(np.float32))
+
+
+@pytest.mark.parametrize("vb,block,ipt", [(4, 256, 5), (4, 256, 9), (4, 256, 11), (4, 128, 7), (4, 512, 7), (4, 256, 15),
+                                          (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
+    dtype = np.float32 if vb == 4 else np.float64
+    rng = np.random.default_rng(block * 100 + ipt)
+    lens = np.minimum((rng.pareto(1.1, 20000) * 2).astype(np.int64), 50000)
+    lens[7777] = 90000
+    csr = random_csr(rng, 20000, 20000, lens, dtype)
+    x = rng.uniform(-1, 1, size=csr.cols).astype(dtype)
+    try:
+        M.set_tuning(vb, block, ipt, flags)
+        info = M.launch_info(csr.rows, csr.nnz, vb)
+        assert (info["block_threads"], info["items_per_thread"], info["flags"]) == (block, ipt, flags)
+        y, ws = run_gpu(M, csr, x)
+        check_strict(M, csr, x, y)
+        if not (flags & 1):
+            check_tiles(M, csr, x, ws)
+    finally:
+        M.set_tuning(vb)
+
+
+def test_axpby_extension(M):
+    rng = np.random.default_rng(11)
+    for dtype in (np.float32, np.float64):
+        csr = random_csr(rng, 4000, 4000, rng.integers(0, 40, 4000), dtype)
+        x = rng.uniform(-1, 1, 4000).astype(dtype)
+        y0 = rng.uniform(-1, 1, 4000).astype(dtype)
+        g, s = O.spmv_gold_acc64(csr, x)
+        for alpha, beta in ((1.0, 0.0), (2.5, 0.0), (1.0, 1.0), (-0.5, 3.0)):
+            y = dev(y0.copy())
+            M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=y, alpha=alpha, beta=beta)
+            want = alpha * g + beta * y0.astype(np.float64)
+            tol = (2.0 ** -20 if dtype == np.float32 else 2.0 ** -48) * (abs(alpha) * s + abs(beta) * np.abs(y0) + 1e-30)
+            assert np.all(np.abs(y.cpu().numpy() - want) <= tol)
+        # beta == 0 must not read y (NaN there would poison it otherwise)
+        y = torch.full((4000,), float("nan"), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
+        M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=y, alpha=2.0, beta=0.0)
+        assert not torch.isnan(y).any()
+
+
+def test_two_phase_temp_storage_on_device(M):
+    csr = O.make("grid2d", 40, dtype=np.float32)
+    st, size = M.DeviceSpmv.CsrMV(None, 0, dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices),
+                                  dev(np.ones(csr.cols, np.float32)), torch.empty(csr.rows, device="cuda"),
+                                  csr.rows, csr.cols, csr.nnz)
+    assert st == 0 and size > 0
+    small = torch.empty(size - 1, dtype=torch.uint8, device="cuda")
+    st, _ = M.DeviceSpmv.CsrMV(small, size - 1, dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices),
+                               dev(np.ones(csr.cols, np.float32)), torch.empty(csr.rows, device="cuda"),
+                               csr.rows, csr.cols, csr.nnz)
+    assert st == 1
+
+
+def test_runs_on_a_side_stream_and_with_debug_sync(M, capfd):
+    csr = O.make("grid3d", 12, dtype=np.float64)
+    x = np.ones(csr.cols)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y, _ = run_gpu(M, csr, x, stream=s, debug_synchronous=True)
+    assert np.array_equal(y, O.spmv_gold(csr, x))
+    out = capfd.readouterr().out
+    assert "tile_kernel" in out and "search_kernel" in out
+
+
+def test_single_hip_runtime_loaded(M):
+    """libmspmv.so must bind to the HIP runtime torch already loaded."""
+    maps = open("/proc/self/maps").read()
+    libs = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+    assert any("libmspmv.so" in line for line in maps.splitlines())
+
+
+def test_full_size_c2_properties(M):
+    """BASELINE config 2 at full size (3.125M rows x 32 nnz/row = 100M nnz,
+    fp32): the oracle gold is O(seconds) in C/OpenMP, so check the strict
+    tolerance on every row, plus linearity A(ax+by) = aAx + bAy."""
+    from merge_spmv_amd import generators as G
+    rows = cols = 3_125_000
+    A = G.uniform_csr(rows, cols, 32, dtype=torch.float32, device="cuda")
+    x = G.uniform_pm1(G.SEED_C2 + 2, cols, torch.float32, "cuda")
+    ws = M.CsrMVWorkspace(rows, A.nnz, torch.float32)
+    y = M.csrmv(A.values, A.row_offsets, A.column_indices, x, workspace=ws)
+    torch.cuda.synchronize()
+    csr = O.Csr(rows, cols, A.row_offsets.cpu().numpy(), A.column_indices.cpu().numpy(), A.values.cpu().numpy())
+    xh = x.cpu().numpy()
+    g, s = O.spmv_gold_acc64(csr, xh)
+    ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=7)
+    assert ok, worst
+    x2 = G.uniform_pm1(99, cols, torch.float32, "cuda")
+    y2 = M.csrmv(A.values, A.row_offsets, A.column_indices, x2, workspace=ws).clone()
+    y3 = M.csrmv(A.values, A.row_offsets, A.column_indices, 2.0 * x - 0.5 * x2, workspace=ws)
+    lin = (2.0 * y.double() - 0.5 * y2.double())
+    err = (y3.double() - lin).abs()
+    assert float((err / (torch.from_numpy(s).cuda() * 2.0 ** -18 + 1e-12)).max()) <= 4.0
