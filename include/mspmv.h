@@ -118,6 +118,16 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
 
+/* Opt-in per-kernel timing with hipEvents recorded on the caller's stream
+ * around each of the three passes (the counterpart of the reference's
+ * GpuTimer, utils.h:624-658, at kernel granularity).  While active, every
+ * csrmv call (up to max_calls) records 4 events; mspmv_profile_end
+ * synchronises them, returns the number of profiled calls and the AVERAGE
+ * milliseconds per call of the search, tile and fix-up passes, and turns
+ * profiling off.  Process-global; not for concurrent host threads. */
+int mspmv_profile_begin(int32_t max_calls);
+int mspmv_profile_end(int32_t *calls, float *search_ms, float *tile_ms, float *fixup_ms);
+
 /* ---- multi-GPU merge partitioning (new design, the reference
  * has no multi-device code: its claim is README.md:5).  Host-side, 64-bit. --
  *

@@ -18,7 +18,7 @@ import os
 from typing import Optional, Tuple
 
 __all__ = ["DeviceSpmv", "csrmv", "CsrMVWorkspace", "library_path", "load_library", "launch_info",
-           "set_tuning", "debug_read_tiles", "MspmvError",
+           "set_tuning", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
            "TUNE_XCD_REMAP", "TUNE_ATOMIC_FIX"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -81,6 +81,10 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_debug_read_tiles.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     lib.mspmv_set_tuning.restype = ctypes.c_int
     lib.mspmv_set_tuning.argtypes = [i32, i32, i32, i32]
+    lib.mspmv_profile_begin.restype = ctypes.c_int
+    lib.mspmv_profile_begin.argtypes = [i32]
+    lib.mspmv_profile_end.restype = ctypes.c_int
+    lib.mspmv_profile_end.argtypes = [ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(ctypes.c_float)] * 3
     lib.mspmv_mg_partition.restype = ctypes.c_int
     lib.mspmv_mg_partition.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, i32, vp, vp]
     lib.mspmv_mg_local_offsets.restype = ctypes.c_int
@@ -207,6 +211,19 @@ def launch_info(num_rows: int, num_nonzeros: int, value_bytes: int) -> dict:
 def set_tuning(value_bytes: int, block_threads: int = 0, items_per_thread: int = 0, flags: int = 0) -> None:
     _check(load_library().mspmv_set_tuning(int(value_bytes), int(block_threads), int(items_per_thread), int(flags)),
            "mspmv_set_tuning")
+
+
+def profile_begin(max_calls: int) -> None:
+    """Record hipEvents around the three kernels of the next `max_calls` CsrMV calls."""
+    _check(load_library().mspmv_profile_begin(int(max_calls)), "mspmv_profile_begin")
+
+
+def profile_end() -> dict:
+    """Average per-call milliseconds of each pass since profile_begin()."""
+    calls = ctypes.c_int32()
+    ms = [ctypes.c_float() for _ in range(3)]
+    _check(load_library().mspmv_profile_end(ctypes.byref(calls), *[ctypes.byref(m) for m in ms]), "mspmv_profile_end")
+    return {"calls": calls.value, "search_ms": ms[0].value, "tile_ms": ms[1].value, "fixup_ms": ms[2].value}
 
 
 def debug_read_tiles(workspace_buffer, num_rows: int, num_nonzeros: int, value_bytes: int, stream=None):

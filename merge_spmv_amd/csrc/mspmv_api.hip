@@ -79,6 +79,19 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     return L;
 }
 
+// opt-in per-kernel event timing (mspmv_profile_begin/_end)
+struct Profiler {
+    std::vector<hipEvent_t> events;   // 4 per profiled call
+    int capacity = 0, calls = 0;
+    bool active = false;
+};
+static Profiler g_prof;
+
+static inline void prof_mark(hipStream_t stream, int slot, int which)
+{
+    if (slot >= 0) (void) hipEventRecord(g_prof.events[size_t(slot) * 4 + which], stream);
+}
+
 #define MSPMV_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *name, unsigned grid, unsigned block)
@@ -100,8 +113,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off);
     Carry<V> *carries = reinterpret_cast<Carry<V> *>(base + L.carries_off);
     const int tile_items = BLOCK * IPT;
+    const int slot = (g_prof.active && g_prof.calls < g_prof.capacity) ? g_prof.calls++ : -1;
 
     // 1. tile boundary search
+    prof_mark(stream, slot, 0);
     {
         const unsigned grid = (unsigned) ((L.num_tiles + 1 + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE));
         hipLaunchKernelGGL((search_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows,
@@ -109,6 +124,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         MSPMV_CHECK(after_launch(stream, debug_sync, "search_kernel", grid, SEARCH_BLOCK));
     }
     // 2. tiles
+    prof_mark(stream, slot, 1);
     {
         const unsigned grid = (unsigned) L.num_tiles;
         const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
@@ -122,6 +138,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel", grid, BLOCK));
     }
     // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair)
+    prof_mark(stream, slot, 2);
     if (L.num_tiles > 1) {
         if (L.flags & MSPMV_TUNE_ATOMIC_FIX) {
             const unsigned grid = (unsigned) ((L.num_tiles + FIX_BLOCK - 1) / FIX_BLOCK);
@@ -141,6 +158,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             }
         }
     }
+    prof_mark(stream, slot, 3);
     return hipSuccess;
 }
 
@@ -303,6 +321,38 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
             return hipSuccess;
         }
     return hipErrorInvalidValue;
+}
+
+int mspmv_profile_begin(int32_t max_calls)
+{
+    if (max_calls < 1 || max_calls > (1 << 20)) return hipErrorInvalidValue;
+    for (hipEvent_t e : g_prof.events) (void) hipEventDestroy(e);
+    g_prof.events.assign(size_t(max_calls) * 4, nullptr);
+    for (auto &e : g_prof.events) MSPMV_CHECK(hipEventCreate(&e));
+    g_prof.capacity = max_calls; g_prof.calls = 0; g_prof.active = true;
+    return hipSuccess;
+}
+
+int mspmv_profile_end(int32_t *calls, float *search_ms, float *tile_ms, float *fixup_ms)
+{
+    g_prof.active = false;
+    double acc[3] = {0, 0, 0};
+    for (int c = 0; c < g_prof.calls; ++c) {
+        MSPMV_CHECK(hipEventSynchronize(g_prof.events[size_t(c) * 4 + 3]));
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0;
+            MSPMV_CHECK(hipEventElapsedTime(&ms, g_prof.events[size_t(c) * 4 + k], g_prof.events[size_t(c) * 4 + k + 1]));
+            acc[k] += ms;
+        }
+    }
+    const int n = g_prof.calls;
+    if (calls) *calls = n;
+    if (search_ms) *search_ms = n ? float(acc[0] / n) : 0.f;
+    if (tile_ms) *tile_ms = n ? float(acc[1] / n) : 0.f;
+    if (fixup_ms) *fixup_ms = n ? float(acc[2] / n) : 0.f;
+    for (hipEvent_t e : g_prof.events) (void) hipEventDestroy(e);
+    g_prof.events.clear(); g_prof.capacity = 0; g_prof.calls = 0;
+    return hipSuccess;
 }
 
 int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries, const int64_t *row_split, int32_t parts,

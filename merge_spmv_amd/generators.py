@@ -75,20 +75,26 @@ class DeviceCsr:
 
 
 def uniform_csr(rows: int, cols: int, nnz_per_row: int, dtype=torch.float32, device="cuda",
-                seed: int = SEED_C2, chunk_rows: int = 1 << 19) -> DeviceCsr:
+                seed: int = SEED_C2, chunk_rows: int = 1 << 19, row_lo: int = 0,
+                row_hi: Optional[int] = None) -> DeviceCsr:
     """C2: exactly nnz_per_row entries per row, columns i.i.d. uniform over
     [0, cols) sorted within the row (duplicates kept), values uniform [-1,1)
-    from stream seed+1.  (x for the run: uniform_pm1(seed + 2, cols, ...).)"""
-    nnz = rows * nnz_per_row
+    from stream seed+1.  (x for the run: uniform_pm1(seed + 2, cols, ...).)
+    row_lo/row_hi restrict the output to a row range of the SAME global matrix
+    (counters are global), so ranks can build their swaths independently."""
+    row_hi = rows if row_hi is None else row_hi
+    n_rows = row_hi - row_lo
+    nnz = n_rows * nnz_per_row
     cols_out = torch.empty(nnz, dtype=torch.int32, device=device)
-    for r0 in range(0, rows, chunk_rows):
-        r1 = min(r0 + chunk_rows, rows)
+    for r0 in range(row_lo, row_hi, chunk_rows):
+        r1 = min(r0 + chunk_rows, row_hi)
         idx = torch.arange(r0 * nnz_per_row, r1 * nnz_per_row, dtype=torch.int64, device=device)
         c = (uniform01(seed, idx) * cols).to(torch.int64).clamp_(max=cols - 1)
         c = c.view(r1 - r0, nnz_per_row).sort(dim=1).values
-        cols_out[r0 * nnz_per_row: r1 * nnz_per_row] = c.reshape(-1).to(torch.int32)
-    offsets = (torch.arange(rows + 1, dtype=torch.int64, device=device) * nnz_per_row).to(torch.int32)
-    return DeviceCsr(rows, cols, offsets, cols_out, uniform_pm1(seed + 1, nnz, dtype, device))
+        cols_out[(r0 - row_lo) * nnz_per_row: (r1 - row_lo) * nnz_per_row] = c.reshape(-1).to(torch.int32)
+    offsets = (torch.arange(n_rows + 1, dtype=torch.int64, device=device) * nnz_per_row).to(torch.int32)
+    vals = uniform_pm1(seed + 1, nnz, dtype, device, start=row_lo * nnz_per_row)
+    return DeviceCsr(n_rows, cols, offsets, cols_out, vals)
 
 
 def dense_csr(rows: int, cols: int, dtype=torch.float32, device="cuda", ones: bool = True,

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""tools/sweep.py -- GPU tuning sweep: every compiled tile shape x flag set on
+a few workloads; prints a table of per-kernel milliseconds (hipEvents) and
+end-to-end ms.  Development aid, not part of the product or the tests.
+usage: python tools/sweep.py [workload ...]   (c2 dense32 c4 rmat grid)"""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import merge_spmv_amd as M
+from merge_spmv_amd import generators as G
+
+SHAPES = {4: [(256, 7), (256, 5), (256, 9), (256, 11), (128, 7), (512, 7), (256, 15)],
+          8: [(256, 5), (256, 3), (256, 7), (256, 9), (128, 5), (512, 5), (256, 11)]}
+
+
+def workloads(names):
+    for n in names:
+        if n == "c2":
+            A = G.uniform_csr(3_125_000, 3_125_000, 32, dtype=torch.float32)
+            yield "c2_f32", A, G.uniform_pm1(1, A.cols, torch.float32, "cuda")
+        elif n == "c2d":
+            A = G.uniform_csr(3_125_000, 3_125_000, 32, dtype=torch.float64)
+            yield "c2_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "dense32":
+            A = G.dense_csr(3_125_000, 32, dtype=torch.float32, ones=False)
+            yield "dense32_f32", A, G.uniform_pm1(1, A.cols, torch.float32, "cuda")
+        elif n == "dense32d":
+            A = G.dense_csr(3_125_000, 32, dtype=torch.float64, ones=False)
+            yield "dense32_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "c4":
+            A = G.degenerate_csr(dtype=torch.float32, ones=False)
+            yield "c4_f32", A, G.uniform_pm1(1, A.cols, torch.float32, "cuda")
+        elif n == "rmat":
+            A = G.rmat_csr(22, 60_000_000, dtype=torch.float64, seed=G.SEED_C3)
+            yield "rmat22_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "band":
+            # banded: 5 nnz/row near the diagonal (grid-like locality)
+            rows = 16_000_000
+            off = (torch.arange(rows + 1, dtype=torch.int64, device="cuda") * 5).to(torch.int32)
+            r = torch.arange(rows, dtype=torch.int64, device="cuda").repeat_interleave(5)
+            d = torch.tensor([-4000, -1, 0, 1, 4000], device="cuda").repeat(rows)
+            c = (r + d).clamp_(0, rows - 1).to(torch.int32)
+            A = G.DeviceCsr(rows, rows, off, c, G.uniform_pm1(2, rows * 5, torch.float32, "cuda"))
+            yield "band5_f32", A, G.uniform_pm1(1, rows, torch.float32, "cuda")
+
+
+def time_it(A, x, iters=30):
+    ws = M.CsrMVWorkspace(A.rows, A.nnz, A.values.dtype)
+    y = torch.empty(A.rows, dtype=A.values.dtype, device="cuda")
+    for _ in range(3):
+        M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=A.cols, workspace=ws)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=A.cols, workspace=ws)
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) / iters * 1e3
+    M.profile_begin(iters)
+    for _ in range(iters):
+        M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=A.cols, workspace=ws)
+    torch.cuda.synchronize()
+    p = M.profile_end()
+    return total, p
+
+
+def main():
+    names = sys.argv[1:] or ["c2", "dense32"]
+    flag_sets = [0, 1]
+    for label, A, x in workloads(names):
+        vb = A.values.element_size()
+        balg = A.nnz * (vb + 4) + (A.rows + 1) * 4 + A.rows * vb + A.cols * vb
+        print(f"== {label}: rows {A.rows} nnz {A.nnz}  B_alg {balg/1e6:.1f} MB", flush=True)
+        for (b, i) in SHAPES[vb]:
+            for fl in flag_sets:
+                M.set_tuning(vb, b, i, fl)
+                total, p = time_it(A, x)
+                print(f"  {b:4d}x{i:<3d} flags {fl}: total {total:8.4f} ms  search {p['search_ms']:.4f} tile {p['tile_ms']:.4f} "
+                      f"fix {p['fixup_ms']:.4f}  | {2*A.nnz/total/1e6:9.1f} GFLOP/s  alg {balg/p['tile_ms']/1e6:8.1f} GB/s", flush=True)
+        M.set_tuning(vb)
+        del A, x
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
