@@ -19,7 +19,7 @@ from typing import Optional, Tuple
 
 __all__ = ["DeviceSpmv", "csrmv", "CsrMVWorkspace", "library_path", "load_library", "launch_info",
            "set_tuning", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
-           "TUNE_XCD_REMAP", "TUNE_ATOMIC_FIX"]
+           "TUNE_XCD_REMAP", "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libmspmv.so"
@@ -27,6 +27,7 @@ _lib: Optional[ctypes.CDLL] = None
 
 TUNE_XCD_REMAP = 1
 TUNE_ATOMIC_FIX = 2
+TUNE_NO_VEC = 4
 
 
 class MspmvError(RuntimeError):

@@ -7,6 +7,7 @@
 // pure arithmetic on (rows, nnz), so a call is three kernel launches and
 // nothing else.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -24,7 +25,7 @@ constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 
 static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
 
-// Tile shapes compiled in.  The first entry per value type is the default.
+// Tile shapes compiled in (selectable with mspmv_set_tuning; defaults: pick_shape).
 struct Shape { int block, ipt; };
 static const Shape kShapesF32[] = {{256, 7}, {256, 5}, {256, 9}, {256, 11}, {128, 7}, {512, 7}, {256, 15}};
 static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128, 5}, {512, 5}, {256, 11}};
@@ -32,14 +33,18 @@ static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128,
 struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}; };
 static Tuning g_tune[2];  // [0] = 4-byte values, [1] = 8-byte values
 
-static Shape pick_shape(int value_bytes, int &flags)
+// Default shape: larger tiles amortise the per-tile fixed costs (coordinate loads, the
+// in-tile search, the block scan, two barriers) once there are enough tiles to fill the
+// chip several times over; smaller ones keep more blocks busy on small problems.
+// Measured on MI355X (tools/sweep.py): 256x11 (fp32) / 256x7 (fp64) win from ~8M items up.
+static Shape pick_shape(int value_bytes, long long items, int &flags)
 {
     Tuning &t = g_tune[value_bytes == 8];
     flags = t.flags.load();
-    const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
-    Shape s = tab[0];
-    if (t.block.load() > 0) { s.block = t.block.load(); s.ipt = t.ipt.load(); }
-    return s;
+    if (t.block.load() > 0) return Shape{t.block.load(), t.ipt.load()};
+    const bool large = items >= (8LL << 20);
+    if (value_bytes == 8) return large ? Shape{256, 7} : Shape{256, 5};
+    return large ? Shape{256, 11} : Shape{256, 7};
 }
 
 struct Layout {
@@ -53,8 +58,8 @@ struct Layout {
 static Layout make_layout(int rows, int nnz, int value_bytes)
 {
     Layout L; memset(&L, 0, sizeof(L));
-    L.shape = pick_shape(value_bytes, L.flags);
     const long long total = (long long) rows + nnz;
+    L.shape = pick_shape(value_bytes, total, L.flags);
     const int tile = L.shape.block * L.shape.ipt;
     L.num_tiles = (int) ((total + tile - 1) / tile);
     const uint64_t pair = value_bytes == 8 ? 16 : 8;
@@ -77,6 +82,20 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     }
     L.total = off > 0 ? off : 256;
     return L;
+}
+
+// CU count of the current device, queried once per device (never on the hot path again).
+static int device_cus()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 // opt-in per-kernel event timing (mspmv_profile_begin/_end)
@@ -115,25 +134,60 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     const int tile_items = BLOCK * IPT;
     const int slot = (g_prof.active && g_prof.calls < g_prof.capacity) ? g_prof.calls++ : -1;
 
-    // 1. tile boundary search
+    // 1. tile boundary coordinates
     prof_mark(stream, slot, 0);
-    {
+    if (L.flags & MSPMV_TUNE_BINARY_SEARCH) {
         const unsigned grid = (unsigned) ((L.num_tiles + 1 + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE));
         hipLaunchKernelGGL((search_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows,
                            p.nnz, tile_items, L.num_tiles, coords);
         MSPMV_CHECK(after_launch(stream, debug_sync, "search_kernel", grid, SEARCH_BLOCK));
+    } else {
+        const long long threads = ((long long) p.rows + 1 + 3) / 4;       // 4 row indices per thread
+        const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
+        const int *row_offsets = p.row_end - 1;
+        if ((reinterpret_cast<uintptr_t>(row_offsets) & 15) == 0)
+            hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true>), dim3(grid), dim3(SEARCH_BLOCK), 0,
+                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords);
+        else
+            hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, false>), dim3(grid), dim3(SEARCH_BLOCK), 0,
+                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
     }
     // 2. tiles
     prof_mark(stream, slot, 1);
     {
         const unsigned grid = (unsigned) L.num_tiles;
         const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
-        if (axpby) {
-            if (remap) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
-            else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        // 16-byte streaming needs 16-byte aligned array bases (hipMalloc gives 256) and at
+        // least one full 4-element chunk in each array
+        const bool vec = !(L.flags & MSPMV_TUNE_NO_VEC) && p.nnz >= 4 && p.rows >= 3 &&
+                         ((reinterpret_cast<uintptr_t>(p.values) | reinterpret_cast<uintptr_t>(p.cols) |
+                           reinterpret_cast<uintptr_t>(p.row_end - 1)) & 15) == 0;
+        if (vec) {
+            // resident grid: blocks_per_cu * CUs blocks walk the tiles with a software-prefetched stream
+            // (size the grid by what is actually resident: a block that has to wait for a slot
+            // would do its whole strided share of tiles after everyone else)
+            int per_cu = (L.flags >> 8) & 0xff;
+            if (per_cu == 0) {
+                static std::atomic<int> resident{0};           // one per <V, BLOCK, IPT> instantiation
+                per_cu = resident.load(std::memory_order_relaxed);
+                if (per_cu == 0) {
+                    int n = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tile_kernel_persistent<V, BLOCK, IPT, false, true>, BLOCK, 0) != hipSuccess || n < 1) n = 4;
+                    per_cu = std::min(n, 2048 / BLOCK);
+                    resident.store(per_cu, std::memory_order_relaxed);
+                }
+            }
+            const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
+#define MSPMV_LAUNCH_P(...) hipLaunchKernelGGL((tile_kernel_persistent<V, BLOCK, IPT, __VA_ARGS__>), dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles)
+            if ((L.flags >> 16) & 1) MSPMV_LAUNCH_P(false, false, 1);
+            else if (axpby) { if (remap) MSPMV_LAUNCH_P(true, true); else MSPMV_LAUNCH_P(true, false); }
+            else if (remap) MSPMV_LAUNCH_P(false, true);
+            else MSPMV_LAUNCH_P(false, false);
+#undef MSPMV_LAUNCH_P
         } else {
-            if (remap) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
-            else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+            if (axpby) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+            else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
         }
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel", grid, BLOCK));
     }
@@ -312,7 +366,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX)) return hipErrorInvalidValue;  // FUSED_SEARCH: not built yet
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | 0xff00 | 0x10000)) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)

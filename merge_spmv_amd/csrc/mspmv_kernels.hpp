@@ -28,6 +28,10 @@ namespace mspmv {
 
 constexpr int WAVE = 64;
 
+typedef int int4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+
 struct Coord {
     int x;  // row-ends consumed   (list A index)
     int y;  // nonzeros consumed   (list B index)
@@ -100,6 +104,78 @@ __global__ __launch_bounds__(BLOCK) void search_kernel(const int *__restrict__ r
 }
 
 // ---------------------------------------------------------------------------
+// The same coordinates by ONE coalesced pass over the row offsets instead of
+// num_tiles independent searches (each 4 dependent, scattered loads): the
+// merge position of row-end r is m_r = r + row_end[r] (r row-ends and
+// row_end[r] nonzeros precede it -- ties go to the row end, Appendix B.1), and
+// the point of diagonal d has x(d) = #{r : m_r < d}.  So thread r owns exactly
+// the tile boundaries d = t*tile_items with m_{r-1} < d <= m_r and writes
+// (r, d - r) for them; thread `rows` owns the boundaries past the last row end.
+// Usually a thread owns 0 or 1 boundary; a row longer than a tile owns many, and
+// a wave then fills one such row's run of boundaries cooperatively (a giant row
+// of 2^26 nonzeros owns ~37 000 of them).  Measured on MI355X: 3-15 us where
+// the search kernel took 27-52 us.
+// ---------------------------------------------------------------------------
+template <int BLOCK, int TILE_ITEMS, bool VEC>
+__global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__restrict__ row_offsets, int rows, int nnz,
+                                                               int num_tiles, Coord *__restrict__ coords)
+{
+    // With M(i) = (i - 1) + row_offsets[i] (i >= 1; the merge position of row-end i - 1) and
+    // M(0) = -1, row r owns the boundaries t with M(r) < t*TILE_ITEMS <= M(r + 1); row index
+    // `rows` owns the ones past M(rows).  A thread takes 4 consecutive r (one 16-byte load).
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long gid = (long long) blockIdx.x * BLOCK + threadIdx.x;
+    const int total = rows + nnz;                              // < 2^31
+    const long long base = gid * 4;                            // first r of this thread
+    int o[5];                                                  // row_offsets[base .. base + 4]
+    if (VEC && base + 4 <= rows) {
+        const int4v v = *reinterpret_cast<const int4v *>(row_offsets + base);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; o[4] = row_offsets[base + 4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) o[j] = base + j <= rows ? row_offsets[base + j] : 0;
+    }
+    int t_lo[4], t_hi[4];
+    bool any_long = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long r = base + j;
+        t_lo[j] = 1; t_hi[j] = 0;
+        if (r <= rows) {
+            const int m_lo = r == 0 ? -1 : (int) r - 1 + o[j];
+            t_lo[j] = m_lo < 0 ? 0 : m_lo / TILE_ITEMS + 1;
+            t_hi[j] = r < rows ? ((int) r + o[j + 1]) / TILE_ITEMS : num_tiles;
+            const int count = t_hi[j] - t_lo[j] + 1;
+            if (count > 0 && count <= 2) {
+                for (int t = t_lo[j]; t <= t_hi[j]; ++t) {
+                    const long long d = (long long) t * TILE_ITEMS;
+                    Coord c; c.x = (int) r; c.y = (int) (d < total ? d : total) - (int) r;
+                    coords[t] = c;
+                }
+            }
+            any_long |= count > 2;
+        }
+    }
+    // rows longer than two tiles: the wave fills each such run of boundaries together
+    if (__ballot(any_long) == 0ull) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned long long pending = __ballot(t_hi[j] - t_lo[j] + 1 > 2);
+        while (pending) {
+            const int src = __ffsll((long long) pending) - 1;
+            pending &= pending - 1;
+            const int lo = __shfl(t_lo[j], src, WAVE), hi = __shfl(t_hi[j], src, WAVE);
+            const int rr = (int) __shfl((int) base, src, WAVE) + j;
+            for (int t = lo + lane; t <= hi; t += WAVE) {
+                const long long d = (long long) t * TILE_ITEMS;
+                Coord c; c.x = rr; c.y = (int) (d < total ? d : total) - rr;
+                coords[t] = c;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // wave64 inclusive segmented (reduce-by-key) scan over one (key, value) pair
 // per lane.  Keys are non-decreasing across lanes (rows along the merge
 // path), so "same key" == "same segment"; the combine is the reference's
@@ -154,68 +230,61 @@ __device__ __forceinline__ void block_exclusive_rbk(int key, V val, int *s_wave_
 }
 
 // ---------------------------------------------------------------------------
-// The tile kernel.  ref: DeviceSpmvKernel / AgentSpmv::ConsumeTile,
-// dispatch_spmv_orig.cuh:157-186, agent_spmv_orig.cuh:413-639,856-914.
-// Everything inside a tile is tile-relative (row 0 == coords[tile].x,
-// nonzero 0 == coords[tile].y), so all indices are small.
-//   LDS: s_end[r]  = tile-relative nonzero index where tile row r ends, for
-//                    the tile_rows rows that end in the tile, then a +inf
-//                    sentinel for the row left open (the reference instead
-//                    loads row_end[tile_rows] -- one past the array for the
-//                    last tile);
-//        s_prod[j] = values[j] * x[cols[j]] for the tile's nonzeros.
+// Streaming loads.  The nonzero arrays and the row offsets are read exactly
+// once per SpMV: load them non-temporally so they do not evict x from the
+// XCD's 4 MiB L2 (measured: -7 % time on the 12.5 MB-x gather), 16 bytes per
+// lane (a dword-per-lane stream tops out at 4.0 TB/s on MI355X, 16 B/lane at
+// 6.4 TB/s).
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP>
-__global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *__restrict__ coords,
-                                                     Carry<V> *__restrict__ carries, int num_tiles)
+__device__ __forceinline__ int ld_stream(const int *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+
+template <typename T> struct Vec4;
+template <> struct Vec4<int> { int4v v; __device__ __forceinline__ int get(int i) const { return v[i]; } };
+template <> struct Vec4<float> { float4v v; __device__ __forceinline__ float get(int i) const { return v[i]; } };
+template <> struct Vec4<double> { double2v a, b; __device__ __forceinline__ double get(int i) const { return i < 2 ? a[i] : b[i - 2]; } };
+
+__device__ __forceinline__ Vec4<int> ld_stream4(const int *p)
+{ Vec4<int> r; r.v = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p)); return r; }
+__device__ __forceinline__ Vec4<float> ld_stream4(const float *p)
+{ Vec4<float> r; r.v = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(p)); return r; }
+__device__ __forceinline__ Vec4<double> ld_stream4(const double *p)
 {
-    constexpr int TILE = BLOCK * IPT;
-    constexpr int NW = BLOCK / WAVE;
-    __shared__ int s_end[TILE + 1];
-    __shared__ V s_prod[TILE];
-    __shared__ int s_wave_key[NW];
-    __shared__ V s_wave_val[NW];
+    Vec4<double> r;
+    r.a = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p));
+    r.b = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p) + 1);
+    return r;
+}
+__device__ __forceinline__ void st_lds4(float *p, const float (&v)[4])
+{ float4v w; w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3]; *reinterpret_cast<float4v *>(p) = w; }
+__device__ __forceinline__ void st_lds4(double *p, const double (&v)[4])
+{
+    double2v a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+    *reinterpret_cast<double2v *>(p) = a; *(reinterpret_cast<double2v *>(p) + 1) = b;
+}
+__device__ __forceinline__ void st_lds4(int *p, const int (&v)[4])
+{ int4v w; w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3]; *reinterpret_cast<int4v *>(p) = w; }
 
-    int tile = blockIdx.x;
-    if (XCD_REMAP) {
-        // Blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8);
-        // give each XCD (private 4 MiB L2) a contiguous range of tiles so that
-        // neighbouring tiles' x / row-offset lines share one L2.  Bijective
-        // for any num_tiles.  Placement only affects speed.
-        const int q = num_tiles / 8, r = num_tiles % 8;
-        const int xcd = tile % 8, idx = tile / 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+// ---------------------------------------------------------------------------
+// The LDS phases of a tile, shared by both tile kernels: per-thread merge-path
+// search on diagonal tid*IPT, the IPT-step path walk, the block-wide carry
+// scan, the y stores and the tile's carry-out.
+// ref: agent_spmv_orig.cuh:539-634,906-913.  Everything is tile-relative
+// (row 0 == c0.x, nonzero 0 == c0.y).
+//   s_end[r]  = tile-relative nonzero index where tile row r ends (r <
+//               tile_rows), +inf for the row left open at the tile end (the
+//               reference instead loads row_end[tile_rows] -- one past the
+//               array for the last tile);
+//   s_prod[j] = values[j] * x[cols[j]] for the tile's nonzeros.
+// ---------------------------------------------------------------------------
+template <typename V, int BLOCK, int IPT, bool AXPBY>
+__device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
+                                                 const int *s_end, const V *s_prod, int *s_wave_key, V *s_wave_val,
+                                                 Carry<V> *__restrict__ carry_out)
+{
     const int tid = threadIdx.x;
-
-    const Coord c0 = coords[tile];
-    const Coord c1 = coords[tile + 1];
-    const int tile_rows = c1.x - c0.x;
-    const int tile_nnz = c1.y - c0.y;
     const int tile_items = tile_rows + tile_nnz;
-
-    // ---- stream the tile's nonzeros (coalesced), gather x, stage products
-    const int *__restrict__ cols = p.cols + c0.y;
-    const V *__restrict__ vals = p.values + c0.y;
-    int col_r[IPT];
-    V val_r[IPT];
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        const int j = tid + k * BLOCK;
-        if (j < tile_nnz) { col_r[k] = cols[j]; val_r[k] = vals[j]; }
-    }
-    // ---- row-end offsets of the rows ending in this tile
-    const int *__restrict__ row_end = p.row_end + c0.x;
-    for (int r = tid; r < tile_rows; r += BLOCK) s_end[r] = row_end[r] - c0.y;
-    if (tid == 0) s_end[tile_rows] = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        const int j = tid + k * BLOCK;
-        if (j < tile_nnz) s_prod[j] = val_r[k] * p.x[col_r[k]];
-    }
-    __syncthreads();
-
-    // ---- per-thread merge-path search inside the tile (LDS), diagonal tid*IPT
     int diag = tid * IPT; diag = diag < tile_items ? diag : tile_items;
     int lo = diag - tile_nnz; lo = lo < 0 ? 0 : lo;
     int hi = diag < tile_rows ? diag : tile_rows;
@@ -227,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
     int nz = diag - lo;      // tile-relative nonzero it starts at
     int n_items = tile_items - diag; n_items = n_items < IPT ? n_items : IPT;
 
-    // ---- walk IPT path items
+    // walk IPT path items
     V *__restrict__ y = p.y + c0.x;
     int cur_end = s_end[row];
     V total = 0;
@@ -249,8 +318,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
             }
         }
     }
-
-    // ---- carry between threads: block-wide exclusive reduce-by-key scan
+    // carry between threads: block-wide exclusive reduce-by-key scan
     int prev_key, agg_key; V carry_in, agg_val;
     block_exclusive_rbk<V, BLOCK>(row, total, s_wave_key, s_wave_val, prev_key, carry_in, agg_key, agg_val);
     if (first_row >= 0) {
@@ -263,7 +331,225 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
     if (tid == BLOCK - 1) {
         // the row left open at the tile end (ref: agent_spmv_orig.cuh:906-913)
         Carry<V> c; c.key = c0.x + agg_key; c.value = agg_val;
-        carries[tile] = c;
+        *carry_out = c;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One block per tile, dword-per-lane staging: the fallback for CSR arrays
+// whose base addresses are not 16-byte aligned and for tiny matrices.
+// ref: DeviceSpmvKernel / AgentSpmv::ConsumeTile, dispatch_spmv_orig.cuh:157-186,
+// agent_spmv_orig.cuh:413-639,856-914.
+// ---------------------------------------------------------------------------
+template <typename V, int BLOCK, int IPT, bool AXPBY>
+__global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *__restrict__ coords,
+                                                     Carry<V> *__restrict__ carries, int num_tiles)
+{
+    constexpr int TILE = BLOCK * IPT;
+    constexpr int NW = BLOCK / WAVE;
+    __shared__ int s_end[TILE + 1];
+    __shared__ V s_prod[TILE];
+    __shared__ int s_wave_key[NW];
+    __shared__ V s_wave_val[NW];
+
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    const Coord c0 = coords[tile];
+    const Coord c1 = coords[tile + 1];
+    const int tile_rows = c1.x - c0.x;
+    const int tile_nnz = c1.y - c0.y;
+
+    const int *__restrict__ cols = p.cols + c0.y;
+    const V *__restrict__ vals = p.values + c0.y;
+    int col_r[IPT];
+    V val_r[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid + k * BLOCK;
+        if (j < tile_nnz) { col_r[k] = cols[j]; val_r[k] = vals[j]; }
+    }
+    const int *__restrict__ row_end = p.row_end + c0.x;
+    for (int r = tid; r < tile_rows; r += BLOCK) s_end[r] = row_end[r] - c0.y;
+    if (tid == 0) s_end[tile_rows] = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid + k * BLOCK;
+        if (j < tile_nnz) s_prod[j] = val_r[k] * p.x[col_r[k]];
+    }
+    __syncthreads();
+    consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end, s_prod, s_wave_key, s_wave_val,
+                                           carries + tile);
+}
+
+// ---------------------------------------------------------------------------
+// The production kernel: persistent, software-prefetched, 16-byte streaming.
+// A one-tile-per-block launch keeps loads in flight for only a fraction of a
+// block's life (coords -> nonzeros -> gather -> LDS phases form a dependent
+// chain), which caps a 32-wave/CU grid near 4 TB/s.  Here a resident block
+// walks tiles blockIdx.x, +gridDim.x, ... and requests the NEXT tile's
+// nonzeros (into the registers the current tile has just drained into LDS)
+// before it starts the current tile's LDS phases, so its HBM stream never
+// pauses.  Same per-tile arithmetic and carries as tile_kernel.
+//
+// Staging works on 4-element chunks aligned in ARRAY index space (the CSR
+// arrays are 16-byte aligned -- checked by the dispatcher -- but a tile starts
+// anywhere): chunk addresses are clamped to the last full chunk of the array
+// instead of being branched around, so every load is unconditional,
+// straight-line code (a branch per chunk made hipcc wait for each load before
+// issuing the next); elements outside the tile are predicated off, and the
+// <= 3 elements of a ragged array tail are read by scalar loads in a rarely
+// taken branch.  Nothing outside [0,nnz) / [0,rows] is ever read.
+// ---------------------------------------------------------------------------
+template <typename V, int BLOCK, int IPT>
+struct TileRegs {
+    static constexpr int CPT = IPT / 4 + 1;   // 4-element chunks per thread: covers TILE + 3
+    Vec4<int> col[CPT];
+    Vec4<V> val[CPT];
+};
+
+template <typename V, int BLOCK, int IPT>
+__device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
+                                                    TileRegs<V, BLOCK, IPT> &r)
+{
+    constexpr int CPT = IPT / 4 + 1;
+    const int a0 = c0.y & ~3;
+    const int last_full = (p.nnz & ~3) - 4;        // first element of the array's last full chunk (nnz >= 4)
+    const int safe = a0 < last_full ? a0 : last_full;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        int e0 = a0 + 4 * ((int) threadIdx.x + k * BLOCK);
+        // a chunk past the tile (it belongs to the next tile) or past the last full chunk of
+        // the array is not fetched: those lanes re-read the tile's first chunk instead (one
+        // cached address), so no byte of HBM traffic is spent on data this tile does not use
+        e0 = (e0 < c1.y && e0 <= last_full) ? e0 : safe;
+        r.col[k] = ld_stream4(p.cols + e0);
+        r.val[k] = ld_stream4(p.values + e0);
+    }
+}
+
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, int ABLATE = 0>
+__global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
+                                                                Carry<V> *__restrict__ carries, int num_tiles)
+{
+    constexpr int NW = BLOCK / WAVE;
+    constexpr int CPT = IPT / 4 + 1;
+    constexpr int SLOTS = CPT * BLOCK * 4;         // >= TILE + 8
+    __shared__ __attribute__((aligned(16))) int s_end_raw[SLOTS];
+    __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
+    __shared__ int s_wave_key[NW];
+    __shared__ V s_wave_val[NW];
+
+    const int tid = threadIdx.x;
+    // XCD_REMAP: blocks are dealt round-robin to the 8 XCDs (block b -> XCD
+    // b % 8, observed; only speed depends on it); give each XCD's private L2 a
+    // contiguous range of tiles.  Bijective for any num_tiles.
+    auto physical = [&](int t) {
+        if (!XCD_REMAP) return t;
+        const int q = num_tiles / 8, r = num_tiles % 8;
+        const int xcd = t % 8, idx = t / 8;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    };
+    int seq = blockIdx.x;
+    if (seq >= num_tiles) return;
+    int tile = physical(seq);
+    Coord c0 = coords[tile];
+    Coord c1 = coords[tile + 1];
+    TileRegs<V, BLOCK, IPT> regs;
+    issue_nonzero_loads<V, BLOCK, IPT>(p, c0, c1, regs);
+    const int *__restrict__ row_offsets = p.row_end - 1;
+    const int last_full_nz = (p.nnz & ~3) - 4;
+    const int last_full_ro = ((p.rows + 1) & ~3) - 4;   // rows + 1 >= 4
+
+    for (;;) {
+        const int tile_rows = c1.x - c0.x;
+        const int tile_nnz = c1.y - c0.y;
+        const int a0 = c0.y & ~3;
+        const int pshift = c0.y - a0;
+        const int first = c0.x + 1;                // d_row_offsets index of the tile's first row end
+        const int i0 = first & ~3;
+        const int eshift = first - i0;
+
+        // ---- row ends of the current tile -> LDS (chunks of d_row_offsets)
+        Vec4<int> ro[CPT];
+        const int ro_chunks = (tile_rows + eshift + 3) / 4;           // chunks holding a row end of this tile
+        const int ro_safe = i0 < last_full_ro ? i0 : last_full_ro;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int q = tid + k * BLOCK;
+            int i = i0 + 4 * q;
+            i = (q < ro_chunks && i <= last_full_ro) ? i : ro_safe;
+            ro[k] = ld_stream4(row_offsets + i);
+        }
+        // ---- gather x for the current tile (its nonzeros were requested one iteration ago)
+        V xv[CPT][4];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e0 = a0 + 4 * (tid + k * BLOCK);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
+                xv[k][i] = p.x[in ? regs.col[k].get(i) : 0];
+            }
+        }
+        // ---- next tile's coordinates
+        const int next_seq = seq + (int) gridDim.x;
+        const bool has_next = next_seq < num_tiles;
+        const int next = has_next ? physical(next_seq) : tile;
+        const Coord n0 = coords[next];
+        const Coord n1 = coords[next + 1];
+        // ---- stage row ends
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int q = tid + k * BLOCK;
+            const int i = i0 + 4 * q;
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * q - eshift + j;
+                const bool in = r >= 0 && r < tile_rows && i <= last_full_ro;
+                v[j] = in ? ro[k].get(j) - c0.y : 0x7fffffff;
+            }
+            st_lds4(&s_end_raw[4 * q], v);
+        }
+        // ---- stage products
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int chunk = tid + k * BLOCK;
+            const int e0 = a0 + 4 * chunk;
+            V prod[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
+                prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
+            }
+            st_lds4(&s_prod_raw[4 * chunk], prod);
+        }
+        // ---- ragged array tails (at most 3 elements each; only the tile that reaches the array
+        //      end).  Block-uniform branch; the barrier orders these writes after the zeros /
+        //      sentinels the chunk owners stored into the same slots above.
+        const bool nz_tail = c1.y > last_full_nz + 4;
+        const bool ro_tail = first + tile_rows > last_full_ro + 4;
+        if (nz_tail || ro_tail) {
+            __syncthreads();
+            const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
+            if (nz_tail && j < c1.y && j >= c0.y)
+                s_prod_raw[j - a0] = ld_stream(p.values + j) * p.x[ld_stream(p.cols + j)];
+            const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
+            const int r = i - first;
+            if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream(row_offsets + i) - c0.y;
+        }
+        __syncthreads();
+        // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
+        if (has_next) issue_nonzero_loads<V, BLOCK, IPT>(p, n0, n1, regs);
+        if (ABLATE == 1) {
+            // ablation (development): staging only -- keep the LDS data live, skip search/walk/scan
+            if (s_prod_raw[tid] == (V) 12345.678 && s_end_raw[tid] == 77) carries[tile].key = 1;
+        } else
+        consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw + pshift,
+                                               s_wave_key, s_wave_val, carries + tile);
+        if (!has_next) break;
+        __syncthreads();          // all LDS reads of this tile done before the next tile's staging writes
+        seq = next_seq; tile = next; c0 = n0; c1 = n1;
     }
 }
 

@@ -67,7 +67,12 @@ def check_tiles(M, csr, x, ws):
     assert np.array_equal(coords, want[: info["num_tiles"] + 1])
     _, ck, cv = O.tiled_csrmv(csr, x.astype(csr.values.dtype), info["tile_items"])
     assert np.array_equal(keys, ck)
-    assert np.allclose(vals, cv, rtol=1e-4 if vb == 4 else 1e-12, atol=1e-5 if vb == 4 else 1e-12)
+    # a carry is a sum of up to tile_items products of magnitude <= max|val*x|, summed in a
+    # different association order than the sequential emulation: bound the difference by
+    # eps * tile_items * max|val|*max|x| (cancellation makes a relative bound meaningless)
+    eps = 2.0 ** -23 if vb == 4 else 2.0 ** -52
+    scale = float(np.abs(csr.values).max(initial=0)) * float(np.abs(x).max(initial=0)) * info["tile_items"]
+    assert np.all(np.abs(vals.astype(np.float64) - cv.astype(np.float64)) <= eps * scale + 1e-300)
 
 
 def test_known_answer_device_spmv(M, golden_kat):
@@ -170,7 +175,7 @@ def test_all_ones_giant_row_is_exact(M):
 
 @pytest.mark.parametrize("vb,block,ipt", [(4, 256, 5), (4, 256, 9), (4, 256, 11), (4, 128, 7), (4, 512, 7), (4, 256, 15),
                                           (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
-@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 15])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)
@@ -230,7 +235,7 @@ def test_runs_on_a_side_stream_and_with_debug_sync(M, capfd):
         y, _ = run_gpu(M, csr, x, stream=s, debug_synchronous=True)
     assert np.array_equal(y, O.spmv_gold(csr, x))
     out = capfd.readouterr().out
-    assert "tile_kernel" in out and "search_kernel" in out
+    assert "tile_kernel" in out and "coords_scatter_kernel" in out
 
 
 def test_single_hip_runtime_loaded(M):

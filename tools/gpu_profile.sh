@@ -1,0 +1,41 @@
+#!/bin/bash
+# tools/gpu_profile.sh <tag> [bench args] -- run on the GPU box (via gpurun):
+# rocprofv3 kernel trace + stats of bench.py, then separate PMC passes (never
+# combined with sys/hip traces).  Raw output stays in /tmp; only summaries
+# (stats CSVs, mspmv kernel rows, per-kernel PMC sums) go to gpurun_out/prof_<tag>/.
+set -u
+TAG=${1:-r01}; shift || true
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+RAW=/tmp/prof_raw_$TAG
+rm -rf $OUT $RAW; mkdir -p $OUT $RAW
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o bench -- $BENCH > $OUT/bench_trace.log 2>&1
+tail -2 $OUT/bench_trace.log
+for f in $(find $RAW/trace -name "*stats*.csv"); do cp $f $OUT/; done
+KT=$(find $RAW/trace -name "*kernel_trace.csv" | head -1)
+if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_mspmv.csv; grep mspmv $KT | head -400 >> $OUT/kernel_trace_mspmv.csv; fi
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCP_TCC_READ_REQ_sum"; do
+  name=$(echo $pmc | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $RAW/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1
+  CC=$(find $RAW/pmc_$name -name "*counter_collection.csv" | head -1)
+  if [ -n "$CC" ]; then
+    python3 - "$CC" "$OUT/pmc_$name.summary.csv" <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    k = r.get("Kernel_Name", "")
+    if "mspmv" not in k: continue
+    short = k.split("(")[0].split("<")[0].split("::")[-1]
+    key = (short, r.get("Counter_Name", ""))
+    acc[key][0] += 1; acc[key][1] += float(r.get("Counter_Value", 0) or 0)
+with open(sys.argv[2], "w") as f:
+    f.write("kernel,counter,dispatches,sum,avg_per_dispatch\n")
+    for (k, c), (n, s) in sorted(acc.items()):
+        f.write(f"{k},{c},{n},{s},{s / n if n else 0}\n")
+print(open(sys.argv[2]).read())
+PY
+  else echo "no counter csv for $pmc"; tail -5 $OUT/pmc_$name.log; fi
+done
+ls -la $OUT; du -sh $OUT

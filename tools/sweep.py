@@ -65,7 +65,7 @@ def time_it(A, x, iters=30):
 
 def main():
     names = sys.argv[1:] or ["c2", "dense32"]
-    flag_sets = [0, 1]
+    flag_sets = [0, 8]
     for label, A, x in workloads(names):
         vb = A.values.element_size()
         balg = A.nnz * (vb + 4) + (A.rows + 1) * 4 + A.rows * vb + A.cols * vb
