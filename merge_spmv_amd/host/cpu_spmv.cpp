@@ -1,0 +1,165 @@
+// cpu_spmv.cpp -- OpenMP merge-path CsrMV driver: the reference's cpu_spmv
+// command line and report (cpu_spmv.cpp:682-747) without MKL.  This is the
+// PRODUCT CPU path (timed beside the GPU one); it shares no
+// code with the oracle.
+//
+//   cpu_spmv [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32] [--threads=<n>]
+//            [--alpha=<a>] [--beta=<b>]
+//            --mtx=<file> | --dense=<cols> | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
+//
+// Differences from the reference, all deliberate:
+//  * the per-thread carry arrays are sized by the thread count (the reference
+//    uses fixed [256] stack arrays, cpu_spmv.cpp:302-303, and smashes its stack
+//    beyond 256 threads);
+//  * the comparison column is a plain row-parallel OpenMP CsrMV ("OMP-row
+//    CsrMV") where the reference calls MKL (cpu_spmv.cpp:417-491);
+//  * besides the reference's vacuous PASS/FAIL rule, a strict per-row tolerance
+//    check is printed (--no-strict to skip);
+//  * --wheel is honoured (the reference never parses it, cpu_spmv.cpp:721-732).
+#include <omp.h>
+
+#include <cstring>
+#include <vector>
+
+#include "driver_common.hpp"
+
+using namespace mspmv_host;
+
+namespace {
+
+struct PathPoint { int row, nz; };
+
+// Diagonal search over row END offsets vs the natural numbers
+// (cpu_spmv.cpp:223-245): first row whose end offset exceeds diagonal - row - 1.
+inline PathPoint SearchDiagonal(int diagonal, const int *row_end, int rows, int nnz)
+{
+    int lo = std::max(diagonal - nnz, 0), hi = std::min(diagonal, rows);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row_end[mid] <= diagonal - mid - 1) lo = mid + 1; else hi = mid;
+    }
+    return PathPoint{std::min(lo, rows), diagonal - lo};
+}
+
+// y = A*x by merge-path decomposition over `segments` equal path segments
+// (OmpMergeCsrmv, cpu_spmv.cpp:292-353).  The association order depends on
+// `segments` only.
+template <typename V>
+void MergeCsrmv(int segments, int rows, int nnz, const int *row_end, const int *cols, const V *vals, const V *x, V *y,
+                std::vector<int> &carry_row, std::vector<V> &carry_val)
+{
+    carry_row.resize(segments); carry_val.resize(segments);
+    const long long total = (long long) rows + nnz;
+    const long long per_segment = (total + segments - 1) / segments;
+#pragma omp parallel for schedule(static) num_threads(segments)
+    for (int s = 0; s < segments; ++s) {
+        const int d0 = (int) std::min(per_segment * s, total);
+        const int d1 = (int) std::min((long long) d0 + per_segment, total);
+        PathPoint p = SearchDiagonal(d0, row_end, rows, nnz);
+        const PathPoint end = SearchDiagonal(d1, row_end, rows, nnz);
+        for (; p.row < end.row; ++p.row) {           // rows that end inside the segment
+            V sum = 0;
+            for (; p.nz < row_end[p.row]; ++p.nz) sum += vals[p.nz] * x[cols[p.nz]];
+            y[p.row] = sum;
+        }
+        V sum = 0;                                    // the row left open at the segment end
+        for (; p.nz < end.nz; ++p.nz) sum += vals[p.nz] * x[cols[p.nz]];
+        carry_row[s] = end.row; carry_val[s] = sum;
+    }
+    for (int s = 0; s + 1 < segments; ++s)            // cpu_spmv.cpp:348-352
+        if (carry_row[s] < rows) y[carry_row[s]] += carry_val[s];
+}
+
+template <typename V>
+void RowParallelCsrmv(int threads, int rows, const int *row_offsets, const int *cols, const V *vals, const V *x, V *y)
+{
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int r = 0; r < rows; ++r) {
+        V sum = 0;
+        for (int k = row_offsets[r]; k < row_offsets[r + 1]; ++k) sum += vals[k] * x[cols[k]];
+        y[r] = sum;
+    }
+}
+
+template <typename V, typename Fn>
+float TimeMethod(const RunConfig &c, const CsrMatrix<V> &a, const V *x, const V *gold, V *y, int iterations, int ipt_for_bound,
+                 Fn &&spmv)
+{
+    memset(y, -1, sizeof(V) * a.num_rows);            // NaN sentinel for unwritten rows (cpu_spmv.cpp:380)
+    spmv();
+    if (!c.quiet) {
+        const int bad = CompareResultsReferenceRule(y, gold, a.num_rows, true);
+        printf("\t%s\n", bad ? "FAIL" : "PASS");
+        if (c.strict) {
+            double worst = 0;
+            const long long v = StrictCheck(a.num_rows, a.row_offsets.data(), a.column_indices.data(), a.values.data(), x, y,
+                                            ipt_for_bound, &worst);
+            printf("\tstrict check: %s (%lld rows outside tolerance, worst ratio %.3g)\n", v ? "FAIL" : "PASS", v, worst);
+        }
+        fflush(stdout);
+    }
+    spmv(); spmv(); spmv();                           // re-populate caches (cpu_spmv.cpp:390-392)
+    CpuTimer timer;
+    timer.Start();
+    for (int it = 0; it < iterations; ++it) spmv();
+    timer.Stop();
+    return timer.ElapsedMillis() / iterations;
+}
+
+template <typename V>
+void Run(const RunConfig &c)
+{
+    CooMatrix<V> coo;
+    BuildInput(c, coo);
+    CsrMatrix<V> csr(coo);
+    coo.Clear();
+    ReportMatrix(c, csr);
+
+    int iterations = c.timing_iterations;
+    if (iterations == -1) {
+        iterations = AdaptiveIterations(csr.num_nonzeros, 200000ull);
+        if (!c.quiet) printf("\t%d timing iterations\n", iterations);
+    }
+    std::vector<V> x((size_t) csr.num_cols, (V) 1.0), y_in((size_t) csr.num_rows, (V) 1.0), gold((size_t) csr.num_rows),
+        y((size_t) csr.num_rows);
+    SpmvGold(csr, x.data(), y_in.data(), gold.data(), (V) c.alpha, (V) c.beta);
+
+    const int threads = c.threads > 0 ? c.threads : omp_get_num_procs();
+    const int *row_end = csr.row_offsets.data() + 1;
+
+    if (!c.quiet) printf("\n\n");
+    printf("OMP-row CsrMV, "); fflush(stdout);
+    float avg = TimeMethod(c, csr, x.data(), gold.data(), y.data(), iterations, 8, [&] {
+        RowParallelCsrmv(threads, csr.num_rows, csr.row_offsets.data(), csr.column_indices.data(), csr.values.data(), x.data(), y.data());
+    });
+    DisplayPerf(c.quiet, (int) sizeof(V), 0.0, avg, csr.num_rows, csr.num_nonzeros, -1);
+
+    if (!c.quiet) printf("\n\n");
+    printf("Merge CsrMV, "); fflush(stdout);
+    if (!c.quiet) printf("\tUsing %d threads on %d procs\n", threads, omp_get_num_procs());
+    std::vector<int> carry_row; std::vector<V> carry_val;
+    avg = TimeMethod(c, csr, x.data(), gold.data(), y.data(), iterations, 8, [&] {
+        MergeCsrmv(threads, csr.num_rows, csr.num_nonzeros, row_end, csr.column_indices.data(), csr.values.data(), x.data(),
+                   y.data(), carry_row, carry_val);
+    });
+    DisplayPerf(c.quiet, (int) sizeof(V), 0.0, avg, csr.num_rows, csr.num_nonzeros, -1);
+    if (!c.quiet) DisplayRoofline((int) sizeof(V), avg, csr.num_rows, csr.num_cols, csr.num_nonzeros, -1);
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    CommandLineArgs args(argc, argv);
+    if (args.CheckCmdLineFlag("help")) {
+        printf("%s [--quiet] [--v] [--v2] [--threads=<OMP threads>] [--i=<timing iterations>] [--fp32] "
+               "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--no-strict]\n"
+               "\t--mtx=<matrix market file>\n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
+               argv[0]);
+        return 0;
+    }
+    const RunConfig c = ParseCommon(args, false);
+    if (c.fp32) Run<float>(c); else Run<double>(c);
+    printf("\n");
+    return 0;
+}

@@ -1,0 +1,290 @@
+// gpu_spmv.cpp -- the MI355X driver with the reference's gpu_spmv command line
+// and report (gpu_spmv.cu:671-741): builds the CSR matrix on the host, uploads
+// it, runs the merge-based CsrMV through the drop-in boundary
+// (mspmv::DeviceSpmv::CsrMV -> include/mspmv.h) with the reference's protocol
+// (size query, allocate, reset y, one warm-up + verification, events around N
+// back-to-back calls; gpu_spmv.cu:376-435) and then the vendor library for
+// comparison: rocSPARSE CsrMV (analysis time reported as setup) and rocSPARSE
+// HybMV, where the reference ran cuSPARSE (gpu_spmv.cu:106-364,565-578).
+//
+//   gpu_spmv [--device=<id>] [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32]
+//            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor]
+//            --mtx=<file> | --dense=<cols> [--size=<nnz>] | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
+//
+// alpha/beta: the reference parses them but its CsrMV forces 1/0, so any other
+// value makes the reference print FAIL; here they are passed to the
+// y = alpha*A*x + beta*y extension of the C ABI.
+#include <hip/hip_runtime.h>
+#include <rocsparse/rocsparse.h>
+
+#include <cstring>
+#include <vector>
+
+#include "device_spmv.hpp"
+#include "driver_common.hpp"
+
+using namespace mspmv_host;
+
+#define HIP_OK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            fprintf(stderr, "HIP error %d (%s) at %s:%d\n", (int) e_, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                                  \
+        }                                                                                             \
+    } while (0)
+#define ROCSPARSE_OK(expr)                                                                            \
+    do {                                                                                              \
+        rocsparse_status s_ = (expr);                                                                 \
+        if (s_ != rocsparse_status_success) {                                                         \
+            fprintf(stderr, "rocSPARSE error %d at %s:%d\n", (int) s_, __FILE__, __LINE__);          \
+            exit(1);                                                                                  \
+        }                                                                                             \
+    } while (0)
+
+namespace {
+
+struct GpuTimer {                                       // utils.h:624-658 with hipEvents
+    hipEvent_t start, stop;
+    GpuTimer() { HIP_OK(hipEventCreate(&start)); HIP_OK(hipEventCreate(&stop)); }
+    ~GpuTimer() { (void) hipEventDestroy(start); (void) hipEventDestroy(stop); }
+    void Start() { HIP_OK(hipEventRecord(start, 0)); }
+    void Stop() { HIP_OK(hipEventRecord(stop, 0)); }
+    float ElapsedMillis() { float ms; HIP_OK(hipEventSynchronize(stop)); HIP_OK(hipEventElapsedTime(&ms, start, stop)); return ms; }
+};
+
+struct Device {
+    hipDeviceProp_t prop;
+    double giga_bandwidth = 0;
+    int id = 0;
+};
+
+// args.DeviceInit() (utils.h:451-515): out-of-range ids fall back to device 0.
+Device DeviceInit(const RunConfig &c)
+{
+    Device d;
+    int count = 0;
+    HIP_OK(hipGetDeviceCount(&count));
+    if (count == 0) { fprintf(stderr, "No devices supporting HIP.\n"); exit(1); }
+    d.id = (c.device >= 0 && c.device < count) ? c.device : 0;
+    HIP_OK(hipSetDevice(d.id));
+    HIP_OK(hipGetDeviceProperties(&d.prop, d.id));
+    size_t free_b = 0, total_b = 0;
+    HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    // the reference's formula (utils.h:491) underestimates HBM3E; MI355X datasheet peak is 8 TB/s
+    d.giga_bandwidth = double(d.prop.memoryBusWidth) * d.prop.memoryClockRate * 2 / 8 / 1000 / 1000;
+    if (strstr(d.prop.gcnArchName, "gfx950")) d.giga_bandwidth = 8000.0;
+    if (c.peak_gbs > 0) d.giga_bandwidth = c.peak_gbs;
+    if (!c.quiet) {
+        printf("Using device %d: %s (%s, %d CUs, %lld free / %lld total MB physmem, %.3f GB/s @ %d kHz mem clock, ECC %s)\n",
+               d.id, d.prop.name, d.prop.gcnArchName, d.prop.multiProcessorCount, (long long) free_b / 1024 / 1024,
+               (long long) total_b / 1024 / 1024, d.giga_bandwidth, d.prop.memoryClockRate, d.prop.ECCEnabled ? "on" : "off");
+        fflush(stdout);
+    }
+    return d;
+}
+
+template <typename V>
+struct DeviceProblem {
+    V *d_values = nullptr, *d_x = nullptr, *d_y = nullptr;
+    int *d_row_offsets = nullptr, *d_cols = nullptr;
+    int rows = 0, cols = 0, nnz = 0;
+    void Upload(const CsrMatrix<V> &a, const std::vector<V> &x)
+    {
+        rows = a.num_rows; cols = a.num_cols; nnz = a.num_nonzeros;
+        HIP_OK(hipMalloc(&d_values, sizeof(V) * std::max(nnz, 1)));
+        HIP_OK(hipMalloc(&d_row_offsets, sizeof(int) * (rows + 1)));
+        HIP_OK(hipMalloc(&d_cols, sizeof(int) * std::max(nnz, 1)));
+        HIP_OK(hipMalloc(&d_x, sizeof(V) * std::max(cols, 1)));
+        HIP_OK(hipMalloc(&d_y, sizeof(V) * std::max(rows, 1)));
+        HIP_OK(hipMemcpy(d_values, a.values.data(), sizeof(V) * nnz, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_row_offsets, a.row_offsets.data(), sizeof(int) * (rows + 1), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_cols, a.column_indices.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_x, x.data(), sizeof(V) * cols, hipMemcpyHostToDevice));
+    }
+    ~DeviceProblem()
+    {
+        (void) hipFree(d_values); (void) hipFree(d_row_offsets); (void) hipFree(d_cols); (void) hipFree(d_x); (void) hipFree(d_y);
+    }
+};
+
+template <typename V>
+void Verify(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &gold, const V *d_y,
+            bool alpha_beta_default)
+{
+    std::vector<V> y((size_t) a.num_rows);
+    HIP_OK(hipMemcpy(y.data(), d_y, sizeof(V) * a.num_rows, hipMemcpyDeviceToHost));
+    if (c.verbose) {
+        printf("\nReference / computed:\n");
+        for (int r = 0; r < a.num_rows; ++r) printf("[%d] %g %g\n", r, (double) gold[r], (double) y[r]);
+    }
+    const int bad = CompareResultsReferenceRule(y.data(), gold.data(), a.num_rows, true);
+    printf("\t%s\n", bad ? "FAIL" : "PASS");
+    if (c.strict && alpha_beta_default) {
+        double worst = 0;
+        const long long v = StrictCheck(a.num_rows, a.row_offsets.data(), a.column_indices.data(), a.values.data(), x.data(),
+                                        y.data(), 16, &worst);
+        printf("\tstrict check: %s (%lld rows outside tolerance, worst ratio %.3g)\n", v ? "FAIL" : "PASS", v, worst);
+    }
+    fflush(stdout);
+}
+
+// TestGpuMergeCsrmv (gpu_spmv.cu:376-435)
+template <typename V>
+float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
+                const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms)
+{
+    setup_ms = 0;
+    const bool plain = c.alpha == 1.0f && c.beta == 0.0f;
+    auto call = [&](void *temp, size_t &bytes, bool debug) {
+        return plain ? mspmv::DeviceSpmv::CsrMV(temp, bytes, p.d_values, p.d_row_offsets, p.d_cols, p.d_x, p.d_y, p.rows, p.cols,
+                                                p.nnz, (hipStream_t) 0, debug)
+                     : mspmv::DeviceSpmv::CsrMV(temp, bytes, p.d_values, p.d_row_offsets, p.d_cols, p.d_x, p.d_y, p.rows, p.cols,
+                                                p.nnz, (V) c.alpha, (V) c.beta, (hipStream_t) 0, debug);
+    };
+    size_t temp_bytes = 0;
+    void *d_temp = nullptr;
+    HIP_OK(call(nullptr, temp_bytes, false));
+    HIP_OK(hipMalloc(&d_temp, temp_bytes));
+    HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));
+    HIP_OK(call(d_temp, temp_bytes, !c.quiet));                      // warm-up (+ launch log, like debug_synchronous)
+    if (!c.quiet) Verify(c, a, x, gold, p.d_y, plain);
+    GpuTimer timer;
+    timer.Start();
+    for (int it = 0; it < iterations; ++it) HIP_OK(call(d_temp, temp_bytes, false));
+    timer.Stop();
+    const float ms = timer.ElapsedMillis() / iterations;
+    HIP_OK(hipFree(d_temp));
+    return ms;
+}
+
+template <typename V> struct Roc;
+template <> struct Roc<float> {
+    static constexpr auto analysis = rocsparse_scsrmv_analysis; static constexpr auto csrmv = rocsparse_scsrmv;
+    static constexpr auto csr2hyb = rocsparse_scsr2hyb; static constexpr auto hybmv = rocsparse_shybmv;
+};
+template <> struct Roc<double> {
+    static constexpr auto analysis = rocsparse_dcsrmv_analysis; static constexpr auto csrmv = rocsparse_dcsrmv;
+    static constexpr auto csr2hyb = rocsparse_dcsr2hyb; static constexpr auto hybmv = rocsparse_dhybmv;
+};
+
+// rocSPARSE CsrMV, the counterpart of TestCusparseCsrmv (gpu_spmv.cu:262-364); setup = analysis
+template <typename V>
+float TestRocsparseCsrmv(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
+                         const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms,
+                         rocsparse_handle handle)
+{
+    rocsparse_mat_descr descr; rocsparse_mat_info info;
+    ROCSPARSE_OK(rocsparse_create_mat_descr(&descr));
+    ROCSPARSE_OK(rocsparse_create_mat_info(&info));
+    CpuTimer setup; HIP_OK(hipDeviceSynchronize()); setup.Start();
+    ROCSPARSE_OK(Roc<V>::analysis(handle, rocsparse_operation_none, p.rows, p.cols, p.nnz, descr, p.d_values, p.d_row_offsets,
+                                  p.d_cols, info));
+    HIP_OK(hipDeviceSynchronize()); setup.Stop();
+    setup_ms = setup.ElapsedMillis();
+    const V alpha = (V) c.alpha, beta = (V) c.beta;
+    HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));
+    ROCSPARSE_OK(Roc<V>::csrmv(handle, rocsparse_operation_none, p.rows, p.cols, p.nnz, &alpha, descr, p.d_values,
+                               p.d_row_offsets, p.d_cols, info, p.d_x, &beta, p.d_y));
+    if (!c.quiet) Verify(c, a, x, gold, p.d_y, c.alpha == 1.0f && c.beta == 0.0f);
+    GpuTimer timer; timer.Start();
+    for (int it = 0; it < iterations; ++it)
+        ROCSPARSE_OK(Roc<V>::csrmv(handle, rocsparse_operation_none, p.rows, p.cols, p.nnz, &alpha, descr, p.d_values,
+                                   p.d_row_offsets, p.d_cols, info, p.d_x, &beta, p.d_y));
+    timer.Stop();
+    const float ms = timer.ElapsedMillis() / iterations;
+    ROCSPARSE_OK(rocsparse_destroy_mat_info(info));
+    ROCSPARSE_OK(rocsparse_destroy_mat_descr(descr));
+    return ms;
+}
+
+// rocSPARSE HybMV, the counterpart of TestCusparseHybmv (gpu_spmv.cu:106-257); setup = CSR -> HYB
+template <typename V>
+float TestRocsparseHybmv(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
+                         const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms,
+                         rocsparse_handle handle)
+{
+    rocsparse_mat_descr descr; rocsparse_hyb_mat hyb;
+    ROCSPARSE_OK(rocsparse_create_mat_descr(&descr));
+    ROCSPARSE_OK(rocsparse_create_hyb_mat(&hyb));
+    CpuTimer setup; HIP_OK(hipDeviceSynchronize()); setup.Start();
+    ROCSPARSE_OK(Roc<V>::csr2hyb(handle, p.rows, p.cols, descr, p.d_values, p.d_row_offsets, p.d_cols, hyb, 0,
+                                 rocsparse_hyb_partition_auto));
+    HIP_OK(hipDeviceSynchronize()); setup.Stop();
+    setup_ms = setup.ElapsedMillis();
+    const V alpha = (V) c.alpha, beta = (V) c.beta;
+    HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));   // (the reference copies sizeof(float) here, gpu_spmv.cu:213)
+    ROCSPARSE_OK(Roc<V>::hybmv(handle, rocsparse_operation_none, &alpha, descr, hyb, p.d_x, &beta, p.d_y));
+    if (!c.quiet) Verify(c, a, x, gold, p.d_y, c.alpha == 1.0f && c.beta == 0.0f);
+    GpuTimer timer; timer.Start();
+    for (int it = 0; it < iterations; ++it)
+        ROCSPARSE_OK(Roc<V>::hybmv(handle, rocsparse_operation_none, &alpha, descr, hyb, p.d_x, &beta, p.d_y));
+    timer.Stop();
+    const float ms = timer.ElapsedMillis() / iterations;
+    ROCSPARSE_OK(rocsparse_destroy_hyb_mat(hyb));
+    ROCSPARSE_OK(rocsparse_destroy_mat_descr(descr));
+    return ms;
+}
+
+template <typename V>
+void Run(const RunConfig &c, const Device &dev, bool vendor)
+{
+    CooMatrix<V> coo;
+    BuildInput(c, coo);
+    int iterations = c.timing_iterations;
+    if (iterations == -1) iterations = AdaptiveIterations(coo.num_nonzeros(), 50000ull);
+    if (!c.quiet) printf("\t%d timing iterations\n", iterations);      // gpu_spmv.cu:495-496
+    CsrMatrix<V> csr(coo);
+    coo.Clear();
+    ReportMatrix(c, csr);
+
+    std::vector<V> x((size_t) csr.num_cols, (V) 1.0), y_in((size_t) csr.num_rows, (V) 1.0), gold((size_t) csr.num_rows);
+    SpmvGold(csr, x.data(), y_in.data(), gold.data(), (V) c.alpha, (V) c.beta);
+    if (c.quiet) { printf("%s, %s, ", dev.prop.name, sizeof(V) > 4 ? "fp64" : "fp32"); fflush(stdout); }
+
+    DeviceProblem<V> p;
+    p.Upload(csr, x);
+    float setup_ms = 0, avg_ms = 0;
+
+    if (!c.quiet) printf("\n\n");
+    printf("Merge-based CsrMV, "); fflush(stdout);
+    avg_ms = TestMerge(c, csr, x, y_in, gold, p, iterations, setup_ms);
+    DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+    if (!c.quiet) DisplayRoofline((int) sizeof(V), avg_ms, csr.num_rows, csr.num_cols, csr.num_nonzeros, dev.giga_bandwidth);
+
+    if (vendor) {
+        rocsparse_handle handle;
+        ROCSPARSE_OK(rocsparse_create_handle(&handle));
+        if (!c.quiet) printf("\n\n");
+        printf("rocSPARSE CsrMV, "); fflush(stdout);
+        avg_ms = TestRocsparseCsrmv(c, csr, x, y_in, gold, p, iterations, setup_ms, handle);
+        DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+        if (!c.quiet) printf("\n\n");
+        printf("rocSPARSE HybMV, "); fflush(stdout);
+        avg_ms = TestRocsparseHybmv(c, csr, x, y_in, gold, p, iterations, setup_ms, handle);
+        DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+        ROCSPARSE_OK(rocsparse_destroy_handle(handle));
+    }
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    CommandLineArgs args(argc, argv);
+    if (args.CheckCmdLineFlag("help")) {
+        printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
+               "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
+               "[--no-strict] [--no-vendor]\n"
+               "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
+               argv[0]);
+        return 0;
+    }
+    const RunConfig c = ParseCommon(args, true);
+    const Device dev = DeviceInit(c);
+    const bool vendor = !args.CheckCmdLineFlag("no-vendor");
+    if (c.fp32) Run<float>(c, dev, vendor); else Run<double>(c, dev, vendor);
+    HIP_OK(hipDeviceSynchronize());
+    printf("\n");
+    return 0;
+}

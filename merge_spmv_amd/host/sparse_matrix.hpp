@@ -1,0 +1,314 @@
+// sparse_matrix.hpp -- host data model of the MI355X merge-based CsrMV drivers.
+//
+// Reproduces the BEHAVIOUR of the reference's sparse_matrix.h (the CSR input
+// layout north_star says to keep, plus its Matrix Market reader, synthetic
+// generators, statistics and histogram) with a different design:
+//   * COO is structure-of-arrays (row[], col[], val[]) instead of an array of
+//     tuples, and is built straight into std::vector storage;
+//   * COO -> CSR is a stable counting sort by row followed by an independent,
+//     OpenMP-parallel stable sort by column inside each row -- the same order
+//     as the reference's single-threaded std::stable_sort by (row, col)
+//     (sparse_matrix.h:636-643,676; duplicates kept), but O(nnz) + parallel,
+//     which is what SURVEY.md 8(f) N2 asks for at corpus scale;
+//   * no MKL / libnuma allocation paths (sparse_matrix.h:679-699).
+// Each function cites the reference lines whose behaviour it matches; the
+// parity tests (tests/test_host_model.py) compare against golden vectors
+// produced by the reference's own header.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mspmv_host {
+
+/// Row-length statistics (reference GraphStats, sparse_matrix.h:59-107).
+struct GraphStats {
+    int num_rows = 0, num_cols = 0, num_nonzeros = 0;
+    double row_length_mean = 0, row_length_std_dev = 0, row_length_variation = 0, row_length_skewness = 0;
+
+    /// Labelled (human) or CSV form; byte-for-byte the reference's formats
+    /// (sparse_matrix.h:72-106).
+    void Display(bool show_labels, FILE *out = stdout) const
+    {
+        if (show_labels)
+            fprintf(out,
+                    "\n"
+                    "\t num_rows: %d\n"
+                    "\t num_cols: %d\n"
+                    "\t num_nonzeros: %d\n"
+                    "\t row_length_mean: %.5f\n"
+                    "\t row_length_std_dev: %.5f\n"
+                    "\t row_length_variation: %.5f\n"
+                    "\t row_length_skewness: %.5f\n",
+                    num_rows, num_cols, num_nonzeros, row_length_mean, row_length_std_dev, row_length_variation,
+                    row_length_skewness);
+        else
+            fprintf(out, "%d, %d, %d, %.5f, %.5f, %.5f, %.5f, ", num_rows, num_cols, num_nonzeros, row_length_mean,
+                    row_length_std_dev, row_length_variation, row_length_skewness);
+    }
+};
+
+struct MarketError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+/// Coordinate-format matrix in emission order (not necessarily sorted).
+template <typename ValueT>
+struct CooMatrix {
+    int num_rows = 0, num_cols = 0;
+    std::vector<int> row, col;
+    std::vector<ValueT> val;
+
+    int num_nonzeros() const { return (int) row.size(); }
+    void Clear() { std::vector<int>().swap(row); std::vector<int>().swap(col); std::vector<ValueT>().swap(val); }
+    void Reserve(size_t n) { row.reserve(n); col.reserve(n); val.reserve(n); }
+    void Push(int r, int c, ValueT v) { row.push_back(r); col.push_back(c); val.push_back(v); }
+
+    /// Dense rows x cols, row-major, all = default_value (InitDense, sparse_matrix.h:386-413).
+    void InitDense(int rows, int cols, ValueT default_value = 1.0)
+    {
+        num_rows = rows; num_cols = cols;
+        const size_t n = (size_t) rows * cols;
+        row.resize(n); col.resize(n); val.assign(n, default_value);
+#pragma omp parallel for schedule(static)
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) { row[(size_t) r * cols + c] = r; col[(size_t) r * cols + c] = c; }
+    }
+
+    /// Hub-and-rim wheel with `spokes` spokes (InitWheel, sparse_matrix.h:419-452).
+    void InitWheel(int spokes, ValueT default_value = 1.0)
+    {
+        num_rows = num_cols = spokes + 1;
+        Reserve((size_t) spokes * 2);
+        for (int i = 0; i < spokes; ++i) Push(0, i + 1, default_value);
+        for (int i = 0; i < spokes; ++i) Push(i + 1, (i + 1) % spokes + 1, default_value);
+    }
+
+    /// width^2 lattice, neighbours emitted W, E, N, S (+ self) (InitGrid2d, sparse_matrix.h:461-526).
+    void InitGrid2d(int width, bool self_loop, ValueT default_value = 1.0)
+    {
+        num_rows = num_cols = width * width;
+        Reserve((size_t) num_rows * (self_loop ? 5 : 4));
+        for (int j = 0; j < width; ++j)
+            for (int k = 0; k < width; ++k) {
+                const int me = j * width + k;
+                if (k - 1 >= 0) Push(me, me - 1, default_value);
+                if (k + 1 < width) Push(me, me + 1, default_value);
+                if (j - 1 >= 0) Push(me, me - width, default_value);
+                if (j + 1 < width) Push(me, me + width, default_value);
+                if (self_loop) Push(me, me, default_value);
+            }
+    }
+
+    /// width^3 lattice, neighbours k-1, k+1, j-1, j+1, i-1, i+1 (+ self) (InitGrid3d, sparse_matrix.h:533-617).
+    void InitGrid3d(int width, bool self_loop, ValueT default_value = 1.0)
+    {
+        const int w = width, w2 = width * width;
+        num_rows = num_cols = w2 * w;
+        Reserve((size_t) num_rows * (self_loop ? 7 : 6));
+        for (int i = 0; i < w; ++i)
+            for (int j = 0; j < w; ++j)
+                for (int k = 0; k < w; ++k) {
+                    const int me = i * w2 + j * w + k;
+                    if (k - 1 >= 0) Push(me, me - 1, default_value);
+                    if (k + 1 < w) Push(me, me + 1, default_value);
+                    if (j - 1 >= 0) Push(me, me - w, default_value);
+                    if (j + 1 < w) Push(me, me + w, default_value);
+                    if (i - 1 >= 0) Push(me, me - w2, default_value);
+                    if (i + 1 < w) Push(me, me + w2, default_value);
+                    if (self_loop) Push(me, me, default_value);
+                }
+    }
+
+    /// Matrix Market reader with the reference's quirks (InitMarket, sparse_matrix.h:217-380):
+    /// banner flags are substring tests for "symmetric", "skew", "array" only (:265-267);
+    /// a line of >= 1024 characters, or a last line without a newline, ends parsing
+    /// (getline(line,1024) + good() test, :244-250); indices by strtol base 0 (:330-345);
+    /// a missing value becomes default_value (:351-355); entries are 1-based (:357);
+    /// symmetric input mirrors off-diagonal entries, negated when skew (:362-368);
+    /// array format is column-major and NOT index-shifted (:316-324); the final
+    /// nonzero count is the number of entries produced (:373).
+    /// Throws MarketError where the reference prints to stderr and exit(1)s.
+    void InitMarket(const std::string &filename, ValueT default_value = 1.0, bool verbose = false)
+    {
+        if (verbose) { printf("Reading... "); fflush(stdout); }
+        std::ifstream ifs(filename.c_str(), std::ifstream::in);
+        if (!ifs.good()) throw MarketError("Error opening file");
+        bool array = false, symmetric = false, skew = false;
+        long long declared = 0, current = -1;
+        char line[1024];
+        if (verbose) { printf("Parsing... "); fflush(stdout); }
+        for (;;) {
+            ifs.getline(line, 1024);
+            if (!ifs.good()) break;
+            if (line[0] == '%') {
+                if (line[1] == '%') {
+                    symmetric = strstr(line, "symmetric") != nullptr;
+                    skew = strstr(line, "skew") != nullptr;
+                    array = strstr(line, "array") != nullptr;
+                    if (verbose) { printf("(symmetric: %d, skew: %d, array: %d) ", symmetric, skew, array); fflush(stdout); }
+                }
+                continue;
+            }
+            if (current == -1) {
+                int nz = 0;
+                const int parsed = sscanf(line, "%d %d %d", &num_rows, &num_cols, &nz);
+                if (!array && parsed == 3) declared = symmetric ? 2LL * nz : nz;
+                else if (array && parsed == 2) declared = (long long) num_rows * num_cols;
+                else throw MarketError(std::string("Error parsing MARKET matrix: invalid problem description: ") + line);
+                Reserve((size_t) declared);
+                current = 0;
+                continue;
+            }
+            if (current >= declared)
+                throw MarketError("Error parsing MARKET matrix: encountered more than " + std::to_string(declared) + " num_nonzeros");
+            int r, c; double v;
+            if (array) {
+                if (sscanf(line, "%lf", &v) != 1)
+                    throw MarketError("Error parsing MARKET matrix: badly formed current_nz: '" + std::string(line) + "'");
+                c = (int) (current / num_rows);
+                r = (int) (current - (long long) num_rows * c);
+                Push(r, c, (ValueT) v);
+            } else {
+                char *l = line, *t = nullptr;
+                r = (int) strtol(l, &t, 0);
+                if (t == l) throw MarketError("Error parsing MARKET matrix: badly formed row at edge " + std::to_string(current));
+                l = t;
+                c = (int) strtol(l, &t, 0);
+                if (t == l) throw MarketError("Error parsing MARKET matrix: badly formed col at edge " + std::to_string(current));
+                l = t;
+                v = strtod(l, &t);
+                if (t == l) v = (double) default_value;
+                Push(r - 1, c - 1, (ValueT) v);
+            }
+            ++current;
+            if (symmetric && r != c) {          // compares the indices as parsed (1-based / array), like :362
+                Push(col.back(), row[row.size() - 1], val.back() * (ValueT) (skew ? -1 : 1));
+                ++current;
+            }
+        }
+        if (verbose) { printf("done. "); fflush(stdout); }
+    }
+};
+
+/// CSR in the reference's layout (sparse_matrix.h:645-650): row_offsets[rows+1]
+/// ([0] = 0, [rows] = nnz, repeated for empty rows), column_indices[nnz]
+/// 0-based and sorted by (row, col) with duplicates kept, values[nnz].
+template <typename ValueT>
+struct CsrMatrix {
+    int num_rows = 0, num_cols = 0, num_nonzeros = 0;
+    std::vector<int> row_offsets, column_indices;
+    std::vector<ValueT> values;
+
+    CsrMatrix() = default;
+    explicit CsrMatrix(const CooMatrix<ValueT> &coo) { Init(coo); }
+
+    /// COO -> CSR (CsrMatrix::Init, sparse_matrix.h:666-728): same result as a stable
+    /// sort of the tuples by (row, col).
+    void Init(const CooMatrix<ValueT> &coo)
+    {
+        num_rows = coo.num_rows; num_cols = coo.num_cols; num_nonzeros = coo.num_nonzeros();
+        const size_t n = (size_t) num_nonzeros;
+        row_offsets.assign((size_t) num_rows + 1, 0);
+        for (size_t k = 0; k < n; ++k) {
+            if (coo.row[k] < 0 || coo.row[k] >= num_rows) throw MarketError("row index out of range");
+            ++row_offsets[(size_t) coo.row[k] + 1];
+        }
+        for (int r = 0; r < num_rows; ++r) row_offsets[(size_t) r + 1] += row_offsets[r];
+        // stable scatter by row (keeps emission order inside a row)
+        std::vector<int> cursor(row_offsets.begin(), row_offsets.end() - 1);
+        std::vector<int> perm(n);
+        for (size_t k = 0; k < n; ++k) perm[(size_t) cursor[coo.row[k]]++] = (int) k;
+        // stable sort by column inside each row, rows in parallel
+        column_indices.resize(n); values.resize(n);
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (int r = 0; r < num_rows; ++r) {
+            int *b = perm.data() + row_offsets[r], *e = perm.data() + row_offsets[(size_t) r + 1];
+            bool sorted = true;
+            for (int *q = b; q + 1 < e; ++q) if (coo.col[q[1]] < coo.col[q[0]]) { sorted = false; break; }
+            if (!sorted) std::stable_sort(b, e, [&](int a, int c) { return coo.col[a] < coo.col[c]; });
+            for (int *q = b; q < e; ++q) {
+                column_indices[q - perm.data()] = coo.col[*q];
+                values[q - perm.data()] = coo.val[*q];
+            }
+        }
+    }
+
+    /// Row-length statistics (CsrMatrix::Stats, sparse_matrix.h:897-910; the
+    /// pearson_r it also computes is never printed and is not reproduced).
+    GraphStats Stats() const
+    {
+        GraphStats s;
+        s.num_rows = num_rows; s.num_cols = num_cols; s.num_nonzeros = num_nonzeros;
+        s.row_length_mean = double(num_nonzeros) / num_rows;
+        double variance = 0.0, cube = 0.0;
+        for (int r = 0; r < num_rows; ++r) {
+            const double delta = double(row_offsets[(size_t) r + 1] - row_offsets[r]) - s.row_length_mean;
+            variance += delta * delta;
+            cube += delta * delta * delta;
+        }
+        variance /= num_rows;
+        s.row_length_std_dev = std::sqrt(variance);
+        s.row_length_skewness = (cube / num_rows) / std::pow(s.row_length_std_dev, 3.0);
+        s.row_length_variation = s.row_length_std_dev / s.row_length_mean;
+        return s;
+    }
+
+    /// Log-10 histogram of row lengths (DisplayHistogram, sparse_matrix.h:919-956),
+    /// including its percentage relative to num_COLS (:953).
+    void DisplayHistogram(FILE *out = stdout) const
+    {
+        int log_counts[12] = {0};
+        int max_log = -1, max_len = -1;
+        for (int r = 0; r < num_rows; ++r) {
+            int length = row_offsets[(size_t) r + 1] - row_offsets[r];
+            max_len = std::max(max_len, length);
+            int lg = -1;
+            while (length > 0) { length /= 10; ++lg; }
+            max_log = std::max(max_log, lg);
+            ++log_counts[lg + 1];
+        }
+        fprintf(out, "CSR matrix (%d rows, %d columns, %d non-zeros, max-length %d):\n", num_rows, num_cols,
+                num_nonzeros, max_len);
+        for (int i = -1; i < max_log + 1; ++i)
+            fprintf(out, "\tDegree 1e%d: \t%d (%.2f%%)\n", i, log_counts[i + 1],
+                    (float) log_counts[i + 1] * 100.0 / num_cols);
+        fflush(out);
+    }
+
+    /// --v2 dump (CsrMatrix::Display, sparse_matrix.h:962-976).
+    void Display(FILE *out = stdout) const
+    {
+        fprintf(out, "Input Matrix (%d vertices, %d nonzeros):\n", num_rows, num_nonzeros);
+        for (int r = 0; r < num_rows; ++r) {
+            fprintf(out, "%d [@%d, #%d]: ", r, row_offsets[r], row_offsets[(size_t) r + 1] - row_offsets[r]);
+            for (int k = row_offsets[r]; k < row_offsets[(size_t) r + 1]; ++k)
+                fprintf(out, "%d (%f), ", column_indices[k], (double) values[k]);
+            fprintf(out, "\n");
+        }
+        fflush(out);
+    }
+};
+
+/// Sequential gold (SpmvGold, gpu_spmv.cu:72-92 / cpu_spmv.cpp:257-277): accumulates in ValueT.
+template <typename ValueT>
+void SpmvGold(const CsrMatrix<ValueT> &a, const ValueT *x, const ValueT *y_in, ValueT *y_out, ValueT alpha, ValueT beta)
+{
+    for (int r = 0; r < a.num_rows; ++r) {
+        ValueT partial = beta * y_in[r];
+        for (int k = a.row_offsets[r]; k < a.row_offsets[(size_t) r + 1]; ++k)
+            partial += alpha * a.values[k] * x[a.column_indices[k]];
+        y_out[r] = partial;
+    }
+}
+
+}  // namespace mspmv_host

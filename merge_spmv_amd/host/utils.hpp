@@ -1,0 +1,125 @@
+// utils.hpp -- command line, timing and verification helpers of the drivers.
+// Behavioural counterpart of the reference's utils.h: the `--key=value`
+// CommandLineArgs (utils.h:280-387), the wall-clock CpuTimer (utils.h:533-553,
+// the omp_get_wtime flavour -- the getrusage one sums CPU time over threads and
+// is wrong for OpenMP), and CompareResults (utils.h:672-742), whose weak rule is
+// kept ONLY to print the reference's PASS/FAIL verdict next to the strict
+// check this project adds.
+#pragma once
+
+#include <omp.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace mspmv_host {
+
+/// `--flag`, `--key=value` and naked arguments (CommandLineArgs, utils.h:280-387).
+/// Like the reference: a key may repeat (the last value wins), a value that does
+/// not parse leaves the stream's zero-initialised result (e.g. --i=abc -> 0), and
+/// arguments that do not start with "--" are naked.
+class CommandLineArgs {
+public:
+    CommandLineArgs(int argc, char **argv)
+    {
+        for (int i = 1; i < argc; ++i) {
+            const std::string arg = argv[i];
+            if (arg.size() < 2 || arg[0] != '-' || arg[1] != '-') { naked_.push_back(arg); continue; }
+            const std::string::size_type eq = arg.find('=');
+            if (eq == std::string::npos) { keys_.push_back(arg.substr(2)); values_.push_back(""); }
+            else { keys_.push_back(arg.substr(2, eq - 2)); values_.push_back(arg.substr(eq + 1)); }
+        }
+    }
+
+    bool CheckCmdLineFlag(const char *name) const
+    {
+        for (const std::string &k : keys_) if (k == name) return true;
+        return false;
+    }
+
+    template <typename T>
+    void GetCmdLineArgument(const char *name, T &val) const
+    {
+        for (size_t i = 0; i < keys_.size(); ++i)
+            if (keys_[i] == name) { std::istringstream ss(values_[i]); ss >> val; }
+    }
+
+    void GetCmdLineArgument(const char *name, std::string &val) const
+    {
+        for (size_t i = 0; i < keys_.size(); ++i)
+            if (keys_[i] == name) { std::istringstream ss(values_[i]); ss >> val; }
+    }
+
+    size_t NumNakedArgs() const { return naked_.size(); }
+
+private:
+    std::vector<std::string> keys_, values_, naked_;
+};
+
+/// Wall-clock timer (utils.h:533-553).
+struct CpuTimer {
+    double start = 0, stop = 0;
+    void Start() { start = omp_get_wtime(); }
+    void Stop() { stop = omp_get_wtime(); }
+    float ElapsedMillis() const { return float((stop - start) * 1000); }
+};
+
+/// The reference's comparator (utils.h:692-742), for its PASS/FAIL line only:
+/// both value types are cast to float, the INTEGER difference of the bit
+/// patterns is taken, and a mismatch is reported only if sqrt(diff) > len --
+/// vacuous for len > 46341.  Returns 1 on "mismatch".
+template <typename T>
+int CompareResultsReferenceRule(const T *computed, const T *reference, int len, bool verbose = true)
+{
+    for (int i = 0; i < len; ++i) {
+        const float a = (float) computed[i], b = (float) reference[i];
+        int32_t ia, ib;
+        memcpy(&ia, &a, 4); memcpy(&ib, &b, 4);
+        const int32_t diff = (int32_t) ((uint32_t) ia - (uint32_t) ib);
+        const int32_t int_diff = diff < 0 ? (int32_t) (0u - (uint32_t) diff) : diff;
+        const float sqrt_diff = sqrtf((float) int_diff);
+        if (sqrt_diff > (float) len) {
+            if (verbose) printf("INCORRECT (sqrt_diff: %g): [%d]: %g != %g", sqrt_diff, i, (double) computed[i], (double) reference[i]);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/// Strict check (SURVEY.md 8d / BASELINE.md 2): with g = fp64-accumulated
+/// gold and s = sum |val*x| per row, PASS iff |y - g| <= c*eps*s for every row,
+/// c = 2*(ceil(log2(len+1)) + items_per_thread + 8), eps = 2^-24 / 2^-53; rows
+/// without entries must be exactly 0.  Returns the number of violating rows and
+/// the worst |y-g| / bound ratio.
+template <typename T>
+long long StrictCheck(int rows, const int *row_offsets, const int *cols, const T *vals, const T *x, const T *y,
+                      int items_per_thread, double *worst_ratio)
+{
+    const double eps = sizeof(T) == 4 ? std::ldexp(1.0, -24) : std::ldexp(1.0, -53);
+    long long bad = 0;
+    double worst = 0.0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : bad) reduction(max : worst)
+    for (int r = 0; r < rows; ++r) {
+        double g = 0.0, s = 0.0;
+        for (int k = row_offsets[r]; k < row_offsets[r + 1]; ++k) {
+            const double p = (double) vals[k] * (double) x[cols[k]];
+            g += p; s += std::fabs(p);
+        }
+        const int len = row_offsets[r + 1] - row_offsets[r];
+        if (len == 0) { if (y[r] != (T) 0) ++bad; continue; }
+        const double c = 2.0 * (std::ceil(std::log2((double) len + 1.0)) + items_per_thread + 8);
+        const double bound = c * eps * s;
+        const double err = std::fabs((double) y[r] - g);
+        if (!(err <= bound)) ++bad;                       // also catches NaN
+        if (bound > 0 && err / bound > worst) worst = err / bound;
+    }
+    if (worst_ratio) *worst_ratio = worst;
+    return bad;
+}
+
+}  // namespace mspmv_host

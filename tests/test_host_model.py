@@ -1,0 +1,136 @@
+"""The PRODUCT's C++ host code (merge_spmv_amd/host/*.hpp through
+libmspmv_host.so, and the cpu_spmv driver binary) against golden vectors made
+by the reference's own sparse_matrix.h / utils.h (tests/golden/*.json).  CPU only."""
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+CASES = load_golden("matrices.json")["cases"]
+IDS = [c["label"] for c in CASES]
+PKG = os.path.join(ROOT, "merge_spmv_amd")
+
+
+@pytest.fixture(scope="module")
+def H():
+    path = os.path.join(PKG, "libmspmv_host.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", PKG, "libmspmv_host.so", "cpu_spmv"])
+    lib = ctypes.CDLL(path)
+    lib.mspmv_host_matrix_create.restype = ctypes.c_void_p
+    lib.mspmv_host_matrix_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_int)]
+    lib.mspmv_host_matrix_destroy.argtypes = [ctypes.c_void_p]
+    lib.mspmv_host_matrix_error.restype = ctypes.c_char_p
+    lib.mspmv_host_matrix_error.argtypes = [ctypes.c_void_p]
+    lib.mspmv_host_matrix_shape.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int)] * 3
+    lib.mspmv_host_matrix_copy.argtypes = [ctypes.c_void_p] * 4
+    lib.mspmv_host_matrix_text.restype = ctypes.c_char_p
+    lib.mspmv_host_matrix_text.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.mspmv_host_adaptive_iterations.argtypes = [ctypes.c_longlong, ctypes.c_ulonglong]
+    return lib
+
+
+def create(H, case, fp32):
+    kind = case["kind"].encode()
+    args = case["args"]
+    a = int(args[0]) if case["kind"] != "mtx" else 0
+    b = int(args[1]) if len(args) > 1 and case["kind"] != "mtx" else 0
+    path = os.path.join(ROOT, args[0]).encode() if case["kind"] == "mtx" else b""
+    st = ctypes.c_int()
+    h = H.mspmv_host_matrix_create(kind, a, b, path, int(fp32), ctypes.byref(st))
+    assert st.value == 0, H.mspmv_host_matrix_error(h)
+    return h
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_csr_stats_histogram_match_reference(H, case, prec):
+    h = create(H, case, prec == "f32")
+    try:
+        r, c, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        H.mspmv_host_matrix_shape(h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(n))
+        assert (r.value, c.value, n.value) == (case["rows"], case["cols"], case["nnz"])
+        off = np.zeros(r.value + 1, np.int32); col = np.zeros(max(n.value, 1), np.int32)
+        val = np.zeros(max(n.value, 1), np.float32 if prec == "f32" else np.float64)
+        H.mspmv_host_matrix_copy(h, off.ctypes.data, col.ctypes.data, val.ctypes.data)
+        assert off.tolist() == case["row_offsets"]
+        assert col[: n.value].tolist() == case["column_indices"]
+        want = np.asarray(case[prec]["values"], np.float64).astype(val.dtype)
+        assert np.array_equal(val[: n.value], want)
+        assert H.mspmv_host_matrix_text(h, 0).decode() == case[prec]["stats_csv"]
+        assert H.mspmv_host_matrix_text(h, 2).decode() == case["histogram"]
+    finally:
+        H.mspmv_host_matrix_destroy(h)
+
+
+def test_weak_comparator_and_cli_match_reference(H, golden_host):
+    for c in golden_host["compare_results"]:
+        dt = np.float32 if c["prec"] == "f32" else np.float64
+
+        def expand(v):
+            if isinstance(v, dict):
+                a = np.full(v["len"], v["fill"], dtype=dt); a[-1] = v["last"]; return a
+            return np.asarray(v, dtype=dt)
+        a, b = expand(c["computed"]), expand(c["reference"])
+        fn = H.mspmv_host_compare_reference_rule_f32 if dt == np.float32 else H.mspmv_host_compare_reference_rule_f64
+        assert fn(a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), a.size) == c["verdict"]
+    for c in golden_host["command_line"]:
+        argv = [b"prog"] + [a.encode() for a in c["argv"]]
+        arr = (ctypes.c_char_p * len(argv))(*argv)
+        out = ctypes.create_string_buffer(512)
+        H.mspmv_host_parse_args(len(argv), arr, out, 512)
+        assert json.loads(out.value.decode()) == c["parsed"]
+
+
+def test_adaptive_iterations(H):
+    """clamp(2^34 / nnz, 100, cap): gpu_spmv.cu:492-493 (cap 50000), cpu_spmv.cpp:611-616 (cap 200000)."""
+    assert H.mspmv_host_adaptive_iterations(59524291, 50000) == 288           # circuit5M, README.md:116
+    assert H.mspmv_host_adaptive_iterations(100, 50000) == 50000
+    assert H.mspmv_host_adaptive_iterations(100, 200000) == 200000
+    assert H.mspmv_host_adaptive_iterations(2_000_000_000, 50000) == 100
+
+
+def run(*args):
+    return subprocess.run([os.path.join(PKG, "cpu_spmv"), *args], capture_output=True, text=True, timeout=120)
+
+
+def test_cpu_driver_quiet_csv_contract(H):
+    """eval_csrmv.sh contract: label, 7 stats fields, then per method
+    `name, setup_ms, avg_ms, gflops, GB/s` (eval_csrmv.sh:8, cpu_spmv.cpp:515-520)."""
+    case = next(c for c in CASES if c["label"] == "grid3d_4")
+    r = run("--quiet", "--grid3d=4", "--i=3", "--threads=3")
+    assert r.returncode == 0
+    line = r.stdout.strip()
+    assert line.startswith("grid3d_4, " + case["f64"]["stats_csv"])
+    fields = [f.strip() for f in line.split(",")]
+    assert fields[8] == "OMP-row CsrMV" and fields[13] == "Merge CsrMV"
+    for i in (9, 10, 11, 12, 14, 15, 16, 17):
+        float(fields[i])
+    assert len(fields) == 19 and fields[18] == ""
+
+
+@pytest.mark.parametrize("flags", [["--grid2d=40"], ["--grid3d=9", "--fp32"], ["--wheel=3000"], ["--dense=7"],
+                                   ["--mtx=" + os.path.join(ROOT, "tests/golden/mtx/giant_row.mtx")]])
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_cpu_driver_verifies_itself(H, flags, threads):
+    r = run(*flags, "--i=2", f"--threads={threads}")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("\tPASS\n") == 2 and "FAIL" not in r.stdout
+    assert r.stdout.count("strict check: PASS") == 2
+    assert f"Using {threads} threads on" in r.stdout
+    assert "timing iterations" not in r.stdout           # only printed when adaptive (cpu_spmv.cpp:611-616)
+
+
+def test_cpu_driver_edge_behaviour(H):
+    r = run("--i=2")
+    assert r.returncode == 1 and "No graph type specified." in r.stderr
+    r = run("--mtx=" + os.path.join(ROOT, "tests/golden/mtx/array.mtx"), "--i=2")
+    assert r.returncode == 0 and "OMP-row CsrMV" in r.stdout
+    r = run("--help")
+    assert r.returncode == 0 and "--mtx=<matrix market file>" in r.stdout
