@@ -180,7 +180,11 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             }
             const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
 #define MSPMV_LAUNCH_P(...) hipLaunchKernelGGL((tile_kernel_persistent<V, BLOCK, IPT, __VA_ARGS__>), dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles)
-            if ((L.flags >> 16) & 1) MSPMV_LAUNCH_P(false, false, 1);
+            const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
+            if (ablate == 1) MSPMV_LAUNCH_P(false, false, 1);
+            else if (ablate == 2) MSPMV_LAUNCH_P(false, false, 2);
+            else if (ablate == 3) MSPMV_LAUNCH_P(false, false, 3);
+            else if (ablate == 4) MSPMV_LAUNCH_P(false, false, 4);
             else if (axpby) { if (remap) MSPMV_LAUNCH_P(true, true); else MSPMV_LAUNCH_P(true, false); }
             else if (remap) MSPMV_LAUNCH_P(false, true);
             else MSPMV_LAUNCH_P(false, false);
@@ -366,7 +370,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | 0xff00 | 0x10000)) return hipErrorInvalidValue;
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | 0xff00 | 0x70000)) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)

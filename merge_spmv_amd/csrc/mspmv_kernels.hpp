@@ -278,60 +278,98 @@ __device__ __forceinline__ void st_lds4(int *p, const int (&v)[4])
 //               array for the last tile);
 //   s_prod[j] = values[j] * x[cols[j]] for the tile's nonzeros.
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int IPT, bool AXPBY>
+template <typename V, int BLOCK, int IPT, bool AXPBY, int ABLATE = 0>
 __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
-                                                 const int *s_end, const V *s_prod, int *s_wave_key, V *s_wave_val,
-                                                 Carry<V> *__restrict__ carry_out)
+                                                 const int *s_end, const V *s_prod, V *s_y, int *s_wave_key,
+                                                 V *s_wave_val, Carry<V> *__restrict__ carry_out)
 {
+    // s_y (tile_rows entries) may alias the memory behind s_prod.
+    // Straight-line code throughout: divergent branches in the search and the walk made
+    // every wave execute both sides of each step (measured 15-23 % of the kernel on
+    // short-row matrices).  Requirements on the staging: s_end[r] = +inf for every
+    // r >= tile_rows and s_prod[j] = 0 for every j >= tile_nnz, up to TILE + IPT + 3.
     const int tid = threadIdx.x;
     const int tile_items = tile_rows + tile_nnz;
     int diag = tid * IPT; diag = diag < tile_items ? diag : tile_items;
-    int lo = diag - tile_nnz; lo = lo < 0 ? 0 : lo;
-    int hi = diag < tile_rows ? diag : tile_rows;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (s_end[mid] <= diag - mid - 1) lo = mid + 1; else hi = mid;
-    }
-    int row = lo;            // tile-relative row this thread starts in
-    int nz = diag - lo;      // tile-relative nonzero it starts at
-    int n_items = tile_items - diag; n_items = n_items < IPT ? n_items : IPT;
 
-    // walk IPT path items
-    V *__restrict__ y = p.y + c0.x;
-    int cur_end = s_end[row];
-    V total = 0;
-    int first_row = -1;      // first row this thread completes (needs the carry-in)
-    V first_total = 0;
+    // ---- in-tile merge-path search: x(diag) = #{r < tile_rows : s_end[r] + r < diag}
+    // (the predicate is monotone in r, Appendix B.2; the bounds max(diag - nnz, 0) and
+    // min(diag, rows) of the reference's search are implied by it).  Uniform trip count.
+    int row = 0;
+    if (ABLATE == 4) row = (int) ((long long) diag * tile_rows / (tile_items > 0 ? tile_items : 1));   // no search (wrong results)
+    else
+    for (int step = 1 << (31 - __builtin_clz(tile_rows | 1)); step > 0; step >>= 1) {
+        const int q = row + step;                      // candidate count
+        const int e = s_end[q - 1 < tile_rows ? q - 1 : tile_rows];   // clamped: slot tile_rows holds +inf
+        row = (q <= tile_rows && e + (q - 1) < diag) ? q : row;
+    }
+    const int first_row = row;                         // the row this thread starts in
+    const int nz = diag - row;
+
+    // ---- walk IPT path items, latency-free form.
+    // The reference's walk (agent_spmv_orig.cuh:557-578) reads LDS once per step with the
+    // address depending on the previous step: IPT dependent LDS round trips.  Here the
+    // <= IPT row ends this thread can reach are read in one batch; row-end j sits at path
+    // item (s_end[first_row + j] - nz) + j of this thread, which gives a bit mask of the
+    // items that are row ends; the k-th item is then nonzero nz + k - popcount(mask below
+    // k), so all products are read in a second batch and the segmented sum runs in registers.
+    unsigned mask = 0;
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        if (k < n_items) {
-            if (nz < cur_end) {
-                total += s_prod[nz];
-                ++nz;
-            } else {
-                if (first_row < 0) { first_row = row; first_total = total; }
-                else if (AXPBY) y[row] = p.alpha * total + (p.beta == (V) 0 ? (V) 0 : p.beta * y[row]);
-                else y[row] = total;
-                total = 0;
-                ++row;
-                cur_end = s_end[row];
-            }
+    for (int j = 0; j < (ABLATE == 3 ? 1 : IPT); ++j) {
+        const int pos = s_end[row + j] - nz + j;       // +inf sentinel (2^30) stays out of range
+        mask |= pos < IPT ? 1u << pos : 0u;
+    }
+    V prod[IPT];
+    {
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
+            prod[k] = s_prod[nz + k - cnt];
+            cnt += (mask >> k) & 1u;
         }
     }
-    // carry between threads: block-wide exclusive reduce-by-key scan
+    // segmented sum in registers: ended[k] = total of the row that ends at item k
+    V ended[IPT];
+    V total = 0;
+#pragma unroll
+    for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
+        const bool end = (mask >> k) & 1u;
+        ended[k] = total;
+        total = end ? (V) 0 : total + prod[k];
+    }
+    const int done_all = __builtin_popcount(mask);
+    // ---- carry between threads: block-wide exclusive reduce-by-key scan (has a barrier
+    //      inside: after it every thread has finished reading s_prod, which s_y aliases)
     int prev_key, agg_key; V carry_in, agg_val;
-    block_exclusive_rbk<V, BLOCK>(row, total, s_wave_key, s_wave_val, prev_key, carry_in, agg_key, agg_val);
-    if (first_row >= 0) {
-        // prev_key == first_row whenever tid > 0 (the previous thread ended in
-        // the row this thread started in); thread 0 has no in-tile carry.
-        const V sum = first_total + ((tid > 0 && prev_key == first_row) ? carry_in : (V) 0);
-        if (AXPBY) y[first_row] = p.alpha * sum + (p.beta == (V) 0 ? (V) 0 : p.beta * y[first_row]);
-        else y[first_row] = sum;
+    if (ABLATE == 2) { prev_key = row; carry_in = total; agg_key = row; agg_val = total; }   // no scan (wrong results)
+    else
+    block_exclusive_rbk<V, BLOCK>(row + done_all, total, s_wave_key, s_wave_val, prev_key, carry_in, agg_key, agg_val);
+    // ---- row totals -> LDS (scattered 4/8-byte LDS writes are cheap; scattered global
+    //      stores were not: ~1.3 rows per L2 write request, as many requests as the
+    //      whole read stream on a 5-nnz/row matrix), then one coalesced copy to y.
+    {
+        // prev_key == first_row whenever tid > 0 (the previous thread ended in the row this
+        // thread started in); thread 0 has no in-tile carry.
+        const V first_carry = (tid > 0 && prev_key == first_row) ? carry_in : (V) 0;
+        int done = 0;
+#pragma unroll
+        for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
+            if ((mask >> k) & 1u) {
+                s_y[row + done] = done == 0 ? ended[k] + first_carry : ended[k];
+                ++done;
+            }
+        }
     }
     if (tid == BLOCK - 1) {
         // the row left open at the tile end (ref: agent_spmv_orig.cuh:906-913)
         Carry<V> c; c.key = c0.x + agg_key; c.value = agg_val;
         *carry_out = c;
+    }
+    __syncthreads();
+    V *__restrict__ y = p.y + c0.x;
+    for (int r = tid; r < tile_rows; r += BLOCK) {
+        if (AXPBY) y[r] = p.alpha * s_y[r] + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
+        else y[r] = s_y[r];
     }
 }
 
@@ -347,8 +385,9 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
 {
     constexpr int TILE = BLOCK * IPT;
     constexpr int NW = BLOCK / WAVE;
-    __shared__ int s_end[TILE + 1];
-    __shared__ V s_prod[TILE];
+    constexpr int PAD = IPT + 4;
+    __shared__ int s_end[TILE + PAD];
+    __shared__ V s_prod[TILE + PAD];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
 
@@ -369,15 +408,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
         if (j < tile_nnz) { col_r[k] = cols[j]; val_r[k] = vals[j]; }
     }
     const int *__restrict__ row_end = p.row_end + c0.x;
-    for (int r = tid; r < tile_rows; r += BLOCK) s_end[r] = row_end[r] - c0.y;
-    if (tid == 0) s_end[tile_rows] = 0x7fffffff;
+    for (int r = tid; r < TILE + PAD; r += BLOCK) s_end[r] = r < tile_rows ? row_end[r] - c0.y : 0x3fffffff;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const int j = tid + k * BLOCK;
-        if (j < tile_nnz) s_prod[j] = val_r[k] * p.x[col_r[k]];
+        s_prod[j] = j < tile_nnz ? val_r[k] * p.x[col_r[k]] : (V) 0;
     }
+    if (tid < PAD) s_prod[TILE + tid] = (V) 0;
     __syncthreads();
-    consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end, s_prod, s_wave_key, s_wave_val,
+    consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end, s_prod, s_prod, s_wave_key, s_wave_val,
                                            carries + tile);
 }
 
@@ -507,7 +546,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, con
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * q - eshift + j;
                 const bool in = r >= 0 && r < tile_rows && i <= last_full_ro;
-                v[j] = in ? ro[k].get(j) - c0.y : 0x7fffffff;
+                v[j] = in ? ro[k].get(j) - c0.y : 0x3fffffff;
             }
             st_lds4(&s_end_raw[4 * q], v);
         }
@@ -545,8 +584,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, con
             // ablation (development): staging only -- keep the LDS data live, skip search/walk/scan
             if (s_prod_raw[tid] == (V) 12345.678 && s_end_raw[tid] == 77) carries[tile].key = 1;
         } else
-        consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw + pshift,
-                                               s_wave_key, s_wave_val, carries + tile);
+        consume_tile_lds<V, BLOCK, IPT, AXPBY, ABLATE>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw + pshift,
+                                                       s_prod_raw, s_wave_key, s_wave_val, carries + tile);
         if (!has_next) break;
         __syncthreads();          // all LDS reads of this tile done before the next tile's staging writes
         seq = next_seq; tile = next; c0 = n0; c1 = n1;
