@@ -118,17 +118,7 @@ def main():
         def op(xv):
             return M.csrmv(A.values, A.row_offsets, A.column_indices, xv, y=y, num_cols=cols, workspace=ws)
     else:
-        off = np.arange(rows + 1, dtype=np.int64) * npr
-        row_split, nz_split = MG.partition(off, world)
-        r0, r1 = int(row_split[rank]), int(row_split[rank + 1])
-        r_hi = min(r1 + 1, rows)                                   # include the row cut by the right boundary
-        full = G.uniform_csr(rows, cols, npr, dtype=tdt, device=dev, row_lo=r0, row_hi=r_hi)
-        a = int(nz_split[rank]) - r0 * npr
-        b = int(nz_split[rank + 1]) - r0 * npr
-        lo = MG.local_offsets(off, r0, r1, int(nz_split[rank]), int(nz_split[rank + 1]))
-        shard = MG.Shard(rank, world, row_split, nz_split, torch.from_numpy(lo).to(dev),
-                         full.column_indices[a:b].contiguous(), full.values[a:b].contiguous(), cols)
-        del full
+        shard = MG.uniform_shard(rows, cols, npr, rank, world, tdt, device=dev)
         local_rows, local_nnz = shard.local_rows, shard.local_nnz
         op = MG.ShardedCsrMV(shard, group=None)
     x = G.uniform_pm1(G.SEED_C2 + 2, cols, tdt, dev)

@@ -132,3 +132,22 @@ def shard_from_host_csr(row_offsets: np.ndarray, column_indices: np.ndarray, val
                  torch.from_numpy(lo).to(device),
                  torch.from_numpy(np.ascontiguousarray(column_indices[a:b], dtype=np.int32)).to(device),
                  torch.from_numpy(np.ascontiguousarray(values[a:b])).to(device), int(num_cols))
+
+
+def uniform_shard(rows: int, cols: int, nnz_per_row: int, part: int, parts: int, dtype, device="cuda") -> Shard:
+    """Rank `part`'s swath of generators.uniform_csr(rows, cols, nnz_per_row) built directly
+    on `device` without ever materialising the whole matrix: the global row offsets of that
+    generator are r * nnz_per_row, the generator's counters are global, so a rank only
+    generates the rows its swath touches (plus the row its right boundary cuts)."""
+    import torch
+    from . import generators as G
+    off = np.arange(rows + 1, dtype=np.int64) * nnz_per_row
+    row_split, nz_split = partition(off, parts)
+    r0, r1 = int(row_split[part]), int(row_split[part + 1])
+    r_hi = min(r1 + 1, rows)
+    full = G.uniform_csr(rows, cols, nnz_per_row, dtype=dtype, device=device, row_lo=r0, row_hi=r_hi)
+    a = int(nz_split[part]) - r0 * nnz_per_row
+    b = int(nz_split[part + 1]) - r0 * nnz_per_row
+    lo = local_offsets(off, r0, r1, int(nz_split[part]), int(nz_split[part + 1]))
+    return Shard(part, parts, row_split, nz_split, torch.from_numpy(lo).to(device),
+                 full.column_indices[a:b].contiguous(), full.values[a:b].contiguous(), int(cols))

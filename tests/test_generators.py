@@ -1,0 +1,74 @@
+"""The synthetic workloads of SURVEY.md 8(d) (merge_spmv_amd/generators.py, torch ops so
+they can be built in HBM) against an independent numpy splitmix64: same integers, same
+values, valid CSR.  CPU only."""
+import numpy as np
+import torch
+
+from merge_spmv_amd import generators as G
+
+M64 = (1 << 64) - 1
+
+
+def splitmix64_np(seed, idx):
+    z = (np.uint64(seed) + (idx.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def u01_np(seed, idx):
+    return (splitmix64_np(seed, idx) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def test_splitmix_and_uniform_streams():
+    idx = np.arange(0, 5000, dtype=np.int64)
+    with np.errstate(over="ignore"):
+        want = splitmix64_np(G.SEED_C2, idx)
+    got = G.splitmix64(G.SEED_C2, torch.from_numpy(idx)).numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    with np.errstate(over="ignore"):
+        u = u01_np(G.SEED_C2 + 1, idx)
+    v = G.uniform_pm1(G.SEED_C2 + 1, 5000, torch.float32, "cpu").numpy()
+    assert np.array_equal(v, (u * 2.0 - 1.0).astype(np.float32))
+    assert v.min() >= -1.0 and v.max() < 1.0
+
+
+def test_uniform_csr_is_the_c2_definition():
+    rows, cols, npr = 300, 1000, 32
+    A = G.uniform_csr(rows, cols, npr, dtype=torch.float32, device="cpu")
+    assert A.row_offsets.tolist() == [r * npr for r in range(rows + 1)]
+    with np.errstate(over="ignore"):
+        c = np.minimum((u01_np(G.SEED_C2, np.arange(rows * npr)) * cols).astype(np.int64), cols - 1).reshape(rows, npr)
+    c.sort(axis=1)
+    assert np.array_equal(A.column_indices.numpy().reshape(rows, npr), c)
+    # a row range of the same matrix
+    B = G.uniform_csr(rows, cols, npr, dtype=torch.float32, device="cpu", row_lo=100, row_hi=180)
+    assert torch.equal(B.column_indices, A.column_indices[100 * npr: 180 * npr])
+    assert torch.equal(B.values, A.values[100 * npr: 180 * npr])
+
+
+def test_degenerate_csr_shape():
+    A = G.degenerate_csr(rows=1 << 12, giant_nnz=1 << 14, every=64, dtype=torch.float32, device="cpu")
+    lens = np.diff(A.row_offsets.numpy())
+    assert lens[2048] == 1 << 14 and lens.sum() == A.nnz
+    others = np.delete(lens, 2048)
+    assert set(np.unique(others)) <= {0, 1} and others.sum() == (1 << 12) // 64 - 1
+    cols = A.column_indices.numpy()
+    g0 = A.row_offsets[2048].item()
+    assert np.all(np.diff(cols[g0: g0 + (1 << 14)]) >= 0) and cols.max() < (1 << 12)
+
+
+def test_rmat_csr_valid_and_range_consistent():
+    scale, edges = 10, 20000
+    A, e = G.rmat_csr(scale, edges, dtype=torch.float64, device="cpu", return_edge_ids=True)
+    off = A.row_offsets.numpy().astype(np.int64); col = A.column_indices.numpy()
+    assert off[0] == 0 and off[-1] == edges and np.all(np.diff(off) >= 0)
+    rowid = np.repeat(np.arange(1 << scale), np.diff(off))
+    key = rowid * (1 << scale) + col
+    assert np.all(np.diff(key) >= 0)                       # sorted by (row, col), duplicates kept
+    assert len(np.unique(e.numpy())) == edges
+    lens = np.diff(off)
+    assert lens.max() > 20 * lens.mean()                   # skewed, as R-MAT should be
+    B = G.rmat_csr(scale, edges, dtype=torch.float64, device="cpu", row_lo=100, row_hi=400)
+    a, b = off[100], off[400]
+    assert torch.equal(B.column_indices, A.column_indices[a:b]) and torch.equal(B.values, A.values[a:b])

@@ -268,3 +268,34 @@ def test_full_size_c2_properties(M):
     lin = (2.0 * y.double() - 0.5 * y2.double())
     err = (y3.double() - lin).abs()
     assert float((err / (torch.from_numpy(s).cuda() * 2.0 ** -18 + 1e-12)).max()) <= 4.0
+
+
+@pytest.mark.parametrize("parts", [1, 2, 4, 8])
+def test_sharded_merge_partition_on_one_gpu(M, parts):
+    """every part's swath through the HIP CsrMV as a local CSR (its extra
+    last row is the carry), the carries exchanged (here: copied, all parts live on one
+    GPU) and applied by mspmv_mg_apply_carries; equals the unsharded result."""
+    from merge_spmv_amd import multi_gpu as MG
+    rng = np.random.default_rng(parts)
+    lens = np.minimum((rng.pareto(1.1, 30000) * 2).astype(np.int64), 40000)
+    lens[12345] = 400000                                    # spans several parts
+    csr = random_csr(rng, 30000, 30000, lens, np.float64)
+    x = rng.uniform(-1, 1, csr.cols)
+    xd = dev(x)
+    ops = [MG.ShardedCsrMV(MG.shard_from_host_csr(csr.row_offsets, csr.column_indices, csr.values, csr.cols, g, parts))
+           for g in range(parts)]
+    carries = torch.zeros(parts, dtype=torch.float64, device="cuda")
+    for g, op in enumerate(ops):
+        s = op.shard
+        st, _ = M.DeviceSpmv.CsrMV(op.workspace.buffer, op.workspace.bytes, s.values, s.row_offsets, s.column_indices, xd,
+                                   op.y_local, s.local_rows, s.num_cols, s.local_nnz)
+        assert st == 0
+        carries[g] = op.y_local[s.local_rows - 1]
+    y = np.full(csr.rows, np.nan)
+    for g, op in enumerate(ops):
+        op.carries.copy_(carries)
+        op._apply_carries()
+        torch.cuda.synchronize()
+        s = op.shard
+        y[int(s.row_split[g]): int(s.row_split[g + 1])] = op.y_local[: s.owned_rows].cpu().numpy()
+    check_strict(M, csr, x, y)
