@@ -35,8 +35,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (rows per GPU, nnz per row, default dtype)
+    # name: (rows per GPU, nnz per row, default dtype).  "c2" is the headline (BASELINE config 2,
+    # uniform random columns); "dense32" is its reference-compatible pure-streaming variant
+    # (--dense=32 --size=100000000, gpu_spmv.cu:645-650): same sizes, x has 32 entries.
     "c2": (3_125_000, 32, "f32"),
+    "dense32": (3_125_000, 32, "f32"),
 }
 
 
@@ -104,13 +107,16 @@ def main():
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
     rows = rows_per_gpu * world
-    cols = rows
+    cols = rows if args.workload == "c2" else npr
     nnz_total = rows * npr
+    if args.workload != "c2" and world > 1:
+        raise SystemExit("only the c2 workload is sharded across GPUs")
 
     # ---- build this rank's swath directly in HBM -------------------------
     if world == 1:
         # the plain drop-in call: no shard wrapper, no collective
-        A = G.uniform_csr(rows, cols, npr, dtype=tdt, device=dev)
+        A = (G.uniform_csr(rows, cols, npr, dtype=tdt, device=dev) if args.workload == "c2"
+             else G.dense_csr(rows, npr, dtype=tdt, device=dev, ones=False))
         local_rows, local_nnz = rows, nnz_total
         ws = M.CsrMVWorkspace(rows, nnz_total, tdt, device=dev)
         y = torch.empty(rows, dtype=tdt, device=dev)
@@ -170,8 +176,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": f"C2 uniform CSR: {rows} x {cols}, {npr} nnz/row, {nnz_total} nnz "
-                                   f"({rows_per_gpu * npr} nnz per GPU), uniform random sorted columns, values/x in [-1,1)",
+            "config": {"workload": (f"C2 uniform CSR: {rows} x {cols}, {npr} nnz/row, {nnz_total} nnz "
+                                    f"({rows_per_gpu * npr} nnz per GPU), uniform random sorted columns, values/x in [-1,1)")
+                       if args.workload == "c2" else
+                       f"dense {rows} x {npr} as CSR ({nnz_total} nnz): the streaming variant of C2 (--dense=32 --size=100000000)",
                        "tile": f"{info['block_threads']}x{info['items_per_thread']}",
                        "partition": "single GPU" if world == 1 else f"merge-path diagonal split over {world} GPUs + 1 RCCL all-gather of carries"},
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
