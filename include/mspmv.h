@@ -116,6 +116,7 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_ATOMIC_FIX 2   /* single-launch atomicAdd fix-up (non-deterministic) */
 #define MSPMV_TUNE_NO_VEC     4   /* force the one-block-per-tile dword-per-lane kernel (the path taken for unaligned arrays) */
 #define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by per-boundary wave search instead of the one-pass scatter */
+#define MSPMV_TUNE_NO_FUSED   16  /* never use the single-launch small-problem kernel */
 /* bits 8..15 of flags: resident blocks per CU of the persistent grid (0 = default 8) */
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);

@@ -22,6 +22,7 @@ constexpr int SEARCH_BLOCK = 256;
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 8;
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
+constexpr int FUSED_MAX_TILES = 2048;            // up to here: tiles search their own coordinates (one launch less)
 
 static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
 
@@ -43,13 +44,21 @@ static Shape pick_shape(int value_bytes, long long items, int &flags)
     flags = t.flags.load();
     if (t.block.load() > 0) return Shape{t.block.load(), t.ipt.load()};
     const bool large = items >= (8LL << 20);
-    if (value_bytes == 8) return large ? Shape{256, 7} : Shape{256, 5};
-    return large ? Shape{256, 11} : Shape{256, 7};
+    const Shape dflt = value_bytes == 8 ? (large ? Shape{256, 7} : Shape{256, 5}) : (large ? Shape{256, 11} : Shape{256, 7});
+    // small problems: the smallest (>= default) shape whose tile count fits one resident wave of
+    // blocks / one fix-up chunk: tile_kernel_fused + a single fix-up launch (2 launches in all)
+    static const int ipts32[] = {7, 9, 11, 15}, ipts64[] = {5, 7, 9, 11};
+    const int *ipts = value_bytes == 8 ? ipts64 : ipts32;
+    if (!(flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED)))
+        for (int i = 0; i < 4; ++i)
+            if (ipts[i] >= dflt.ipt && (items + 256LL * ipts[i] - 1) / (256LL * ipts[i]) <= FIX_CHUNK) return Shape{256, ipts[i]};
+    return dflt;
 }
 
 struct Layout {
     Shape shape; int flags;
     int num_tiles;
+    bool fused;            // small: tile_kernel_fused (needs aligned arrays, decided again at launch)
     int fix_n[3];          // pairs entering fix-up level i (fix_n[0] == num_tiles)
     int fix_levels;
     uint64_t coords_off, carries_off, fix_off[2], total;
@@ -66,6 +75,7 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     uint64_t off = 0;
     L.coords_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(Coord));
     L.carries_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * pair);
+    L.fused = !(L.flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED)) && L.num_tiles <= FUSED_MAX_TILES;
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
@@ -134,6 +144,21 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     const int tile_items = BLOCK * IPT;
     const int slot = (g_prof.active && g_prof.calls < g_prof.capacity) ? g_prof.calls++ : -1;
 
+    // 16-byte streaming needs 16-byte aligned array bases (hipMalloc gives 256) and at
+    // least one full 4-element chunk in each array
+    const bool vec = !(L.flags & MSPMV_TUNE_NO_VEC) && p.nnz >= 4 && p.rows >= 3 &&
+                     ((reinterpret_cast<uintptr_t>(p.values) | reinterpret_cast<uintptr_t>(p.cols) |
+                       reinterpret_cast<uintptr_t>(p.row_end - 1)) & 15) == 0;
+    const bool fused = L.fused && vec;
+    if (fused) {
+        // small problems: the tiles search their own coordinates (no coordinate pass)
+        prof_mark(stream, slot, 0);
+        prof_mark(stream, slot, 1);
+        const unsigned grid = (unsigned) L.num_tiles;
+        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
+    } else {
     // 1. tile boundary coordinates
     prof_mark(stream, slot, 0);
     if (L.flags & MSPMV_TUNE_BINARY_SEARCH) {
@@ -158,11 +183,6 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     {
         const unsigned grid = (unsigned) L.num_tiles;
         const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
-        // 16-byte streaming needs 16-byte aligned array bases (hipMalloc gives 256) and at
-        // least one full 4-element chunk in each array
-        const bool vec = !(L.flags & MSPMV_TUNE_NO_VEC) && p.nnz >= 4 && p.rows >= 3 &&
-                         ((reinterpret_cast<uintptr_t>(p.values) | reinterpret_cast<uintptr_t>(p.cols) |
-                           reinterpret_cast<uintptr_t>(p.row_end - 1)) & 15) == 0;
         if (vec) {
             // resident grid: blocks_per_cu * CUs blocks walk the tiles with a software-prefetched stream
             // (size the grid by what is actually resident: a block that has to wait for a slot
@@ -194,6 +214,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
         }
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel", grid, BLOCK));
+    }
     }
     // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair)
     prof_mark(stream, slot, 2);
@@ -370,7 +391,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | 0xff00 | 0x70000)) return hipErrorInvalidValue;
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | 0xff00 | 0x70000)) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)

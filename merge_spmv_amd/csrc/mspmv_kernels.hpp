@@ -466,6 +466,90 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
     }
 }
 
+// Stage one tile whose nonzeros are already in `regs` (requested earlier): row offsets
+// and x gathers are issued, tile-relative row ends and products land in LDS (every slot of
+// both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
+// and the block is synchronised.
+template <typename V, int BLOCK, int IPT>
+__device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1,
+                                           const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
+                                           int last_full_nz, int last_full_ro)
+{
+    constexpr int CPT = IPT / 4 + 1;
+    const int tid = threadIdx.x;
+    const int *__restrict__ row_offsets = p.row_end - 1;
+    const int tile_rows = c1.x - c0.x;
+    const int tile_nnz = c1.y - c0.y;
+    const int a0 = c0.y & ~3;
+    const int first = c0.x + 1;                // d_row_offsets index of the tile's first row end
+    const int i0 = first & ~3;
+    const int eshift = first - i0;
+    // ---- row ends of the current tile -> LDS (chunks of d_row_offsets)
+    Vec4<int> ro[CPT];
+    const int ro_chunks = (tile_rows + eshift + 3) / 4;           // chunks holding a row end of this tile
+    const int ro_safe = i0 < last_full_ro ? i0 : last_full_ro;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int q = tid + k * BLOCK;
+        int i = i0 + 4 * q;
+        i = (q < ro_chunks && i <= last_full_ro) ? i : ro_safe;
+        ro[k] = ld_stream4(row_offsets + i);
+    }
+    // ---- gather x for the current tile (its nonzeros were requested one iteration ago)
+    V xv[CPT][4];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int e0 = a0 + 4 * (tid + k * BLOCK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
+            xv[k][i] = p.x[in ? regs.col[k].get(i) : 0];
+        }
+    }
+    // ---- stage row ends
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int q = tid + k * BLOCK;
+        const int i = i0 + 4 * q;
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q - eshift + j;
+            const bool in = r >= 0 && r < tile_rows && i <= last_full_ro;
+            v[j] = in ? ro[k].get(j) - c0.y : 0x3fffffff;
+        }
+        st_lds4(&s_end_raw[4 * q], v);
+    }
+    // ---- stage products
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int chunk = tid + k * BLOCK;
+        const int e0 = a0 + 4 * chunk;
+        V prod[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
+            prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
+        }
+        st_lds4(&s_prod_raw[4 * chunk], prod);
+    }
+    // ---- ragged array tails (at most 3 elements each; only the tile that reaches the array
+    //      end).  Block-uniform branch; the barrier orders these writes after the zeros /
+    //      sentinels the chunk owners stored into the same slots above.
+    const bool nz_tail = c1.y > last_full_nz + 4;
+    const bool ro_tail = first + tile_rows > last_full_ro + 4;
+    if (nz_tail || ro_tail) {
+        __syncthreads();
+        const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
+        if (nz_tail && j < c1.y && j >= c0.y)
+            s_prod_raw[j - a0] = ld_stream(p.values + j) * p.x[ld_stream(p.cols + j)];
+        const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
+        const int r = i - first;
+        if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream(row_offsets + i) - c0.y;
+    }
+    __syncthreads();
+}
+
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, int ABLATE = 0>
 __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
@@ -495,7 +579,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, con
     Coord c1 = coords[tile + 1];
     TileRegs<V, BLOCK, IPT> regs;
     issue_nonzero_loads<V, BLOCK, IPT>(p, c0, c1, regs);
-    const int *__restrict__ row_offsets = p.row_end - 1;
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;   // rows + 1 >= 4
 
@@ -508,76 +591,13 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, con
         const int i0 = first & ~3;
         const int eshift = first - i0;
 
-        // ---- row ends of the current tile -> LDS (chunks of d_row_offsets)
-        Vec4<int> ro[CPT];
-        const int ro_chunks = (tile_rows + eshift + 3) / 4;           // chunks holding a row end of this tile
-        const int ro_safe = i0 < last_full_ro ? i0 : last_full_ro;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int q = tid + k * BLOCK;
-            int i = i0 + 4 * q;
-            i = (q < ro_chunks && i <= last_full_ro) ? i : ro_safe;
-            ro[k] = ld_stream4(row_offsets + i);
-        }
-        // ---- gather x for the current tile (its nonzeros were requested one iteration ago)
-        V xv[CPT][4];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int e0 = a0 + 4 * (tid + k * BLOCK);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
-                xv[k][i] = p.x[in ? regs.col[k].get(i) : 0];
-            }
-        }
-        // ---- next tile's coordinates
+        // ---- next tile's coordinates (scalar loads, in flight during the staging)
         const int next_seq = seq + (int) gridDim.x;
         const bool has_next = next_seq < num_tiles;
         const int next = has_next ? physical(next_seq) : tile;
         const Coord n0 = coords[next];
         const Coord n1 = coords[next + 1];
-        // ---- stage row ends
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int q = tid + k * BLOCK;
-            const int i = i0 + 4 * q;
-            int v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * q - eshift + j;
-                const bool in = r >= 0 && r < tile_rows && i <= last_full_ro;
-                v[j] = in ? ro[k].get(j) - c0.y : 0x3fffffff;
-            }
-            st_lds4(&s_end_raw[4 * q], v);
-        }
-        // ---- stage products
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int chunk = tid + k * BLOCK;
-            const int e0 = a0 + 4 * chunk;
-            V prod[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
-                prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
-            }
-            st_lds4(&s_prod_raw[4 * chunk], prod);
-        }
-        // ---- ragged array tails (at most 3 elements each; only the tile that reaches the array
-        //      end).  Block-uniform branch; the barrier orders these writes after the zeros /
-        //      sentinels the chunk owners stored into the same slots above.
-        const bool nz_tail = c1.y > last_full_nz + 4;
-        const bool ro_tail = first + tile_rows > last_full_ro + 4;
-        if (nz_tail || ro_tail) {
-            __syncthreads();
-            const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
-            if (nz_tail && j < c1.y && j >= c0.y)
-                s_prod_raw[j - a0] = ld_stream(p.values + j) * p.x[ld_stream(p.cols + j)];
-            const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
-            const int r = i - first;
-            if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream(row_offsets + i) - c0.y;
-        }
-        __syncthreads();
+        stage_tile<V, BLOCK, IPT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
         // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
         if (has_next) issue_nonzero_loads<V, BLOCK, IPT>(p, n0, n1, regs);
         if (ABLATE == 1) {
@@ -606,17 +626,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, con
 // Fixed association order => bitwise reproducible results.
 // ---------------------------------------------------------------------------
 template <typename V, int BLOCK, int IPT>
-__global__ __launch_bounds__(BLOCK) void fixup_kernel(const Carry<V> *__restrict__ in, int n,
-                                                      Carry<V> *__restrict__ out, V *__restrict__ y, int rows,
-                                                      V alpha)
+__device__ __forceinline__ void fixup_chunk(const Carry<V> *in, int n, int chunk, bool multi, Carry<V> *out, V *y,
+                                            int rows, V alpha, int *s_wave_key, V *s_wave_val)
 {
     constexpr int CHUNK = BLOCK * IPT;
-    constexpr int NW = BLOCK / WAVE;
-    __shared__ int s_wave_key[NW];
-    __shared__ V s_wave_val[NW];
-    const bool multi = gridDim.x > 1;
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * CHUNK;
+    const int base = chunk * CHUNK;
     const int key0 = in[base].key;           // base < n by construction of the grid
 
     int keys[IPT]; V vals[IPT];
@@ -635,28 +650,113 @@ __global__ __launch_bounds__(BLOCK) void fixup_kernel(const Carry<V> *__restrict
     if (tid > 0 && first_i - 1 >= n) cur = 0x7fffffff;
     V total = 0;
     int first_key = -1; V first_total = 0; bool have_first = false;
-    auto emit = [&](int key, V sum) {
-        if (multi && key == key0) { Carry<V> c; c.key = key; c.value = sum; out[2 * blockIdx.x] = c; }
-        else if (key < rows) y[key] += alpha * sum;
-    };
+    // Segments this thread closes are collected (slot k = item index that closed them) and
+    // applied afterwards in one batch of independent loads followed by the stores: a
+    // load-add-store per segment in sequence made each thread wait for up to IPT dependent
+    // memory round trips.
+    int ekey[IPT]; V esum[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
+        ekey[k] = -1; esum[k] = 0;
         if (keys[k] != cur) {
             if (!have_first) { have_first = true; first_key = cur; first_total = total; }
-            else emit(cur, total);
+            else { ekey[k] = cur; esum[k] = total; }
             cur = keys[k]; total = vals[k];
         } else total += vals[k];
     }
     int prev_key, agg_key; V carry_in, agg_val;
     block_exclusive_rbk<V, BLOCK>(cur, total, s_wave_key, s_wave_val, prev_key, carry_in, agg_key, agg_val);
-    if (have_first) emit(first_key, first_total + ((tid > 0 && prev_key == first_key) ? carry_in : (V) 0));
+    int fkey = -1; V fsum = 0;
+    if (have_first) { fkey = first_key; fsum = first_total + ((tid > 0 && prev_key == first_key) ? carry_in : (V) 0); }
     // threads whose whole range is one key contributed through the scan only.
+    int lkey = -1; V lsum = 0;                         // the chunk's open last segment (last thread)
     if (tid == BLOCK - 1) {
         if (multi) {
-            Carry<V> c; c.key = agg_key; c.value = agg_val; out[2 * blockIdx.x + 1] = c;
-            if (agg_key == key0) { Carry<V> z; z.key = key0; z.value = 0; out[2 * blockIdx.x] = z; }
-        } else if (agg_key < rows) y[agg_key] += alpha * agg_val;
+            Carry<V> c; c.key = agg_key; c.value = agg_val; out[2 * chunk + 1] = c;
+            if (agg_key == key0) { Carry<V> z; z.key = key0; z.value = 0; out[2 * chunk] = z; }
+        } else { lkey = agg_key; lsum = agg_val; }
     }
+    // a segment with the chunk's first key may continue from the previous chunk: next level
+    if (multi && fkey == key0) { Carry<V> c; c.key = fkey; c.value = fsum; out[2 * chunk] = c; fkey = -1; }
+#pragma unroll
+    for (int k = 0; k < IPT; ++k)
+        if (multi && ekey[k] == key0) { Carry<V> c; c.key = ekey[k]; c.value = esum[k]; out[2 * chunk] = c; ekey[k] = -1; }
+    // batched y[key] += alpha * sum (keys of one thread are distinct)
+    V old[IPT], fold = 0, lold = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) { const bool ok = ekey[k] >= 0 && ekey[k] < rows; old[k] = ok ? y[ekey[k]] : (V) 0; }
+    if (fkey >= 0 && fkey < rows) fold = y[fkey];
+    if (lkey >= 0 && lkey < rows && lkey != fkey) lold = y[lkey];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) if (ekey[k] >= 0 && ekey[k] < rows) y[ekey[k]] = old[k] + alpha * esum[k];
+    if (fkey >= 0 && fkey < rows) { fold += alpha * fsum; if (lkey == fkey) fold += alpha * lsum; y[fkey] = fold; }
+    if (lkey >= 0 && lkey < rows && lkey != fkey) y[lkey] = lold + alpha * lsum;
+}
+
+template <typename V, int BLOCK, int IPT>
+__global__ __launch_bounds__(BLOCK) void fixup_kernel(const Carry<V> *__restrict__ in, int n,
+                                                      Carry<V> *__restrict__ out, V *__restrict__ y, int rows,
+                                                      V alpha)
+{
+    constexpr int NW = BLOCK / WAVE;
+    __shared__ int s_wave_key[NW];
+    __shared__ V s_wave_val[NW];
+    fixup_chunk<V, BLOCK, IPT>(in, n, blockIdx.x, gridDim.x > 1, out, y, rows, alpha, s_wave_key, s_wave_val);
+}
+
+// ---------------------------------------------------------------------------
+// Small problems (at most one resident wave of tiles, <= 2048): every block finds
+// its own two tile coordinates -- wave 0 searches the tile's start diagonal and
+// wave 1 its end diagonal, concurrently, with the 64-ary wave search -- so the
+// coordinate pass (a launch and 6-9 us) disappears; the persistent kernel's
+// prefetch has nothing to overlap with at this size anyway.  Measured: -5 % on a
+// 3 M-nnz R-MAT matrix; +8 % (worse) at 11 000 tiles, hence the threshold.
+// Tried and removed: applying the carries in the same launch (last block to take
+// a ticket runs the fix-up after an agent-scope release/acquire, CDNA guide G16):
+// ~1800 release fences + ticket atomics on one word cost ~80 us, against ~10 us
+// for the separate fix-up launch.
+// ---------------------------------------------------------------------------
+template <typename V, int BLOCK, int IPT, bool AXPBY>
+__global__ __launch_bounds__(BLOCK) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
+                                                           Carry<V> *__restrict__ carries, int num_tiles)
+{
+    constexpr int TILE = BLOCK * IPT;
+    constexpr int NW = BLOCK / WAVE;
+    constexpr int CPT = IPT / 4 + 1;
+    constexpr int SLOTS = CPT * BLOCK * 4;
+    static_assert(BLOCK >= 2 * WAVE, "two waves search");
+    __shared__ __attribute__((aligned(16))) int s_end_raw[SLOTS];
+    __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
+    __shared__ int s_wave_key[NW];
+    __shared__ V s_wave_val[NW];
+    __shared__ Coord s_coord[2];
+
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const long long total = (long long) p.rows + p.nnz;
+    {
+        const int wave = tid / WAVE;
+        if (wave < 2) {
+            const long long d = (long long) (tile + wave) * TILE;
+            const Coord c = wave_merge_path_search((int) (d < total ? d : total), p.row_end, p.rows, p.nnz);
+            if ((tid & (WAVE - 1)) == 0) s_coord[wave] = c;
+        }
+    }
+    __syncthreads();
+    const Coord c0 = s_coord[0], c1 = s_coord[1];
+    if (tid == 0) {                                  // keep the coordinates inspectable (mspmv_debug_read_tiles)
+        coords[tile] = c0;
+        if (tile == num_tiles - 1) coords[num_tiles] = c1;
+    }
+    const int last_full_nz = (p.nnz & ~3) - 4;
+    const int last_full_ro = ((p.rows + 1) & ~3) - 4;
+    TileRegs<V, BLOCK, IPT> regs;
+    issue_nonzero_loads<V, BLOCK, IPT>(p, c0, c1, regs);
+    stage_tile<V, BLOCK, IPT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+    const int pshift = c0.y - (c0.y & ~3);
+    const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
+    consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw + pshift,
+                                           s_prod_raw, s_wave_key, s_wave_val, carries + tile);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

@@ -136,19 +136,28 @@ SHAPES = {
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-def test_random_and_degenerate_shapes(M, shape, prec):
+@pytest.mark.parametrize("path", ["single_launch", "multi_launch"])
+def test_random_and_degenerate_shapes(M, shape, prec, path):
+    """Both dispatch paths: small problems take tile_kernel_fused (own coordinate search, carries
+    applied by the last block); MSPMV_TUNE_NO_FUSED forces the large-problem pipeline
+    (coordinate pass + persistent kernel + fix-up launches) on the same inputs."""
     dtype, vb = DT[prec]
-    rng = np.random.default_rng(abs(hash(shape)) % 2**32)
+    rng = np.random.default_rng(sum(map(ord, shape)))
     rows, cols, lens = SHAPES[shape](rng)
     csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
     x = rng.uniform(-1, 1, size=cols).astype(dtype)
-    y, ws = run_gpu(M, csr, x)
-    assert not np.isnan(y).any(), "a row was never written"
-    check_strict(M, csr, x, y)
-    check_tiles(M, csr, x, ws)
-    # bitwise reproducible (deterministic fix-up)
-    y_again, _ = run_gpu(M, csr, x)
-    assert np.array_equal(y, y_again)
+    try:
+        M.set_tuning(vb, 0, 0, 16 if path == "multi_launch" else 0)
+        y, ws = run_gpu(M, csr, x)
+        assert not np.isnan(y).any(), "a row was never written"
+        check_strict(M, csr, x, y)
+        check_tiles(M, csr, x, ws)
+        # bitwise reproducible (deterministic fix-up), also across repeated ticket races
+        for _ in range(3):
+            y_again, _ = run_gpu(M, csr, x)
+            assert np.array_equal(y, y_again)
+    finally:
+        M.set_tuning(vb)
 
 
 def test_empty_matrix_and_zero_rows(M):
@@ -159,6 +168,18 @@ def test_empty_matrix_and_zero_rows(M):
         csr = O.Csr(7, 0, np.zeros(8, np.int32), np.zeros(0, np.int32), np.zeros(0, dtype))
         y, _ = run_gpu(M, csr, np.ones(0, dtype))
         assert np.array_equal(y, np.zeros(7, dtype))
+
+
+def test_large_path_launch_log(M, capfd):
+    csr = O.make("grid3d", 12, dtype=np.float64)
+    try:
+        M.set_tuning(8, 0, 0, 16)
+        y, _ = run_gpu(M, csr, np.ones(csr.cols), debug_synchronous=True)
+    finally:
+        M.set_tuning(8)
+    assert np.array_equal(y, O.spmv_gold(csr, np.ones(csr.cols)))
+    out = capfd.readouterr().out
+    assert "coords_scatter_kernel" in out and "tile_kernel" in out
 
 
 def test_all_ones_giant_row_is_exact(M):
@@ -175,7 +196,7 @@ def test_all_ones_giant_row_is_exact(M):
 
 @pytest.mark.parametrize("vb,block,ipt", [(4, 256, 5), (4, 256, 9), (4, 256, 11), (4, 128, 7), (4, 512, 7), (4, 256, 15),
                                           (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
-@pytest.mark.parametrize("flags", [0, 1, 2, 4, 8, 15])
+@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)
@@ -235,7 +256,7 @@ def test_runs_on_a_side_stream_and_with_debug_sync(M, capfd):
         y, _ = run_gpu(M, csr, x, stream=s, debug_synchronous=True)
     assert np.array_equal(y, O.spmv_gold(csr, x))
     out = capfd.readouterr().out
-    assert "tile_kernel" in out and "coords_scatter_kernel" in out
+    assert "tile_kernel_fused" in out
 
 
 def test_single_hip_runtime_loaded(M):

@@ -34,6 +34,9 @@ def workloads(names):
         elif n == "rmat":
             A = G.rmat_csr(22, 60_000_000, dtype=torch.float64, seed=G.SEED_C3)
             yield "rmat22_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "web":
+            A = G.rmat_csr(20, 3_105_536, dtype=torch.float64, seed=G.SEED_C3)
+            yield "rmat20_webbase_like_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "grid2d":
             import numpy as np
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
