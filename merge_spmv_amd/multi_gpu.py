@@ -105,6 +105,30 @@ class ShardedCsrMV:
             self._apply_carries()
         return self.y_local[: s.owned_rows]
 
+    def allgather_rows(self, y_owned, out=None):
+        """turn the row-sharded result into a replicated vector (the x of
+        the next SpMV in an iterative solver): one all-gather of fixed-size (padded) row
+        blocks, then each rank's block is copied to its row range.  This is the step whose
+        cost is set by xGMI bandwidth (rows * sizeof V bytes per GPU), unlike the 8-byte
+        carry exchange."""
+        torch, s = self.torch, self.shard
+        rows_total = int(s.row_split[-1])
+        if out is None:
+            out = torch.empty(rows_total, dtype=y_owned.dtype, device=y_owned.device)
+        if s.parts == 1:
+            out.copy_(y_owned)
+            return out
+        import torch.distributed as dist
+        width = int((s.row_split[1:] - s.row_split[:-1]).max())
+        send = torch.zeros(width, dtype=y_owned.dtype, device=y_owned.device)
+        send[: s.owned_rows] = y_owned
+        recv = torch.empty(s.parts * width, dtype=y_owned.dtype, device=y_owned.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        for g in range(s.parts):
+            a, b = int(s.row_split[g]), int(s.row_split[g + 1])
+            out[a:b] = recv[g * width: g * width + (b - a)]
+        return out
+
     def _apply_carries(self):
         s = self.shard
         if self.y_local.is_cuda:

@@ -320,3 +320,48 @@ def test_sharded_merge_partition_on_one_gpu(M, parts):
         s = op.shard
         y[int(s.row_split[g]): int(s.row_split[g + 1])] = op.y_local[: s.owned_rows].cpu().numpy()
     check_strict(M, csr, x, y)
+
+
+def _host_csr(A):
+    return O.Csr(A.rows, A.cols, A.row_offsets.cpu().numpy(), A.column_indices.cpu().numpy(), A.values.cpu().numpy())
+
+
+def test_full_size_c4_degenerate(M):
+    """BASELINE config 4 at full size: fp32, 16 777 216 rows, one row of 67 108 864 nonzeros
+    (spanning ~24 000 tiles: long equal-key carry runs through both fix-up levels), one nonzero
+    in every 4096-th other row, everything else empty.  All-ones: closed form, exact in fp32
+    (2^26 is representable).  Random values: strict tolerance on every row."""
+    from merge_spmv_amd import generators as G
+    A = G.degenerate_csr(dtype=torch.float32, device="cuda", ones=True)
+    x = torch.ones(A.cols, dtype=torch.float32, device="cuda")
+    y = M.csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols)
+    lens = torch.diff(A.row_offsets.to(torch.int64)).to(torch.float32)
+    assert torch.equal(y, lens)
+    assert int((lens == 0).sum()) > 16_000_000 and float(lens.max()) == float(1 << 26)
+    B = G.degenerate_csr(dtype=torch.float32, device="cuda", ones=False)
+    xr = G.uniform_pm1(G.SEED_C4 + 2, B.cols, torch.float32, "cuda")
+    yr = M.csrmv(B.values, B.row_offsets, B.column_indices, xr, num_cols=B.cols)
+    torch.cuda.synchronize()
+    csr = _host_csr(B)
+    g, s = O.spmv_gold_acc64(csr, xr.cpu().numpy())
+    ok, worst = O.strict_check(csr, yr.cpu().numpy(), g, s, items_per_thread=11)
+    assert ok, worst
+
+
+def test_large_rmat_fp64_power_law(M):
+    """BASELINE config 3 stand-in (no SuiteSparse files offline): R-MAT scale 22, 60 M edges,
+    fp64, duplicates kept -- heavy row-length skew; strict tolerance on every row, and the
+    result is bitwise identical across repeated calls."""
+    from merge_spmv_amd import generators as G
+    A = G.rmat_csr(22, 60_000_000, dtype=torch.float64, device="cuda", seed=G.SEED_C3)
+    x = G.uniform_pm1(G.SEED_C3 + 2, A.cols, torch.float64, "cuda")
+    y = M.csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols)
+    y2 = M.csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    csr = _host_csr(A)
+    lens = np.diff(csr.row_offsets.astype(np.int64))
+    assert lens.max() > 1000 * max(lens.mean(), 1)          # genuinely skewed
+    g, s = O.spmv_gold_acc64(csr, x.cpu().numpy())
+    ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=7)
+    assert ok, worst

@@ -126,3 +126,41 @@ def test_uniform_shard_matches_sharding_the_whole_matrix(parts):
         assert torch.equal(got.column_indices, want.column_indices)
         assert torch.equal(got.values, want.values)
         assert np.array_equal(got.row_split, want.row_split) and np.array_equal(got.nz_split, want.nz_split)
+
+
+def _worker_iter(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        csr, x = make_square()
+        shard = MG.shard_from_host_csr(csr.row_offsets, csr.column_indices, csr.values, csr.cols, rank, world, device="cpu")
+        op = MG.ShardedCsrMV(shard, local_spmv=oracle_local_spmv)
+        xt = torch.from_numpy(x)
+        for _ in range(3):                                  # x <- A x, three times
+            xt = op.allgather_rows(op(xt)).clone()
+        out[rank] = xt.numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def make_square():
+    rng = np.random.default_rng(5)
+    n = 300
+    lens = rng.integers(0, 5, n); lens[7] = 900
+    off = np.zeros(n + 1, np.int64); np.cumsum(lens, out=off[1:])
+    col = rng.integers(0, n, int(off[-1])).astype(np.int32)
+    val = rng.integers(-1, 2, int(off[-1])).astype(np.float64)
+    return O.Csr(n, n, off.astype(np.int32), col, val), rng.integers(-1, 2, n).astype(np.float64)
+
+
+def test_iterated_spmv_with_row_allgather():
+    """N3: y -> x redistribution; three SpMV iterations on 2 ranks equal the serial result."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker_iter, args=(world, _free_port(), out), nprocs=world, join=True)
+    csr, x = make_square()
+    want = x
+    for _ in range(3):
+        want = O.spmv_gold(csr, want)
+    for rank in range(world):
+        assert np.array_equal(out[rank], want)
