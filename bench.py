@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", default=None, help="development: BLOCKxIPT[:flags] passed to mspmv_set_tuning")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +105,10 @@ def main():
 
     rows_per_gpu, npr, default_dtype = WORKLOADS[args.workload]
     dtype_name = args.dtype or default_dtype
+    if args.tune:
+        shape, _, fl = args.tune.partition(":")
+        b, _, i = shape.partition("x")
+        M.set_tuning(4 if dtype_name == "f32" else 8, int(b or 0), int(i or 0), int(fl or "0", 0))
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
     rows = rows_per_gpu * world

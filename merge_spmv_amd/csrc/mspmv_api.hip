@@ -185,21 +185,23 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
         if (vec) {
             // resident grid: blocks_per_cu * CUs blocks walk the tiles with a software-prefetched stream
-            // (size the grid by what is actually resident: a block that has to wait for a slot
-            // would do its whole strided share of tiles after everyone else)
-            int per_cu = (L.flags >> 8) & 0xff;
-            if (per_cu == 0) {
-                static std::atomic<int> resident{0};           // one per <V, BLOCK, IPT> instantiation
-                per_cu = resident.load(std::memory_order_relaxed);
-                if (per_cu == 0) {
-                    int n = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tile_kernel_persistent<V, BLOCK, IPT, false, true>, BLOCK, 0) != hipSuccess || n < 1) n = 4;
-                    per_cu = std::min(n, 2048 / BLOCK);
-                    resident.store(per_cu, std::memory_order_relaxed);
-                }
-            }
-            const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
-#define MSPMV_LAUNCH_P(...) hipLaunchKernelGGL((tile_kernel_persistent<V, BLOCK, IPT, __VA_ARGS__>), dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles)
+            // (sized by what is actually resident for THIS kernel variant: a block that has to wait
+            // for a slot would do its whole strided share of tiles after everyone else)
+            const int forced = (L.flags >> 8) & 0xff;
+#define MSPMV_LAUNCH_P(...)                                                                                        \
+            do {                                                                                                   \
+                auto kernel = tile_kernel_persistent<V, BLOCK, IPT, __VA_ARGS__>;                                  \
+                static std::atomic<int> resident{0};      /* one per kernel variant */                              \
+                int per_cu = forced ? forced : resident.load(std::memory_order_relaxed);                            \
+                if (per_cu == 0) {                                                                                 \
+                    int n = 0;                                                                                     \
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n < 1) n = 4; \
+                    per_cu = std::min(n, 2048 / BLOCK);                                                            \
+                    resident.store(per_cu, std::memory_order_relaxed);                                             \
+                }                                                                                                  \
+                const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, (long long) per_cu * device_cus()); \
+                hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);   \
+            } while (0)
             const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
             if (ablate == 1) MSPMV_LAUNCH_P(false, false, 1);
             else if (ablate == 2) MSPMV_LAUNCH_P(false, false, 2);

@@ -266,6 +266,14 @@ __device__ __forceinline__ void st_lds4(double *p, const double (&v)[4])
 __device__ __forceinline__ void st_lds4(int *p, const int (&v)[4])
 { int4v w; w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3]; *reinterpret_cast<int4v *>(p) = w; }
 
+// LDS index swizzle of the staged products.  Thread t of the walk reads products around index
+// t*IPT - (rows before it); when rows have a regular length the per-lane stride resonates with
+// the 32 banks (dense 32-nnz rows, IPT = 11: lanes l, l+3, l+6 ... hit one bank, an 11-way
+// conflict: SQ_LDS_BANK_CONFLICT was 56 % of all LDS cycles).  XOR-ing index bits 2..4 with
+// bits 5..7 keeps every 4-element chunk contiguous and 16-byte aligned (the staging writes
+// whole chunks) and moves indices 32 apart to different banks.
+__device__ __forceinline__ int swz_prod(int i) { return i ^ (((i >> 5) & 7) << 2); }
+
 // ---------------------------------------------------------------------------
 // The LDS phases of a tile, shared by both tile kernels: per-thread merge-path
 // search on diagonal tid*IPT, the IPT-step path walk, the block-wide carry
@@ -278,12 +286,13 @@ __device__ __forceinline__ void st_lds4(int *p, const int (&v)[4])
 //               array for the last tile);
 //   s_prod[j] = values[j] * x[cols[j]] for the tile's nonzeros.
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int IPT, bool AXPBY, int ABLATE = 0>
+template <typename V, int BLOCK, int IPT, bool AXPBY, int ABLATE = 0, bool SWZ = false>
 __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
                                                  const int *s_end, const V *s_prod, V *s_y, int *s_wave_key,
-                                                 V *s_wave_val, Carry<V> *__restrict__ carry_out)
+                                                 V *s_wave_val, Carry<V> *__restrict__ carry_out, int pshift = 0)
 {
-    // s_y (tile_rows entries) may alias the memory behind s_prod.
+    // s_y (tile_rows entries) may alias the memory behind s_prod.  SWZ: s_prod is the raw
+    // (unshifted) array, product j lives at swz_prod(pshift + j).
     // Straight-line code throughout: divergent branches in the search and the walk made
     // every wave execute both sides of each step (measured 15-23 % of the kernel on
     // short-row matrices).  Requirements on the staging: s_end[r] = +inf for every
@@ -324,7 +333,7 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
         int cnt = 0;
 #pragma unroll
         for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
-            prod[k] = s_prod[nz + k - cnt];
+            prod[k] = SWZ ? s_prod[swz_prod(pshift + nz + k - cnt)] : s_prod[nz + k - cnt];
             cnt += (mask >> k) & 1u;
         }
     }
@@ -439,6 +448,30 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
 // <= 3 elements of a ragged array tail are read by scalar loads in a rarely
 // taken branch.  Nothing outside [0,nnz) / [0,rows] is ever read.
 // ---------------------------------------------------------------------------
+// Resident blocks per CU the vectorised tile kernels are compiled for: what their LDS
+// footprint admits (160 KiB per CU), at most 32 waves per CU.  Passed to __launch_bounds__ as
+// waves per SIMD: left alone, hipcc spent 92-104 VGPRs on these kernels (4-5 waves/SIMD); told
+// the target it fits 64-80 without spilling, which is what actually sets the residency.
+template <typename V, int BLOCK, int IPT>
+constexpr int tile_blocks_per_cu()
+{
+    constexpr int slots = (IPT / 4 + 1) * BLOCK * 4;
+    constexpr int lds = slots * (4 + (int) sizeof(V)) + 256;
+    constexpr int by_lds = 163840 / lds;
+    constexpr int by_waves = 2048 / BLOCK;
+    return by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+}
+template <typename V, int BLOCK, int IPT, bool RELAX = false>
+constexpr int tile_waves_per_simd()
+{
+    // fp64 and the axpby / remap variants need a few more registers: ask for one wave less
+    // (and never more than 6 for fp64) rather than let them spill
+    int w = (tile_blocks_per_cu<V, BLOCK, IPT>() * BLOCK + 255) / 256;
+    if (sizeof(V) == 8 && w > 6) w = 6;
+    if (RELAX && w > 4) w -= 1;
+    return w;
+}
+
 template <typename V, int BLOCK, int IPT>
 struct TileRegs {
     static constexpr int CPT = IPT / 4 + 1;   // 4-element chunks per thread: covers TILE + 3
@@ -531,7 +564,7 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
             const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
             prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
         }
-        st_lds4(&s_prod_raw[4 * chunk], prod);
+        st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
     }
     // ---- ragged array tails (at most 3 elements each; only the tile that reaches the array
     //      end).  Block-uniform branch; the barrier orders these writes after the zeros /
@@ -542,7 +575,7 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
         __syncthreads();
         const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
         if (nz_tail && j < c1.y && j >= c0.y)
-            s_prod_raw[j - a0] = ld_stream(p.values + j) * p.x[ld_stream(p.cols + j)];
+            s_prod_raw[swz_prod(j - a0)] = ld_stream(p.values + j) * p.x[ld_stream(p.cols + j)];
         const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
         const int r = i - first;
         if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream(row_offsets + i) - c0.y;
@@ -551,7 +584,7 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
 }
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, int ABLATE = 0>
-__global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY || XCD_REMAP || ABLATE != 0)>())) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
 {
     constexpr int NW = BLOCK / WAVE;
@@ -604,8 +637,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_persistent(Params<V> p, con
             // ablation (development): staging only -- keep the LDS data live, skip search/walk/scan
             if (s_prod_raw[tid] == (V) 12345.678 && s_end_raw[tid] == 77) carries[tile].key = 1;
         } else
-        consume_tile_lds<V, BLOCK, IPT, AXPBY, ABLATE>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw + pshift,
-                                                       s_prod_raw, s_wave_key, s_wave_val, carries + tile);
+        consume_tile_lds<V, BLOCK, IPT, AXPBY, ABLATE, true>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw,
+                                                             s_prod_raw, s_wave_key, s_wave_val, carries + tile, pshift);
         if (!has_next) break;
         __syncthreads();          // all LDS reads of this tile done before the next tile's staging writes
         seq = next_seq; tile = next; c0 = n0; c1 = n1;
@@ -717,7 +750,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_kernel(const Carry<V> *__restrict
 // for the separate fix-up launch.
 // ---------------------------------------------------------------------------
 template <typename V, int BLOCK, int IPT, bool AXPBY>
-__global__ __launch_bounds__(BLOCK) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>())) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
                                                            Carry<V> *__restrict__ carries, int num_tiles)
 {
     constexpr int TILE = BLOCK * IPT;
@@ -755,8 +788,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel_fused(Params<V> p, Coord *_
     stage_tile<V, BLOCK, IPT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
-    consume_tile_lds<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw + pshift,
-                                           s_prod_raw, s_wave_key, s_wave_val, carries + tile);
+    consume_tile_lds<V, BLOCK, IPT, AXPBY, 0, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw,
+                                                    s_prod_raw, s_wave_key, s_wave_val, carries + tile, pshift);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,
