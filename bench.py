@@ -8,8 +8,10 @@ A "step" is one y = A*x through the C ABI (include/mspmv.h) on the synthetic
 CSR workload BASELINE.json's metric is quoted on for one GPU -- config C2:
 fp32, 3 125 000 x 3 125 000, exactly 32 nnz/row = 100 000 000 nnz, uniform
 random columns.  Inputs are resident in HBM before timing.
-With N GPUs the matrix has N x 3 125 000 rows (per-GPU work fixed: weak
-scaling), is merge-partitioned by diagonal across the ranks
+With N GPUs the matrix has N x 3 125 000 rows over the SAME 3 125 000 columns
+(per-GPU rows, nonzeros and x working set all fixed: weak scaling; growing
+the column space with N would instead measure how the x gather falls out of
+cache), is merge-partitioned by diagonal across the ranks
 (merge_spmv_amd/multi_gpu.py) and each step adds the one RCCL all-gather of the
 boundary-row carries.  Rank 0 prints ONE JSON line.
 
@@ -112,7 +114,7 @@ def main():
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
     rows = rows_per_gpu * world
-    cols = rows if args.workload == "c2" else npr
+    cols = rows_per_gpu if args.workload == "c2" else npr
     nnz_total = rows * npr
     if args.workload != "c2" and world > 1:
         raise SystemExit("only the c2 workload is sharded across GPUs")

@@ -117,6 +117,8 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_NO_VEC     4   /* force the one-block-per-tile dword-per-lane kernel (the path taken for unaligned arrays) */
 #define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by per-boundary wave search instead of the one-pass scatter */
 #define MSPMV_TUNE_NO_FUSED   16  /* never use the single-launch small-problem kernel */
+#define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
+#define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
 /* bits 8..15 of flags: resident blocks per CU of the persistent grid (0 = default 8) */
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);

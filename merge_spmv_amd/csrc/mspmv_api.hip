@@ -155,8 +155,9 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         prof_mark(stream, slot, 0);
         prof_mark(stream, slot, 1);
         const unsigned grid = (unsigned) L.num_tiles;
-        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
-        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        // (small problems always fit the Infinity Cache: ordinary loads)
+        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
     } else {
     // 1. tile boundary coordinates
@@ -202,14 +203,19 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                 const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, (long long) per_cu * device_cus()); \
                 hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);   \
             } while (0)
+            // CSR streams: ordinary loads while the matrix fits the 256 MB Infinity Cache (it then
+            // stays there between the SpMVs of a solver), non-temporal loads beyond (they keep x in L2)
+            const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
+            const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (200ull << 20));
             const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
-            if (ablate == 1) MSPMV_LAUNCH_P(false, false, 1);
-            else if (ablate == 2) MSPMV_LAUNCH_P(false, false, 2);
-            else if (ablate == 3) MSPMV_LAUNCH_P(false, false, 3);
-            else if (ablate == 4) MSPMV_LAUNCH_P(false, false, 4);
-            else if (axpby) { if (remap) MSPMV_LAUNCH_P(true, true); else MSPMV_LAUNCH_P(true, false); }
-            else if (remap) MSPMV_LAUNCH_P(false, true);
-            else MSPMV_LAUNCH_P(false, false);
+            if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1);
+            else if (ablate == 2) MSPMV_LAUNCH_P(false, false, true, 2);
+            else if (ablate == 3) MSPMV_LAUNCH_P(false, false, true, 3);
+            else if (ablate == 4) MSPMV_LAUNCH_P(false, false, true, 4);
+            else if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true); else MSPMV_LAUNCH_P(true, false, false); }
+            else if (remap) { if (nt) MSPMV_LAUNCH_P(false, true, true); else MSPMV_LAUNCH_P(false, true, false); }
+            else if (nt) MSPMV_LAUNCH_P(false, false, true);
+            else MSPMV_LAUNCH_P(false, false, false);
 #undef MSPMV_LAUNCH_P
         } else {
             if (axpby) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
@@ -393,7 +399,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | 0xff00 | 0x70000)) return hipErrorInvalidValue;
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | 0xff00 | 0x70000)) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)

@@ -181,16 +181,50 @@ __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__rest
 // path), so "same key" == "same segment"; the combine is the reference's
 // ReduceByKeyOp<Sum> (thread_operators.cuh:291-301).
 // ---------------------------------------------------------------------------
+// Data-parallel-primitive (DPP) moves: cross-lane operands delivered inside the VALU
+// instead of through the LDS crossbar (__shfl_up lowers to ds_bpermute_b32, ~100 cycles
+// of dependent latency per step; a DPP move costs a VALU slot).  Lanes that receive
+// nothing (out of the row for row_shr, rows masked off for the broadcasts) keep `old`.
+//   row_shr:n   = 0x110 + n   shift right by n inside each row of 16 lanes
+//   row_bcast15 = 0x142       lane 15 of each row -> all lanes of the next row
+//   row_bcast31 = 0x143       lane 31 -> lanes 32..63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float src)
+{
+    return __builtin_bit_cast(float, dpp_move<CTRL, ROW_MASK>(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double old, double src)
+{
+    const long long o = __builtin_bit_cast(long long, old), v = __builtin_bit_cast(long long, src);
+    const int lo = dpp_move<CTRL, ROW_MASK>((int) o, (int) v);
+    const int hi = dpp_move<CTRL, ROW_MASK>((int) (o >> 32), (int) (v >> 32));
+    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned) lo);
+}
+
+template <typename V, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void rbk_step(int key, V &val)
+{
+    const int k2 = dpp_move<CTRL, ROW_MASK>(-1, key);       // -1: "no source lane", never equals a key
+    const V v2 = dpp_move<CTRL, ROW_MASK>((V) 0, val);
+    val += k2 == key ? v2 : (V) 0;
+}
+
 template <typename V>
 __device__ __forceinline__ V wave_segmented_inclusive_sum(int key, V val)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const int k2 = __shfl_up(key, d, WAVE);
-        const V v2 = __shfl_up(val, d, WAVE);
-        if (lane >= d && k2 == key) val += v2;
-    }
+    // keys are >= 0 and non-decreasing across lanes: equal key == same segment
+    rbk_step<V, 0x111, 0xf>(key, val);      // row_shr:1
+    rbk_step<V, 0x112, 0xf>(key, val);      // row_shr:2
+    rbk_step<V, 0x114, 0xf>(key, val);      // row_shr:4
+    rbk_step<V, 0x118, 0xf>(key, val);      // row_shr:8   -> inclusive within each 16-lane row
+    rbk_step<V, 0x142, 0xa>(key, val);      // row_bcast15 into rows 1 and 3
+    rbk_step<V, 0x143, 0xc>(key, val);      // row_bcast31 into rows 2 and 3
     return val;
 }
 
@@ -236,24 +270,36 @@ __device__ __forceinline__ void block_exclusive_rbk(int key, V val, int *s_wave_
 // lane (a dword-per-lane stream tops out at 4.0 TB/s on MI355X, 16 B/lane at
 // 6.4 TB/s).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int ld_stream(const int *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+// NT = false: ordinary loads.  A matrix that fits the 256 MB Infinity Cache stays there
+// between SpMVs of an iterative solver when it is read with ordinary loads (measured +9-10 %
+// at 58 MB and 272 MB), while for larger matrices the non-temporal form wins (+3-6 %): the
+// dispatcher picks per call from the matrix's byte size.
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 
 template <typename T> struct Vec4;
 template <> struct Vec4<int> { int4v v; __device__ __forceinline__ int get(int i) const { return v[i]; } };
 template <> struct Vec4<float> { float4v v; __device__ __forceinline__ float get(int i) const { return v[i]; } };
 template <> struct Vec4<double> { double2v a, b; __device__ __forceinline__ double get(int i) const { return i < 2 ? a[i] : b[i - 2]; } };
 
+template <bool NT>
 __device__ __forceinline__ Vec4<int> ld_stream4(const int *p)
-{ Vec4<int> r; r.v = __builtin_nontemporal_load(reinterpret_cast<const int4v *>(p)); return r; }
+{
+    Vec4<int> r; const int4v *q = reinterpret_cast<const int4v *>(p);
+    r.v = NT ? __builtin_nontemporal_load(q) : *q; return r;
+}
+template <bool NT>
 __device__ __forceinline__ Vec4<float> ld_stream4(const float *p)
-{ Vec4<float> r; r.v = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(p)); return r; }
+{
+    Vec4<float> r; const float4v *q = reinterpret_cast<const float4v *>(p);
+    r.v = NT ? __builtin_nontemporal_load(q) : *q; return r;
+}
+template <bool NT>
 __device__ __forceinline__ Vec4<double> ld_stream4(const double *p)
 {
-    Vec4<double> r;
-    r.a = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p));
-    r.b = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(p) + 1);
+    Vec4<double> r; const double2v *q = reinterpret_cast<const double2v *>(p);
+    r.a = NT ? __builtin_nontemporal_load(q) : q[0];
+    r.b = NT ? __builtin_nontemporal_load(q + 1) : q[1];
     return r;
 }
 __device__ __forceinline__ void st_lds4(float *p, const float (&v)[4])
@@ -479,7 +525,7 @@ struct TileRegs {
     Vec4<V> val[CPT];
 };
 
-template <typename V, int BLOCK, int IPT>
+template <typename V, int BLOCK, int IPT, bool NT>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
                                                     TileRegs<V, BLOCK, IPT> &r)
 {
@@ -494,8 +540,8 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
         // the array is not fetched: those lanes re-read the tile's first chunk instead (one
         // cached address), so no byte of HBM traffic is spent on data this tile does not use
         e0 = (e0 < c1.y && e0 <= last_full) ? e0 : safe;
-        r.col[k] = ld_stream4(p.cols + e0);
-        r.val[k] = ld_stream4(p.values + e0);
+        r.col[k] = ld_stream4<NT>(p.cols + e0);
+        r.val[k] = ld_stream4<NT>(p.values + e0);
     }
 }
 
@@ -503,7 +549,7 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // and x gathers are issued, tile-relative row ends and products land in LDS (every slot of
 // both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
 // and the block is synchronised.
-template <typename V, int BLOCK, int IPT>
+template <typename V, int BLOCK, int IPT, bool NT>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
                                            int last_full_nz, int last_full_ro)
@@ -526,7 +572,7 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
         const int q = tid + k * BLOCK;
         int i = i0 + 4 * q;
         i = (q < ro_chunks && i <= last_full_ro) ? i : ro_safe;
-        ro[k] = ld_stream4(row_offsets + i);
+        ro[k] = ld_stream4<NT>(row_offsets + i);
     }
     // ---- gather x for the current tile (its nonzeros were requested one iteration ago)
     V xv[CPT][4];
@@ -575,15 +621,15 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
         __syncthreads();
         const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
         if (nz_tail && j < c1.y && j >= c0.y)
-            s_prod_raw[swz_prod(j - a0)] = ld_stream(p.values + j) * p.x[ld_stream(p.cols + j)];
+            s_prod_raw[swz_prod(j - a0)] = ld_stream<NT>(p.values + j) * p.x[ld_stream<NT>(p.cols + j)];
         const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
         const int r = i - first;
-        if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream(row_offsets + i) - c0.y;
+        if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream<NT>(row_offsets + i) - c0.y;
     }
     __syncthreads();
 }
 
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, int ABLATE = 0>
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY || XCD_REMAP || ABLATE != 0)>())) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
 {
@@ -611,7 +657,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY |
     Coord c0 = coords[tile];
     Coord c1 = coords[tile + 1];
     TileRegs<V, BLOCK, IPT> regs;
-    issue_nonzero_loads<V, BLOCK, IPT>(p, c0, c1, regs);
+    issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;   // rows + 1 >= 4
 
@@ -630,9 +676,9 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY |
         const int next = has_next ? physical(next_seq) : tile;
         const Coord n0 = coords[next];
         const Coord n1 = coords[next + 1];
-        stage_tile<V, BLOCK, IPT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+        stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
         // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
-        if (has_next) issue_nonzero_loads<V, BLOCK, IPT>(p, n0, n1, regs);
+        if (has_next) issue_nonzero_loads<V, BLOCK, IPT, NT>(p, n0, n1, regs);
         if (ABLATE == 1) {
             // ablation (development): staging only -- keep the LDS data live, skip search/walk/scan
             if (s_prod_raw[tid] == (V) 12345.678 && s_end_raw[tid] == 77) carries[tile].key = 1;
@@ -749,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_kernel(const Carry<V> *__restrict
 // ~1800 release fences + ticket atomics on one word cost ~80 us, against ~10 us
 // for the separate fix-up launch.
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int IPT, bool AXPBY>
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>())) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
                                                            Carry<V> *__restrict__ carries, int num_tiles)
 {
@@ -784,8 +830,8 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
     TileRegs<V, BLOCK, IPT> regs;
-    issue_nonzero_loads<V, BLOCK, IPT>(p, c0, c1, regs);
-    stage_tile<V, BLOCK, IPT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+    issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
+    stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
     consume_tile_lds<V, BLOCK, IPT, AXPBY, 0, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw,

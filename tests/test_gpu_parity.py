@@ -196,7 +196,7 @@ def test_all_ones_giant_row_is_exact(M):
 
 @pytest.mark.parametrize("vb,block,ipt", [(4, 256, 5), (4, 256, 9), (4, 256, 11), (4, 128, 7), (4, 512, 7), (4, 256, 15),
                                           (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
-@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24])
+@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24, 48, 80])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)
