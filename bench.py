@@ -96,6 +96,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP merge-path kernels have no CPU fallback)")
+    # MSPMV_BENCH_ONE_DEVICE=1 + MSPMV_BENCH_BACKEND=gloo: exercise the multi-rank path on a
+    # single-GPU box (all ranks on cuda:0, carries exchanged through gloo) -- a functional
+    # check of the sharding / exchange code, not a measurement
+    if os.environ.get("MSPMV_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     M.load_library()
@@ -103,7 +108,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MSPMV_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     rows_per_gpu, npr, default_dtype = WORKLOADS[args.workload]
     dtype_name = args.dtype or default_dtype
