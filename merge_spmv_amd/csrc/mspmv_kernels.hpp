@@ -510,11 +510,13 @@ constexpr int tile_blocks_per_cu()
 template <typename V, int BLOCK, int IPT, bool RELAX = false>
 constexpr int tile_waves_per_simd()
 {
-    // fp64 and the axpby / remap variants need a few more registers: ask for one wave less
-    // (and never more than 6 for fp64) rather than let them spill
+    // one wave less than the LDS footprint admits (never more than 6 for fp64): with both
+    // staging paths in the kernel the tighter budget spills 3 registers per lane, and the
+    // measured difference between the two choices is within noise
     int w = (tile_blocks_per_cu<V, BLOCK, IPT>() * BLOCK + 255) / 256;
     if (sizeof(V) == 8 && w > 6) w = 6;
-    if (RELAX && w > 4) w -= 1;
+    if (w > 4) w -= 1;
+    (void) RELAX;
     return w;
 }
 
@@ -550,7 +552,7 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
 // and the block is synchronised.
 template <typename V, int BLOCK, int IPT, bool NT>
-__device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1,
+__device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
                                            int last_full_nz, int last_full_ro)
 {
@@ -629,6 +631,84 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
     __syncthreads();
 }
 
+// Interior tiles (all but the handful whose chunk loads would touch the last, ragged chunk of
+// an array -- the matrix's final tile in particular): no per-element predicates at all.
+//  * every column index in a loaded chunk is a valid index even when the element belongs to
+//    the neighbouring tile, so x is gathered unconditionally;
+//  * products of elements outside the tile land in LDS slots the walk never reads as
+//    nonzeros (an item past the tile's nonzeros is always a row end there, and a row end's
+//    product slot is read but discarded by a select, so even a NaN cannot leak);
+//  * row offsets past the tile's last row are REAL offsets (>= the tile's nonzero count), which
+//    serve as the "+inf" the search and the walk need: a row end of a later tile lies at
+//    least IPT path items past every thread of a full tile.
+// Only whole chunks beyond the needed range are redirected to a cached address (no HBM bytes
+// for data the tile does not use).  This removes ~200 of the ~1100 instructions per wave per tile.
+template <typename V, int BLOCK, int IPT, bool NT>
+__device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
+                                                    const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw,
+                                                    V *s_prod_raw)
+{
+    constexpr int CPT = IPT / 4 + 1;
+    const int tid = threadIdx.x;
+    const int *__restrict__ row_offsets = p.row_end - 1;
+    const int tile_rows = c1.x - c0.x;
+    const int first = c0.x + 1;
+    const int i0 = first & ~3;
+    const int eshift = first - i0;
+    Vec4<int> ro[CPT];
+    const int ro_chunks = (tile_rows + eshift + IPT + 3) / 4;     // row ends of the tile + the IPT the walk may peek at
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int q = tid + k * BLOCK;
+        const int i = q < ro_chunks ? i0 + 4 * q : i0;
+        ro[k] = ld_stream4<NT>(row_offsets + (unsigned) i);
+    }
+    V xv[CPT][4];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[k][i] = p.x[(unsigned) regs.col[k].get(i)];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int q = tid + k * BLOCK;
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ro[k].get(j) - c0.y;
+        if (q < ro_chunks) st_lds4(&s_end_raw[4 * q], v);
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int chunk = tid + k * BLOCK;
+        V prod[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) prod[i] = regs.val[k].get(i) * xv[k][i];
+        st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
+    }
+    __syncthreads();
+}
+
+// true when every vector load of the interior path stays inside full chunks of the arrays
+template <int IPT>
+__device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1, int tile, int num_tiles,
+                                                 int last_full_nz, int last_full_ro)
+{
+    const int first = c0.x + 1;
+    const int i0 = first & ~3;
+    const int ro_chunks = ((c1.x - c0.x) + (first - i0) + IPT + 3) / 4;
+    return tile != num_tiles - 1 && c1.y <= last_full_nz + 4 && i0 + 4 * ro_chunks <= last_full_ro + 4;
+}
+
+template <typename V, int BLOCK, int IPT, bool NT>
+__device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
+                                           const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
+                                           int last_full_nz, int last_full_ro)
+{
+    if (tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro))      // block-uniform
+        stage_tile_interior<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw);
+    else
+        stage_tile_careful<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+}
+
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY || XCD_REMAP || ABLATE != 0)>())) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
@@ -676,7 +756,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY |
         const int next = has_next ? physical(next_seq) : tile;
         const Coord n0 = coords[next];
         const Coord n1 = coords[next + 1];
-        stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+        stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
         // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
         if (has_next) issue_nonzero_loads<V, BLOCK, IPT, NT>(p, n0, n1, regs);
         if (ABLATE == 1) {
@@ -831,7 +911,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
     TileRegs<V, BLOCK, IPT> regs;
     issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
-    stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+    stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
     consume_tile_lds<V, BLOCK, IPT, AXPBY, 0, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw,
