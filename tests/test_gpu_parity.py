@@ -365,3 +365,27 @@ def test_large_rmat_fp64_power_law(M):
     g, s = O.spmv_gold_acc64(csr, x.cpu().numpy())
     ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=7)
     assert ok, worst
+
+
+def test_capturable_into_a_hip_graph(M):
+    """The C-ABI call is only kernel launches on the caller's stream (device attributes and
+    residency are queried once, outside capture), so it can be captured into a hipGraph and
+    replayed -- e.g. to amortise launch overhead in a solver loop over a small matrix."""
+    rng = np.random.default_rng(21)
+    for rows, dtype in ((3000, np.float32), (400000, np.float64)):
+        lens = rng.integers(0, 12, rows)
+        csr = random_csr(rng, rows, rows, lens, dtype)
+        x1 = rng.uniform(-1, 1, rows).astype(dtype); x2 = rng.uniform(-1, 1, rows).astype(dtype)
+        tdt = torch.float32 if dtype == np.float32 else torch.float64
+        val, off, col = dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices)
+        x = dev(x1.copy()); y = torch.zeros(rows, dtype=tdt, device="cuda")
+        ws = M.CsrMVWorkspace(rows, csr.nnz, tdt)
+        M.csrmv(val, off, col, x, y=y, workspace=ws)                 # warm-up outside capture (one-time queries)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            M.csrmv(val, off, col, x, y=y, workspace=ws)
+        for xin in (x1, x2):
+            x.copy_(dev(xin)); y.fill_(float("nan"))
+            g.replay(); torch.cuda.synchronize()
+            check_strict(M, csr, xin, y.cpu().numpy())
