@@ -28,6 +28,7 @@ int build(Handle *h, CsrMatrix<V> &csr, const char *kind, int a, int b, const ch
         else if (k == "grid3d") coo.InitGrid3d(a, false);
         else if (k == "wheel") coo.InitWheel(a);
         else if (k == "mtx") coo.InitMarket(path, (V) 1.0, false);
+        else if (k == "mtx_serial") coo.InitMarket(path, (V) 1.0, false, true);
         else return 2;
         csr.Init(coo);
     } catch (const std::exception &e) { h->text = e.what(); return 1; }
