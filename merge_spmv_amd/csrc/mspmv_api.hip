@@ -185,13 +185,25 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const unsigned grid = (unsigned) L.num_tiles;
         const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
         if (vec) {
-            // resident grid: blocks_per_cu * CUs blocks walk the tiles with a software-prefetched stream
-            // (sized by what is actually resident for THIS kernel variant: a block that has to wait
-            // for a slot would do its whole strided share of tiles after everyone else)
+            // Default: one tile per block, the hardware's block scheduler does the load balancing.
+            // The same kernel also runs "persistent" -- a block walks tiles b, b + grid, ... and
+            // requests the next tile's nonzeros before the LDS phases of the current one (tuning
+            // flags: tiles per block in bits 20-23, or blocks per CU in bits 8-15).  That form won
+            // 10-20 % while the in-tile reduction was the reference's per-thread path walk; with the
+            // flag/segmented-scan reduction a resident grid is 7-10 % SLOWER on streaming matrices
+            // (the blocks of a CU march through load bursts and LDS phases together, and the prefetch
+            // registers cost a wave of occupancy), and 2-4 tiles per block are within +-3 % of one.
             const int forced = (L.flags >> 8) & 0xff;
+            const int tpb_flag = (L.flags >> 20) & 0xf;
+            const int tpb = tpb_flag ? tpb_flag : 1;
+            const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
 #define MSPMV_LAUNCH_P(...)                                                                                        \
             do {                                                                                                   \
                 auto kernel = tile_kernel_persistent<V, BLOCK, IPT, __VA_ARGS__>;                                  \
+                if (!persist) {                                                                                    \
+                    hipLaunchKernelGGL(kernel, dim3((unsigned) L.num_tiles), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles); \
+                    break;                                                                                         \
+                }                                                                                                  \
                 static std::atomic<int> resident{0};      /* one per kernel variant */                              \
                 int per_cu = forced ? forced : resident.load(std::memory_order_relaxed);                            \
                 if (per_cu == 0) {                                                                                 \
@@ -200,22 +212,31 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                     per_cu = std::min(n, 2048 / BLOCK);                                                            \
                     resident.store(per_cu, std::memory_order_relaxed);                                             \
                 }                                                                                                  \
-                const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, (long long) per_cu * device_cus()); \
+                long long want = (long long) per_cu * device_cus();                                                \
+                if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
+                const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
                 hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);   \
             } while (0)
             // CSR streams: ordinary loads while the matrix fits the 256 MB Infinity Cache (it then
             // stays there between the SpMVs of a solver), non-temporal loads beyond (they keep x in L2)
             const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
             const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (200ull << 20));
-            const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
-            if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1);
-            else if (ablate == 2) MSPMV_LAUNCH_P(false, false, true, 2);
-            else if (ablate == 3) MSPMV_LAUNCH_P(false, false, true, 3);
-            else if (ablate == 4) MSPMV_LAUNCH_P(false, false, true, 4);
-            else if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true); else MSPMV_LAUNCH_P(true, false, false); }
-            else if (remap) { if (nt) MSPMV_LAUNCH_P(false, true, true); else MSPMV_LAUNCH_P(false, true, false); }
-            else if (nt) MSPMV_LAUNCH_P(false, false, true);
-            else MSPMV_LAUNCH_P(false, false, false);
+            // development variants (always the persistent form): 1 = staging only (wrong results),
+            // 6 = cycle stamps (tools/trace_tiles.py), 7 = the per-thread path walk of the reference
+            bool persist = tpb_flag != 0 || forced != 0 || remap || ablate != 0;
+            if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
+            else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
+            else if (ablate == 7) MSPMV_LAUNCH_P(false, false, true, 7, true);
+            else if (remap) { if (nt) MSPMV_LAUNCH_P(false, true, true, 0, true); else MSPMV_LAUNCH_P(false, true, false, 0, true); }
+            else if (persist) {
+                if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true, 0, true); else MSPMV_LAUNCH_P(true, false, false, 0, true); }
+                else if (nt) MSPMV_LAUNCH_P(false, false, true, 0, true);
+                else MSPMV_LAUNCH_P(false, false, false, 0, true);
+            } else {
+                if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true, 0, false); else MSPMV_LAUNCH_P(true, false, false, 0, false); }
+                else if (nt) MSPMV_LAUNCH_P(false, false, true, 0, false);
+                else MSPMV_LAUNCH_P(false, false, false, 0, false);
+            }
 #undef MSPMV_LAUNCH_P
         } else {
             if (axpby) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
@@ -399,7 +420,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | 0xff00 | 0x70000)) return hipErrorInvalidValue;
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | 0xff00 | 0x70000 | 0xf00000)) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)
@@ -467,3 +488,10 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries, const int64_t
 }
 
 }  // extern "C"
+
+// development: where tile_kernel_persistent<..., ABLATE = 6> writes its cycle stamps (device pointer, 16*8 u64 per block)
+extern "C" int mspmv_dev_set_trace(void *d_buf)
+{
+    unsigned long long *ptr = static_cast<unsigned long long *>(d_buf);
+    return (int) hipMemcpyToSymbol(HIP_SYMBOL(mspmv::g_mspmv_trace), &ptr, sizeof(ptr));
+}

@@ -429,6 +429,173 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 }
 
 // ---------------------------------------------------------------------------
+// In-tile reduction of the production kernels: head flags + segmented scan.
+//
+// The reference walks the tile's merge path thread by thread (a binary search per
+// thread, then ITEMS dependent LDS reads, agent_spmv_orig.cuh:539-578); consume_tile_lds
+// above is that algorithm.  On CDNA4 it costs ~100 instructions per path item, which is what
+// bounds a streaming CsrMV here (39 lane-operations per fp32 nonzero are available at the HBM
+// peak).  The same tile result is obtained with no per-thread search and no dependent walk:
+//   * staging sets one bit per row START in a bit array over the tile's nonzeros (row r ends
+//     at tile-relative nonzero e => the next row starts at e: bit e, when e < tile_nnz; several
+//     empty rows set the same bit), plus the bit of the tile's first nonzero;
+//   * NONZERO PHASE: thread t owns the NPT consecutive staged products [t*NPT, (t+1)*NPT) (16-byte
+//     LDS reads), runs the segmented inclusive sum over them in registers, one block-wide
+//     segmented scan of (has-flag, running-sum) supplies the sum flowing in from the threads
+//     before it, and S[j] = "sum of the row containing nonzero j, up to j" is written back in place;
+//   * ROW PHASE: thread r of the tile's rows reads S at its row's last nonzero (0 for an empty
+//     row) and stores y[r] straight from registers, coalesced.  The row left open at the tile
+//     end is S at the tile's last nonzero: the carry.
+// Path items still bound a tile (rows + nonzeros <= BLOCK*IPT), tiles/carries/fix-up are
+// unchanged; only the association order inside a tile differs (sequential inside a thread's
+// NPT nonzeros, scan tree across threads), as it already did from the reference's.
+// Raw LDS positions outside [pshift, pshift + tile_nnz) may hold anything (the interior
+// staging path does not clear them): the bit at pshift isolates what precedes the tile and
+// nothing reads S past the tile's last nonzero.
+// ---------------------------------------------------------------------------
+// 16-byte units of the staged products are XOR-swizzled when a thread of the nonzero phase
+// owns 2 or 4 of them (lanes 8 or 4 apart would otherwise start in the same banks).
+template <typename V, int CPT>
+__device__ __forceinline__ int prod_unit(int u)
+{
+    constexpr int UPT = CPT * 4 * (int) sizeof(V) / 16;
+    return UPT == 4 ? u ^ ((u >> 4) & 3) : UPT == 2 ? u ^ ((u >> 4) & 1) : u;
+}
+template <typename V, int CPT>
+__device__ __forceinline__ int prod_slot(int e)      // element index (>= 0) in raw order -> LDS element index
+{
+    constexpr int EPU = 16 / (int) sizeof(V);
+    return prod_unit<V, CPT>(e / EPU) * EPU + (e % EPU);
+}
+template <int CPT>
+__device__ __forceinline__ void st_prod_chunk(float *s_prod_raw, int chunk, const float (&v)[4])
+{
+    st_lds4(&s_prod_raw[4 * prod_unit<float, CPT>(chunk)], v);
+}
+template <int CPT>
+__device__ __forceinline__ void st_prod_chunk(double *s_prod_raw, int chunk, const double (&v)[4])
+{
+    double2v a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+    *reinterpret_cast<double2v *>(&s_prod_raw[2 * prod_unit<double, CPT>(2 * chunk)]) = a;
+    *reinterpret_cast<double2v *>(&s_prod_raw[2 * prod_unit<double, CPT>(2 * chunk + 1)]) = b;
+}
+__device__ __forceinline__ void ld_unit(const float *p, float *out)
+{ const float4v w = *reinterpret_cast<const float4v *>(p); out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w; }
+__device__ __forceinline__ void ld_unit(const double *p, double *out)
+{ const double2v w = *reinterpret_cast<const double2v *>(p); out[0] = w.x; out[1] = w.y; }
+__device__ __forceinline__ void st_unit(float *p, const float *in)
+{ float4v w; w.x = in[0]; w.y = in[1]; w.z = in[2]; w.w = in[3]; *reinterpret_cast<float4v *>(p) = w; }
+__device__ __forceinline__ void st_unit(double *p, const double *in)
+{ double2v w; w.x = in[0]; w.y = in[1]; *reinterpret_cast<double2v *>(p) = w; }
+
+// one Kogge-Stone step of the wave's inclusive segmented sum over (flag, value) pairs
+template <typename V, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(int &f, V &v)
+{
+    const int f2 = dpp_move<CTRL, ROW_MASK>(0, f);
+    const V v2 = dpp_move<CTRL, ROW_MASK>((V) 0, v);
+    v += f ? (V) 0 : v2;
+    f |= f2;
+}
+// Block-wide EXCLUSIVE segmented sum: returns the sum of `val` over the threads before this
+// one back to (and including) the nearest preceding thread with flag set.  One barrier inside.
+template <typename V, int BLOCK>
+__device__ __forceinline__ V block_exclusive_segsum(bool flag, V val, int *s_wave_flag, V *s_wave_val)
+{
+    constexpr int NW = BLOCK / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    int f = flag ? 1 : 0;
+    V v = val;
+    seg_step<V, 0x111, 0xf>(f, v);      // row_shr:1
+    seg_step<V, 0x112, 0xf>(f, v);      // row_shr:2
+    seg_step<V, 0x114, 0xf>(f, v);      // row_shr:4
+    seg_step<V, 0x118, 0xf>(f, v);      // row_shr:8
+    seg_step<V, 0x142, 0xa>(f, v);      // row_bcast15 into rows 1 and 3
+    seg_step<V, 0x143, 0xc>(f, v);      // row_bcast31 into rows 2 and 3
+    if (lane == WAVE - 1) { s_wave_flag[wave] = f; s_wave_val[wave] = v; }
+    __syncthreads();
+    V pv = 0;                           // segmented sum of the preceding waves, in order
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+        if (w < wave) { const V wv = s_wave_val[w]; pv = s_wave_flag[w] ? wv : pv + wv; }
+    }
+    const int ef = __shfl_up(f, 1, WAVE);
+    const V ev = __shfl_up(v, 1, WAVE);
+    return lane == 0 ? pv : (ef ? ev : pv + ev);
+}
+
+template <typename V, int BLOCK, int IPT, bool AXPBY>
+__device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
+                                                   const int *s_end, V *s_prod_raw, unsigned *s_flag,
+                                                   int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
+                                                   int pshift, unsigned long long *tr = nullptr)
+{
+    constexpr int CPT = IPT / 4 + 1;
+    constexpr int NPT = CPT * 4;                  // staged products per thread
+    constexpr int EPU = 16 / (int) sizeof(V);     // elements per 16-byte unit
+    constexpr int UPT = NPT / EPU;
+    constexpr int FLAG_WORDS = CPT * BLOCK * 4 / 32 + 1;
+    static_assert(NPT <= 16 && FLAG_WORDS <= BLOCK, "flag word handling");
+    const int tid = threadIdx.x;
+
+    // ---- nonzero phase
+    V s[NPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) ld_unit(&s_prod_raw[prod_unit<V, CPT>(tid * UPT + u) * EPU], &s[u * EPU]);
+    const int base = tid * NPT;
+    const unsigned lo = s_flag[base >> 5], hi = s_flag[(base >> 5) + 1];
+    const unsigned m = (unsigned) ((((unsigned long long) hi << 32) | lo) >> (base & 31)) & ((1u << NPT) - 1u);
+    V run = 0;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        run = ((m >> k) & 1u) ? s[k] : run + s[k];
+        s[k] = run;
+    }
+    if (tr && tid == 0) tr[6] = clock64();
+    const V carry_in = block_exclusive_segsum<V, BLOCK>(m != 0u, run, s_wave_flag, s_wave_val);
+    const unsigned lead = (m & (0u - m)) - 1u;    // bits below the first row start (all ones when none)
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) s[k] += ((lead >> k) & 1u) ? carry_in : (V) 0;
+    if (tile_rows == 0) {
+        // block-uniform: no row ends in this tile (a slice of one long row): only the running sum
+        // at the tile's last nonzero is needed -- the carry.  No write-back, no third barrier.
+        if (tid < FLAG_WORDS) s_flag[tid] = 0u;
+        const int last = pshift + tile_nnz - 1;
+        if (tile_nnz > 0 ? tid == last / NPT : tid == 0) {
+            V v = 0;
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) v = (tile_nnz > 0 && k == last % NPT) ? s[k] : v;
+            Carry<V> c; c.key = c0.x; c.value = v;
+            *carry_out = c;
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) st_unit(&s_prod_raw[prod_unit<V, CPT>(tid * UPT + u) * EPU], &s[u * EPU]);
+    __syncthreads();
+    if (tr && tid == 0) tr[7] = clock64();
+    if (tid < FLAG_WORDS) s_flag[tid] = 0u;       // clean for the next tile's staging (after the loop's barrier)
+
+    // ---- row phase
+    V *__restrict__ y = p.y + c0.x;
+    for (int r = tid; r < tile_rows; r += BLOCK) {
+        const int e = s_end[r];
+        const int e0 = r > 0 ? s_end[r - 1] : 0;
+        const V sum = e > e0 ? s_prod_raw[prod_slot<V, CPT>(pshift + e - 1)] : (V) 0;
+        if (AXPBY) y[r] = p.alpha * sum + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
+        else y[r] = sum;
+    }
+    if (tid == BLOCK - 1) {
+        // the row left open at the tile end (ref: agent_spmv_orig.cuh:906-913)
+        const int e_last = tile_rows > 0 ? s_end[tile_rows - 1] : 0;
+        Carry<V> c; c.key = c0.x + tile_rows;
+        c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
+        *carry_out = c;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // One block per tile, dword-per-lane staging: the fallback for CSR arrays
 // whose base addresses are not 16-byte aligned and for tiny matrices.
 // ref: DeviceSpmvKernel / AgentSpmv::ConsumeTile, dispatch_spmv_orig.cuh:157-186,
@@ -515,8 +682,7 @@ constexpr int tile_waves_per_simd()
     // measured difference between the two choices is within noise
     int w = (tile_blocks_per_cu<V, BLOCK, IPT>() * BLOCK + 255) / 256;
     if (sizeof(V) == 8 && w > 6) w = 6;
-    if (w > 4) w -= 1;
-    (void) RELAX;
+    if (w > 4 && !RELAX) w -= 1;
     return w;
 }
 
@@ -551,10 +717,10 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // and x gathers are issued, tile-relative row ends and products land in LDS (every slot of
 // both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
 // and the block is synchronised.
-template <typename V, int BLOCK, int IPT, bool NT>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
-                                           int last_full_nz, int last_full_ro)
+                                           int last_full_nz, int last_full_ro, unsigned *s_flag)
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = threadIdx.x;
@@ -598,9 +764,14 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
             const int r = 4 * q - eshift + j;
             const bool in = r >= 0 && r < tile_rows && i <= last_full_ro;
             v[j] = in ? ro[k].get(j) - c0.y : 0x3fffffff;
+            if (FL && (unsigned) v[j] < (unsigned) tile_nnz) {
+                const int b = (c0.y - a0) + v[j];
+                atomicOr(&s_flag[b >> 5], 1u << (b & 31));
+            }
         }
         st_lds4(&s_end_raw[4 * q], v);
     }
+    if (FL && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - a0));
     // ---- stage products
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -612,7 +783,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
             const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
             prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
         }
-        st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
+        if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
+        else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
     }
     // ---- ragged array tails (at most 3 elements each; only the tile that reaches the array
     //      end).  Block-uniform branch; the barrier orders these writes after the zeros /
@@ -623,10 +795,14 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
         __syncthreads();
         const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
         if (nz_tail && j < c1.y && j >= c0.y)
-            s_prod_raw[swz_prod(j - a0)] = ld_stream<NT>(p.values + j) * p.x[ld_stream<NT>(p.cols + j)];
+            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0) : swz_prod(j - a0)] = ld_stream<NT>(p.values + j) * p.x[ld_stream<NT>(p.cols + j)];
         const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
         const int r = i - first;
-        if (ro_tail && r >= 0 && r < tile_rows) s_end_raw[r + eshift] = ld_stream<NT>(row_offsets + i) - c0.y;
+        if (ro_tail && r >= 0 && r < tile_rows) {
+            const int v = ld_stream<NT>(row_offsets + i) - c0.y;
+            s_end_raw[r + eshift] = v;
+            if (FL && (unsigned) v < (unsigned) tile_nnz) atomicOr(&s_flag[((c0.y - a0) + v) >> 5], 1u << (((c0.y - a0) + v) & 31));
+        }
     }
     __syncthreads();
 }
@@ -643,10 +819,10 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
 //    least IPT path items past every thread of a full tile.
 // Only whole chunks beyond the needed range are redirected to a cached address (no HBM bytes
 // for data the tile does not use).  This removes ~200 of the ~1100 instructions per wave per tile.
-template <typename V, int BLOCK, int IPT, bool NT>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
                                                     const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw,
-                                                    V *s_prod_raw)
+                                                    V *s_prod_raw, unsigned *s_flag)
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = threadIdx.x;
@@ -656,12 +832,17 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
     const int i0 = first & ~3;
     const int eshift = first - i0;
     Vec4<int> ro[CPT];
-    const int ro_chunks = (tile_rows + eshift + IPT + 3) / 4;     // row ends of the tile + the IPT the walk may peek at
+    // row ends of the tile (+ the IPT the per-thread walk may peek at)
+    const int ro_chunks = (tile_rows + eshift + (FL ? 0 : IPT) + 3) / 4;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int q = tid + k * BLOCK;
-        const int i = q < ro_chunks ? i0 + 4 * q : i0;
-        ro[k] = ld_stream4<NT>(row_offsets + (unsigned) i);
+        // block-uniform: a tile of long rows needs one chunk per thread at most; every vector-memory
+        // instruction spared is a slot in the CU's memory pipeline, which is what this kernel queues on
+        if (k == 0 || k * BLOCK < ro_chunks) {
+            const int q = tid + k * BLOCK;
+            const int i = q < ro_chunks ? i0 + 4 * q : i0;
+            ro[k] = ld_stream4<NT>(row_offsets + (unsigned) i);
+        }
     }
     V xv[CPT][4];
 #pragma unroll
@@ -671,18 +852,30 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int q = tid + k * BLOCK;
-        int v[4];
+        if (q < ro_chunks) {
+            int v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ro[k].get(j) - c0.y;
-        if (q < ro_chunks) st_lds4(&s_end_raw[4 * q], v);
+            for (int j = 0; j < 4; ++j) v[j] = ro[k].get(j) - c0.y;
+            st_lds4(&s_end_raw[4 * q], v);
+            if (FL) {
+                // row starts inside the tile (rows before the tile give v <= 0, rows after it
+                // v >= tile_nnz; v == 0 is the tile's first nonzero, flagged anyway)
+                const int tile_nnz = c1.y - c0.y, pshift = c0.y - (c0.y & ~3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned) v[j] < (unsigned) tile_nnz) atomicOr(&s_flag[(pshift + v[j]) >> 5], 1u << ((pshift + v[j]) & 31));
+            }
+        }
     }
+    if (FL && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - (c0.y & ~3)));
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
         V prod[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) prod[i] = regs.val[k].get(i) * xv[k][i];
-        st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
+        if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
+        else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
     }
     __syncthreads();
 }
@@ -698,19 +891,22 @@ __device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1,
     return tile != num_tiles - 1 && c1.y <= last_full_nz + 4 && i0 + 4 * ro_chunks <= last_full_ro + 4;
 }
 
-template <typename V, int BLOCK, int IPT, bool NT>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
                                            const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
-                                           int last_full_nz, int last_full_ro)
+                                           int last_full_nz, int last_full_ro, unsigned *s_flag)
 {
     if (tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro))      // block-uniform
-        stage_tile_interior<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw);
+        stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag);
     else
-        stage_tile_careful<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+        stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
 }
 
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY || XCD_REMAP || ABLATE != 0)>())) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
+// development: per-phase cycle stamps of the first 16 tiles of every block (ABLATE == 6 variant)
+__device__ unsigned long long *g_mspmv_trace = nullptr;
+
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false>
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST>())) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
 {
     constexpr int NW = BLOCK / WAVE;
@@ -718,10 +914,18 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY |
     constexpr int SLOTS = CPT * BLOCK * 4;         // >= TILE + 8
     __shared__ __attribute__((aligned(16))) int s_end_raw[SLOTS];
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
+    __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
+    constexpr bool FL = ABLATE != 7;               // ABLATE 7 (development): the per-thread path walk instead
+    constexpr bool TRACE = ABLATE == 6;
+    int trace_iter = 0;
+    unsigned long long *const trace = TRACE ? g_mspmv_trace : nullptr;
+#define MSPMV_TR(i) do { if (TRACE && trace && threadIdx.x == 0 && trace_iter < 16) trace[((size_t) blockIdx.x * 16 + trace_iter) * 8 + (i)] = clock64(); } while (0)
 
     const int tid = threadIdx.x;
+    if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
+    __syncthreads();
     // XCD_REMAP: blocks are dealt round-robin to the 8 XCDs (block b -> XCD
     // b % 8, observed; only speed depends on it); give each XCD's private L2 a
     // contiguous range of tiles.  Bijective for any num_tiles.
@@ -752,21 +956,33 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, (AXPBY |
 
         // ---- next tile's coordinates (scalar loads, in flight during the staging)
         const int next_seq = seq + (int) gridDim.x;
-        const bool has_next = next_seq < num_tiles;
+        const bool has_next = PERSIST ? next_seq < num_tiles : false;
         const int next = has_next ? physical(next_seq) : tile;
         const Coord n0 = coords[next];
         const Coord n1 = coords[next + 1];
-        stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+        MSPMV_TR(0);
+        if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MSPMV_TR(1);
+        stage_tile<V, BLOCK, IPT, NT, FL>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
+        MSPMV_TR(2);
         // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
         if (has_next) issue_nonzero_loads<V, BLOCK, IPT, NT>(p, n0, n1, regs);
+        MSPMV_TR(3);
         if (ABLATE == 1) {
             // ablation (development): staging only -- keep the LDS data live, skip search/walk/scan
             if (s_prod_raw[tid] == (V) 12345.678 && s_end_raw[tid] == 77) carries[tile].key = 1;
-        } else
-        consume_tile_lds<V, BLOCK, IPT, AXPBY, ABLATE, true>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw,
-                                                             s_prod_raw, s_wave_key, s_wave_val, carries + tile, pshift);
+        } else if (FL)
+            consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw, s_flag,
+                                                     s_wave_key, s_wave_val, carries + tile, pshift,
+                                                     (TRACE && trace && trace_iter < 16) ? trace + ((size_t) blockIdx.x * 16 + trace_iter) * 8 : nullptr);
+        else
+            consume_tile_lds<V, BLOCK, IPT, AXPBY, 0, true>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw,
+                                                            s_prod_raw, s_wave_key, s_wave_val, carries + tile, pshift);
+        MSPMV_TR(4);
         if (!has_next) break;
         __syncthreads();          // all LDS reads of this tile done before the next tile's staging writes
+        MSPMV_TR(5);
+        ++trace_iter;
         seq = next_seq; tile = next; c0 = n0; c1 = n1;
     }
 }
@@ -886,12 +1102,14 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     static_assert(BLOCK >= 2 * WAVE, "two waves search");
     __shared__ __attribute__((aligned(16))) int s_end_raw[SLOTS];
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
+    __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
     __shared__ Coord s_coord[2];
 
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
+    if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     const long long total = (long long) p.rows + p.nnz;
     {
         const int wave = tid / WAVE;
@@ -911,11 +1129,11 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
     TileRegs<V, BLOCK, IPT> regs;
     issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
-    stage_tile<V, BLOCK, IPT, NT>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro);
+    stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
-    consume_tile_lds<V, BLOCK, IPT, AXPBY, 0, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw,
-                                                    s_prod_raw, s_wave_key, s_wave_val, carries + tile, pshift);
+    consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
+                                             s_wave_key, s_wave_val, carries + tile, pshift);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

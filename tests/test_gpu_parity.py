@@ -196,7 +196,10 @@ def test_all_ones_giant_row_is_exact(M):
 
 @pytest.mark.parametrize("vb,block,ipt", [(4, 256, 5), (4, 256, 9), (4, 256, 11), (4, 128, 7), (4, 512, 7), (4, 256, 15),
                                           (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
-@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24, 48, 80])
+# 16 = no fused small-problem kernel (so the coordinate pass + tile kernel run), +1 XCD remap, +2 atomic fix-up,
+# +8 binary-search coordinate pass, 32/64 forced stream policy; 0x200000 = persistent form, 2 tiles per block;
+# 0x300 = persistent form, 3 blocks per CU; 0x70000 = the reference's per-thread path walk inside the tile
+@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24, 48, 80, 0x200010, 0x310, 0x70010])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)
@@ -223,12 +226,17 @@ def test_axpby_extension(M):
         x = rng.uniform(-1, 1, 4000).astype(dtype)
         y0 = rng.uniform(-1, 1, 4000).astype(dtype)
         g, s = O.spmv_gold_acc64(csr, x)
-        for alpha, beta in ((1.0, 0.0), (2.5, 0.0), (1.0, 1.0), (-0.5, 3.0)):
-            y = dev(y0.copy())
-            M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=y, alpha=alpha, beta=beta)
-            want = alpha * g + beta * y0.astype(np.float64)
-            tol = (2.0 ** -20 if dtype == np.float32 else 2.0 ** -48) * (abs(alpha) * s + abs(beta) * np.abs(y0) + 1e-30)
-            assert np.all(np.abs(y.cpu().numpy() - want) <= tol)
+        for flags in (0, 16, 0x200010):          # fused small-problem kernel, one tile per block, persistent
+            M.set_tuning(csr.values.dtype.itemsize, 0, 0, flags)
+            try:
+                for alpha, beta in ((1.0, 0.0), (2.5, 0.0), (1.0, 1.0), (-0.5, 3.0)):
+                    y = dev(y0.copy())
+                    M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=y, alpha=alpha, beta=beta)
+                    want = alpha * g + beta * y0.astype(np.float64)
+                    tol = (2.0 ** -20 if dtype == np.float32 else 2.0 ** -48) * (abs(alpha) * s + abs(beta) * np.abs(y0) + 1e-30)
+                    assert np.all(np.abs(y.cpu().numpy() - want) <= tol)
+            finally:
+                M.set_tuning(csr.values.dtype.itemsize)
         # beta == 0 must not read y (NaN there would poison it otherwise)
         y = torch.full((4000,), float("nan"), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
         M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=y, alpha=2.0, beta=0.0)

@@ -15,7 +15,7 @@ tail -2 $OUT/bench_trace.log
 for f in $(find $RAW/trace -name "*stats*.csv"); do cp $f $OUT/; done
 KT=$(find $RAW/trace -name "*kernel_trace.csv" | head -1)
 if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_mspmv.csv; grep mspmv $KT | head -400 >> $OUT/kernel_trace_mspmv.csv; fi
-for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCP_TCC_READ_REQ_sum"; do
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_READ_SECTORS_sum" "TCP_TCC_READ_REQ_sum"; do
   name=$(echo $pmc | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $RAW/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1
   CC=$(find $RAW/pmc_$name -name "*counter_collection.csv" | head -1)

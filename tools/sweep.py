@@ -76,12 +76,14 @@ def time_it(A, x, iters=30):
 
 def main():
     names = sys.argv[1:] or ["c2", "dense32"]
-    flag_sets = [0]
+    flag_sets = [int(f, 0) for f in os.environ.get("SWEEP_FLAGS", "0").split(",")]
+    only_default_shape = os.environ.get("SWEEP_DEFAULT_SHAPE") == "1"
     for label, A, x in workloads(names):
         vb = A.values.element_size()
         balg = A.nnz * (vb + 4) + (A.rows + 1) * 4 + A.rows * vb + A.cols * vb
         print(f"== {label}: rows {A.rows} nnz {A.nnz}  B_alg {balg/1e6:.1f} MB", flush=True)
-        for (b, i) in SHAPES[vb]:
+        info0 = M.launch_info(A.rows, A.nnz, vb)
+        for (b, i) in ([(info0["block_threads"], info0["items_per_thread"])] if only_default_shape else SHAPES[vb]):
             for fl in flag_sets:
                 M.set_tuning(vb, b, i, fl)
                 total, p = time_it(A, x)
