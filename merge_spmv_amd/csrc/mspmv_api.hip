@@ -34,25 +34,23 @@ static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128,
 struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}; };
 static Tuning g_tune[2];  // [0] = 4-byte values, [1] = 8-byte values
 
-// Default shape: larger tiles amortise the per-tile fixed costs (coordinate loads, the
-// in-tile search, the block scan, two barriers) once there are enough tiles to fill the
-// chip several times over; smaller ones keep more blocks busy on small problems.
-// Measured on MI355X (tools/sweep.py): 256x11 (fp32) / 256x7 (fp64) win from ~8M items up.
+// Default shape.  Problems of up to FUSED_MAX_TILES tiles take the smallest compiled tile that
+// keeps them within that count (more, smaller tiles = more blocks in flight on a small matrix)
+// and run tile_kernel_fused + one fix-up launch.  Everything larger uses 256x11 for both
+// precisions: measured on MI355X (tools/sweep.py, profiles/r01_sweep_vs_rocsparse.txt) it is
+// the fastest or within 1 % of the fastest compiled shape on every workload tried, and fewer
+// tiles also shorten the coordinate pass and the fix-up.
 static Shape pick_shape(int value_bytes, long long items, int &flags)
 {
     Tuning &t = g_tune[value_bytes == 8];
     flags = t.flags.load();
     if (t.block.load() > 0) return Shape{t.block.load(), t.ipt.load()};
-    const bool large = items >= (8LL << 20);
-    const Shape dflt = value_bytes == 8 ? (large ? Shape{256, 7} : Shape{256, 5}) : (large ? Shape{256, 11} : Shape{256, 7});
-    // small problems: the smallest (>= default) shape whose tile count fits one resident wave of
-    // blocks / one fix-up chunk: tile_kernel_fused + a single fix-up launch (2 launches in all)
     static const int ipts32[] = {7, 9, 11, 15}, ipts64[] = {5, 7, 9, 11};
     const int *ipts = value_bytes == 8 ? ipts64 : ipts32;
     if (!(flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED)))
         for (int i = 0; i < 4; ++i)
-            if (ipts[i] >= dflt.ipt && (items + 256LL * ipts[i] - 1) / (256LL * ipts[i]) <= FUSED_MAX_TILES) return Shape{256, ipts[i]};
-    return dflt;
+            if ((items + 256LL * ipts[i] - 1) / (256LL * ipts[i]) <= FUSED_MAX_TILES) return Shape{256, ipts[i]};
+    return Shape{256, 11};
 }
 
 struct Layout {

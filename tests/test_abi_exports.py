@@ -66,7 +66,7 @@ def test_tuning_rejects_unknown_shapes():
     assert M.launch_info(1_000_000, 3_500_000, 4)["items_per_thread"] == 9      # 4.5M items / 2304 = 1954 tiles
     assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2     # 1954 carries / 512 per block -> 2 launches
     assert M.launch_info(3_125_000, 100_000_000, 4)["items_per_thread"] == 11
-    assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 7
+    assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 11
     with pytest.raises(M.MspmvError):
         M.set_tuning(4, 250, 7)
 
