@@ -200,7 +200,7 @@ def main():
                        "partition": "single GPU" if world == 1 else f"merge-path diagonal split over {world} GPUs + 1 RCCL all-gather of carries"},
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": "tile_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "tile_kernel_vec", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
                          "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5),

@@ -197,7 +197,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
 #define MSPMV_LAUNCH_P(...)                                                                                        \
             do {                                                                                                   \
-                auto kernel = tile_kernel_persistent<V, BLOCK, IPT, __VA_ARGS__>;                                  \
+                auto kernel = tile_kernel_vec<V, BLOCK, IPT, __VA_ARGS__>;                                  \
                 if (!persist) {                                                                                    \
                     hipLaunchKernelGGL(kernel, dim3((unsigned) L.num_tiles), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles); \
                     break;                                                                                         \
@@ -487,7 +487,7 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries, const int64_t
 
 }  // extern "C"
 
-// development: where tile_kernel_persistent<..., ABLATE = 6> writes its cycle stamps (device pointer, 16*8 u64 per block)
+// development: where tile_kernel_vec<..., ABLATE = 6> writes its cycle stamps (device pointer, 16*8 u64 per block)
 extern "C" int mspmv_dev_set_trace(void *d_buf)
 {
     unsigned long long *ptr = static_cast<unsigned long long *>(d_buf);

@@ -643,14 +643,18 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
 }
 
 // ---------------------------------------------------------------------------
-// The production kernel: persistent, software-prefetched, 16-byte streaming.
-// A one-tile-per-block launch keeps loads in flight for only a fraction of a
-// block's life (coords -> nonzeros -> gather -> LDS phases form a dependent
-// chain), which caps a 32-wave/CU grid near 4 TB/s.  Here a resident block
-// walks tiles blockIdx.x, +gridDim.x, ... and requests the NEXT tile's
-// nonzeros (into the registers the current tile has just drained into LDS)
-// before it starts the current tile's LDS phases, so its HBM stream never
-// pauses.  Same per-tile arithmetic and carries as tile_kernel.
+// The production kernel: 16-byte streaming loads, LDS-staged products, flag/segmented-scan
+// reduction (consume_tile_flags).  PERSIST = false (default): one tile per block; the
+// hardware's block scheduler balances the load and de-phases the blocks of a CU.
+// PERSIST = true (tuning flags): a block walks tiles blockIdx.x, +gridDim.x, ... and requests
+// the NEXT tile's nonzeros (into the registers the current tile has just drained into LDS)
+// before the LDS phases of the current one.  The persistent form was the faster one while the
+// in-tile reduction was the per-thread path walk; measured with the present reduction a resident
+// grid is 7-10 % slower on streaming matrices and 2-4 tiles per block are within +-3 % of one
+// (tools/sweep.py with SWEEP_FLAGS=0x100000..0x800000), so the simpler launch is the default.
+// What bounds the kernel is the CU's vector-memory pipeline: cycle stamps (tools/trace_tiles.py)
+// show ~70 % of a block's life spent issuing into / waiting on it, and throughput follows the
+// number of cache lines requested per tile, not the instruction count of the LDS phases.
 //
 // Staging works on 4-element chunks aligned in ARRAY index space (the CSR
 // arrays are 16-byte aligned -- checked by the dispatcher -- but a tile starts
@@ -906,7 +910,7 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
 __device__ unsigned long long *g_mspmv_trace = nullptr;
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST>())) void tile_kernel_persistent(Params<V> p, const Coord *__restrict__ coords,
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
 {
     constexpr int NW = BLOCK / WAVE;

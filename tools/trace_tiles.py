@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/trace_tiles.py [workload] -- development: per-phase cycle stamps inside tile_kernel_persistent
+"""tools/trace_tiles.py [workload] -- development: per-phase cycle stamps inside tile_kernel_vec
 (the ABLATE=6 build of the kernel writes clock64() at phase boundaries for the first 16 tiles of each block)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
