@@ -240,7 +240,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             if (axpby) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
             else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
         }
-        MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel", grid, BLOCK));
+        MSPMV_CHECK(after_launch(stream, debug_sync, vec ? "tile_kernel_vec" : "tile_kernel", grid, BLOCK));
     }
     }
     // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair)

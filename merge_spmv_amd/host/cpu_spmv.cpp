@@ -124,7 +124,7 @@ void Run(const RunConfig &c)
         y((size_t) csr.num_rows);
     SpmvGold(csr, x.data(), y_in.data(), gold.data(), (V) c.alpha, (V) c.beta);
 
-    const int threads = c.threads > 0 ? c.threads : omp_get_num_procs();
+    const int threads = c.threads > 0 ? c.threads : UsableCpus();
     const int *row_end = csr.row_offsets.data() + 1;
 
     if (!c.quiet) printf("\n\n");
@@ -159,6 +159,7 @@ int main(int argc, char **argv)
         return 0;
     }
     const RunConfig c = ParseCommon(args, false);
+    omp_set_num_threads(c.threads > 0 ? c.threads : UsableCpus());     // also sizes the matrix-building regions
     if (c.fp32) Run<float>(c); else Run<double>(c);
     printf("\n");
     return 0;

@@ -274,6 +274,7 @@ void Run(const RunConfig &c, const Device &dev, bool vendor)
 
 int main(int argc, char **argv)
 {
+    omp_set_num_threads(UsableCpus());      // host-side matrix construction and the gold SpMV
     CommandLineArgs args(argc, argv);
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "

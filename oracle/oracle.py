@@ -452,7 +452,16 @@ def compare_results(computed: np.ndarray, reference: np.ndarray) -> int:
 
 
 def max_threads() -> int:
-    return int(lib().oracle_max_threads())
+    """OpenMP thread count worth using: the processor count capped by the container's CPU
+    quota (cgroup cpu.max) -- a team larger than the quota gets throttled as a whole."""
+    n = int(lib().oracle_max_threads())
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 # ---------------------------------------------------------------------------
