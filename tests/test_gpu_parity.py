@@ -136,18 +136,19 @@ SHAPES = {
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("path", ["single_launch", "multi_launch"])
+@pytest.mark.parametrize("path", ["single_launch", "multi_launch", "persistent", "reference_walk"])
 def test_random_and_degenerate_shapes(M, shape, prec, path):
-    """Both dispatch paths: small problems take tile_kernel_fused (own coordinate search, carries
-    applied by the last block); MSPMV_TUNE_NO_FUSED forces the large-problem pipeline
-    (coordinate pass + persistent kernel + fix-up launches) on the same inputs."""
+    """Every dispatch path on the same inputs: small problems take tile_kernel_fused (own coordinate
+    search); MSPMV_TUNE_NO_FUSED forces the large-problem pipeline (coordinate pass + tile_kernel_vec,
+    one tile per block + fix-up launches); "persistent" = the same kernel walking 2 tiles per block
+    with prefetch; "reference_walk" = the per-thread merge-path walk inside the tile."""
     dtype, vb = DT[prec]
     rng = np.random.default_rng(sum(map(ord, shape)))
     rows, cols, lens = SHAPES[shape](rng)
     csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
     x = rng.uniform(-1, 1, size=cols).astype(dtype)
     try:
-        M.set_tuning(vb, 0, 0, 16 if path == "multi_launch" else 0)
+        M.set_tuning(vb, 0, 0, {"single_launch": 0, "multi_launch": 16, "persistent": 0x200010, "reference_walk": 0x70010}[path])
         y, ws = run_gpu(M, csr, x)
         assert not np.isnan(y).any(), "a row was never written"
         check_strict(M, csr, x, y)
