@@ -119,9 +119,19 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_NO_FUSED   16  /* never use the single-launch small-problem kernel */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
 #define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
-/* bits 8..15 of flags: resident blocks per CU of the persistent grid (0 = default 8) */
+/* The vectorised tile kernel runs one tile per block by default.  Its persistent form (a block walks
+ * several tiles and prefetches the next tile's nonzeros) is selected by either of
+ *   bits  8..15: resident blocks per CU (grid = that x CUs), or
+ *   bits 20..23: tiles per block (grid = tiles / that, at least the resident count).
+ * bits 16..18 select development builds of the kernel: 1 = staging only (WRONG results, timing
+ * ablation), 6 = per-phase cycle stamps written to the buffer given to mspmv_dev_set_trace,
+ * 7 = the reference's per-thread merge-path walk inside the tile instead of flags + segmented scan. */
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
+
+/* Development: device buffer (16 x 8 uint64 per block) receiving the clock64() stamps of the
+ * "6" build above (tools/trace_tiles.py); NULL turns it off. */
+int mspmv_dev_set_trace(void *d_buf);
 
 /* Opt-in per-kernel timing with hipEvents recorded on the caller's stream
  * around each of the three passes (the counterpart of the reference's
