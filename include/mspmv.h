@@ -119,6 +119,7 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_NO_FUSED   16  /* never use the single-launch small-problem kernel */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
 #define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
+#define MSPMV_TUNE_MULTILEVEL_FIX 128 /* carry fix-up in two/three chunked levels (one launch each) instead of the one-launch owner-computes kernel */
 /* The vectorised tile kernel runs one tile per block by default.  Its persistent form (a block walks
  * several tiles and prefetches the next tile's nonzeros) is selected by either of
  *   bits  8..15: resident blocks per CU (grid = that x CUs), or

@@ -81,7 +81,7 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
         for (;;) {
             const int blocks = (n + FIX_CHUNK - 1) / FIX_CHUNK;
             ++lvl;
-            if (blocks == 1 || (L.flags & MSPMV_TUNE_ATOMIC_FIX)) break;
+            if (blocks == 1 || (L.flags & MSPMV_TUNE_ATOMIC_FIX) || !(L.flags & MSPMV_TUNE_MULTILEVEL_FIX)) break;
             n = 2 * blocks;
             L.fix_n[lvl] = n;
             L.fix_off[lvl - 1] = off; off = align256(off + uint64_t(n) * pair);
@@ -251,6 +251,11 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             hipLaunchKernelGGL((fixup_atomic_kernel<V, FIX_BLOCK>), dim3(grid), dim3(FIX_BLOCK), 0, stream, carries,
                                L.num_tiles, p.y, p.rows, p.alpha);
             MSPMV_CHECK(after_launch(stream, debug_sync, "fixup_atomic_kernel", grid, FIX_BLOCK));
+        } else if (!(L.flags & MSPMV_TUNE_MULTILEVEL_FIX)) {
+            const unsigned grid = (unsigned) ((L.num_tiles + FIX_CHUNK - 1) / FIX_CHUNK);
+            hipLaunchKernelGGL((fixup_onepass_kernel<V, FIX_BLOCK, FIX_IPT>), dim3(grid), dim3(FIX_BLOCK), 0, stream, carries,
+                               L.num_tiles, p.y, p.rows, p.alpha);
+            MSPMV_CHECK(after_launch(stream, debug_sync, "fixup_onepass_kernel", grid, FIX_BLOCK));
         } else {
             const Carry<V> *in = carries;
             for (int lvl = 0; lvl < L.fix_levels; ++lvl) {
@@ -418,7 +423,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | 0xff00 | 0x70000 | 0xf00000)) return hipErrorInvalidValue;
+    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xff00 | 0x70000 | 0xf00000)) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)

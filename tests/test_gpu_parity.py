@@ -199,8 +199,8 @@ def test_all_ones_giant_row_is_exact(M):
                                           (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
 # 16 = no fused small-problem kernel (so the coordinate pass + tile kernel run), +1 XCD remap, +2 atomic fix-up,
 # +8 binary-search coordinate pass, 32/64 forced stream policy; 0x200000 = persistent form, 2 tiles per block;
-# 0x300 = persistent form, 3 blocks per CU; 0x70000 = the reference's per-thread path walk inside the tile
-@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24, 48, 80, 0x200010, 0x310, 0x70010])
+# 128 = multi-level fix-up (default: one launch); 0x300 = persistent form, 3 blocks per CU; 0x70000 = the reference's per-thread path walk inside the tile
+@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24, 48, 80, 128, 144, 0x200010, 0x310, 0x70010])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)
