@@ -78,6 +78,29 @@ int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_valu
                           int32_t nnz, double alpha, double beta,
                           mspmv_stream_t stream, int debug_sync);
 
+/* ---- extension for iterated SpMV (solvers): the tile coordinates -- the output of the
+ * reference's DeviceSpmvSearchKernel, dispatch_spmv_orig.cuh:104-143 -- depend on d_row_offsets
+ * alone, yet the reference's stateless CsrMV recomputes them on every call (8-22 us here, 5-15 % of
+ * a mid-size SpMV).  mspmv_csrmv_prepare runs that pass once into the caller's temp storage
+ * (same two-phase size query; the size equals mspmv_csrmv_*'s for the same rows/nnz/value_bytes);
+ * mspmv_csrmv_prepared_* then compute y = alpha*A*x + beta*y with the coordinates found there.
+ * The caller guarantees that d_temp was prepared for this d_row_offsets / rows / nnz / value_bytes
+ * and has since been used only by mspmv calls for the same matrix (they leave the coordinates
+ * intact).  Results are bitwise those of mspmv_csrmv_* / mspmv_csrmv_axpby_*. ---- */
+int mspmv_csrmv_prepare(void *d_temp, size_t *temp_bytes, const int32_t *d_row_offsets,
+                        int32_t rows, int32_t nnz, int32_t value_bytes,
+                        mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_prepared_f32(void *d_temp, size_t *temp_bytes, const float *d_values,
+                             const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                             const float *d_x, float *d_y, int32_t rows, int32_t cols,
+                             int32_t nnz, float alpha, float beta,
+                             mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_prepared_f64(void *d_temp, size_t *temp_bytes, const double *d_values,
+                             const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                             const double *d_x, double *d_y, int32_t rows, int32_t cols,
+                             int32_t nnz, double alpha, double beta,
+                             mspmv_stream_t stream, int debug_sync);
+
 /* ---- introspection (the counterpart of the reference's debug_synchronous
  * launch log, dispatch_spmv_orig.cuh:685-739, as data) ---- */
 typedef struct mspmv_launch_info {

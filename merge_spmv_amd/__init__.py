@@ -73,6 +73,14 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_csrmv_axpby_f64.restype = ctypes.c_int
     lib.mspmv_csrmv_axpby_f64.argtypes = [vp, sz_p, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.c_double,
                                           ctypes.c_double, vp, ctypes.c_int]
+    lib.mspmv_csrmv_prepare.restype = ctypes.c_int
+    lib.mspmv_csrmv_prepare.argtypes = [vp, sz_p, vp, i32, i32, i32, vp, ctypes.c_int]
+    lib.mspmv_csrmv_prepared_f32.restype = ctypes.c_int
+    lib.mspmv_csrmv_prepared_f32.argtypes = [vp, sz_p, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.c_float,
+                                             ctypes.c_float, vp, ctypes.c_int]
+    lib.mspmv_csrmv_prepared_f64.restype = ctypes.c_int
+    lib.mspmv_csrmv_prepared_f64.argtypes = [vp, sz_p, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.c_double,
+                                             ctypes.c_double, vp, ctypes.c_int]
     lib.mspmv_error_string.restype = ctypes.c_char_p
     lib.mspmv_error_string.argtypes = [ctypes.c_int]
     lib.mspmv_version.restype = ctypes.c_int
@@ -173,6 +181,17 @@ class CsrMVWorkspace:
         info = launch_info(self.rows, self.nnz, _value_bytes(probe))
         self.bytes = int(info["temp_bytes"])
         self.buffer = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        self.prepared_for = None
+
+    def prepare(self, row_offsets, stream=None):
+        """Run the tile-coordinate pass once for this matrix (mspmv_csrmv_prepare); later
+        ``csrmv(..., workspace=ws)`` calls with the same row_offsets tensor skip it."""
+        size = ctypes.c_size_t(self.bytes)
+        _check(load_library().mspmv_csrmv_prepare(ctypes.c_void_p(self.buffer.data_ptr()), ctypes.byref(size), _ptr(row_offsets),
+                                                  self.rows, self.nnz, _value_bytes(self.buffer.new_empty(0, dtype=self.dtype)),
+                                                  _stream_handle(stream), 0), "mspmv_csrmv_prepare")
+        self.prepared_for = (row_offsets.data_ptr(), self.rows, self.nnz)
+        return self
 
 
 def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int] = None,
@@ -195,6 +214,17 @@ def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int
         y = torch.empty(rows, dtype=values.dtype, device=values.device)
     if workspace is None:
         workspace = CsrMVWorkspace(rows, nnz, values.dtype, device=values.device)
+    if workspace.prepared_for == (row_offsets.data_ptr(), rows, nnz):
+        # coordinates already in the workspace (CsrMVWorkspace.prepare): mspmv_csrmv_prepared_*
+        vb = _value_bytes(values)
+        fn = load_library().mspmv_csrmv_prepared_f32 if vb == 4 else load_library().mspmv_csrmv_prepared_f64
+        ct = ctypes.c_float if vb == 4 else ctypes.c_double
+        size = ctypes.c_size_t(workspace.bytes)
+        status = fn(ctypes.c_void_p(workspace.buffer.data_ptr()), ctypes.byref(size), _ptr(values), _ptr(row_offsets),
+                    _ptr(column_indices), _ptr(x), _ptr(y), rows, cols, nnz, ct(1.0 if alpha is None else alpha),
+                    ct(0.0 if beta is None else beta), _stream_handle(stream), int(bool(debug_synchronous)))
+        _check(int(status), "mspmv_csrmv_prepared")
+        return y
     status, _ = DeviceSpmv.CsrMV(workspace.buffer, workspace.bytes, values, row_offsets, column_indices, x, y,
                                  rows, cols, nnz, stream=stream, debug_synchronous=debug_synchronous,
                                  alpha=alpha, beta=beta)

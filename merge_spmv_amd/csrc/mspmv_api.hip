@@ -132,9 +132,14 @@ static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *n
     return e;
 }
 
+// phase: what a call does -- everything (the reference's stateless call), only the tile-coordinate
+// pass (mspmv_csrmv_prepare), or everything but it (mspmv_csrmv_prepared_*: the coordinates in d_temp
+// depend on row_offsets alone and are reused across the SpMVs of a solver)
+enum { PHASE_ALL = 0, PHASE_COORDS_ONLY = 1, PHASE_SKIP_COORDS = 2 };
+
 template <typename V, int BLOCK, int IPT>
 static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, bool axpby, hipStream_t stream,
-                            int debug_sync)
+                            int debug_sync, int phase)
 {
     char *base = static_cast<char *>(d_temp);
     Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off);
@@ -148,6 +153,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                      ((reinterpret_cast<uintptr_t>(p.values) | reinterpret_cast<uintptr_t>(p.cols) |
                        reinterpret_cast<uintptr_t>(p.row_end - 1)) & 15) == 0;
     const bool fused = L.fused && vec;
+    if (phase == PHASE_COORDS_ONLY && L.fused) return hipSuccess;      // those tiles search their own coordinates
+    if (phase == PHASE_SKIP_COORDS && L.fused && !vec) phase = PHASE_ALL;   // (unaligned arrays: nothing was prepared)
     if (fused) {
         // small problems: the tiles search their own coordinates (no coordinate pass)
         prof_mark(stream, slot, 0);
@@ -160,7 +167,9 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     } else {
     // 1. tile boundary coordinates
     prof_mark(stream, slot, 0);
-    if (L.flags & MSPMV_TUNE_BINARY_SEARCH) {
+    if (phase == PHASE_SKIP_COORDS) {
+        // already in d_temp
+    } else if (L.flags & MSPMV_TUNE_BINARY_SEARCH) {
         const unsigned grid = (unsigned) ((L.num_tiles + 1 + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE));
         hipLaunchKernelGGL((search_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows,
                            p.nnz, tile_items, L.num_tiles, coords);
@@ -177,6 +186,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                                stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords);
         MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
     }
+    if (phase == PHASE_COORDS_ONLY) return hipSuccess;
     // 2. tiles
     prof_mark(stream, slot, 1);
     {
@@ -275,14 +285,14 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
 
 template <typename V>
 static hipError_t dispatch_shape(const Layout &L, void *d_temp, const Params<V> &p, bool axpby, hipStream_t stream,
-                                 int debug_sync);
+                                 int debug_sync, int phase);
 
 #define MSPMV_SHAPE_CASE(V, B, I) \
-    if (L.shape.block == B && L.shape.ipt == I) return run_shape<V, B, I>(L, d_temp, p, axpby, stream, debug_sync);
+    if (L.shape.block == B && L.shape.ipt == I) return run_shape<V, B, I>(L, d_temp, p, axpby, stream, debug_sync, phase);
 
 template <>
 hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<float> &p, bool axpby, hipStream_t stream,
-                                 int debug_sync)
+                                 int debug_sync, int phase)
 {
     MSPMV_SHAPE_CASE(float, 256, 7)
     MSPMV_SHAPE_CASE(float, 256, 5)
@@ -296,7 +306,7 @@ hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<flo
 
 template <>
 hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<double> &p, bool axpby,
-                                  hipStream_t stream, int debug_sync)
+                                  hipStream_t stream, int debug_sync, int phase)
 {
     MSPMV_SHAPE_CASE(double, 256, 5)
     MSPMV_SHAPE_CASE(double, 256, 3)
@@ -311,7 +321,7 @@ hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<do
 template <typename V>
 static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets,
                       const int32_t *d_cols, const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha,
-                      V beta, bool axpby, mspmv_stream_t stream_, int debug_sync)
+                      V beta, bool axpby, mspmv_stream_t stream_, int debug_sync, int phase = PHASE_ALL)
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
     if ((long long) rows + nnz > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -322,12 +332,13 @@ static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const
     }
     if (*temp_bytes < L.total) return hipErrorInvalidValue;   // util_device.cuh:90-93
     if (rows == 0) return hipSuccess;             // nothing to write
-    if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
+    if (phase == PHASE_COORDS_ONLY) { if (!d_row_offsets) return hipErrorInvalidValue; }
+    else if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     Params<V> p;
     p.values = d_values; p.row_end = d_row_offsets + 1; p.cols = d_cols; p.x = d_x; p.y = d_y;
     p.rows = rows; p.nnz = nnz; p.alpha = alpha; p.beta = beta;
-    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync);
+    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, phase);
 }
 
 }  // namespace mspmv
@@ -370,6 +381,36 @@ int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_valu
 {
     return csrmv_impl<double>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
                               alpha, beta, true, stream, debug_sync);
+}
+
+int mspmv_csrmv_prepare(void *d_temp, size_t *temp_bytes, const int32_t *d_row_offsets, int32_t rows, int32_t nnz,
+                        int32_t value_bytes, mspmv_stream_t stream, int debug_sync)
+{
+    if (value_bytes == 4)
+        return csrmv_impl<float>(d_temp, temp_bytes, nullptr, d_row_offsets, nullptr, nullptr, nullptr, rows, 0, nnz, 1.0f, 0.0f,
+                                 false, stream, debug_sync, PHASE_COORDS_ONLY);
+    if (value_bytes == 8)
+        return csrmv_impl<double>(d_temp, temp_bytes, nullptr, d_row_offsets, nullptr, nullptr, nullptr, rows, 0, nnz, 1.0, 0.0,
+                                  false, stream, debug_sync, PHASE_COORDS_ONLY);
+    return hipErrorInvalidValue;
+}
+
+int mspmv_csrmv_prepared_f32(void *d_temp, size_t *temp_bytes, const float *d_values, const int32_t *d_row_offsets,
+                             const int32_t *d_column_indices, const float *d_x, float *d_y, int32_t rows, int32_t cols,
+                             int32_t nnz, float alpha, float beta, mspmv_stream_t stream, int debug_sync)
+{
+    if (!d_temp) return hipErrorInvalidValue;
+    return csrmv_impl<float>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
+                             alpha, beta, !(alpha == 1.0f && beta == 0.0f), stream, debug_sync, PHASE_SKIP_COORDS);
+}
+
+int mspmv_csrmv_prepared_f64(void *d_temp, size_t *temp_bytes, const double *d_values, const int32_t *d_row_offsets,
+                             const int32_t *d_column_indices, const double *d_x, double *d_y, int32_t rows, int32_t cols,
+                             int32_t nnz, double alpha, double beta, mspmv_stream_t stream, int debug_sync)
+{
+    if (!d_temp) return hipErrorInvalidValue;
+    return csrmv_impl<double>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
+                              alpha, beta, !(alpha == 1.0 && beta == 0.0), stream, debug_sync, PHASE_SKIP_COORDS);
 }
 
 int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)

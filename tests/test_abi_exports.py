@@ -62,9 +62,12 @@ def test_tuning_rejects_unknown_shapes():
     M.set_tuning(4)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
     # default shapes: small -> 256x7 / 256x5, a little larger -> the smallest shape with <= 2048 tiles,
-    # large -> 256x11 / 256x7
+    # large -> 256x11
     assert M.launch_info(1_000_000, 3_500_000, 4)["items_per_thread"] == 9      # 4.5M items / 2304 = 1954 tiles
+    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 1     # one-launch fix-up whatever the carry count
+    M.set_tuning(4, 0, 0, 128)                                                     # the chunked multi-level variant
     assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2     # 1954 carries / 512 per block -> 2 launches
+    M.set_tuning(4)
     assert M.launch_info(3_125_000, 100_000_000, 4)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 11
     with pytest.raises(M.MspmvError):

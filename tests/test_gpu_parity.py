@@ -398,3 +398,29 @@ def test_capturable_into_a_hip_graph(M):
             x.copy_(dev(xin)); y.fill_(float("nan"))
             g.replay(); torch.cuda.synchronize()
             check_strict(M, csr, xin, y.cpu().numpy())
+
+
+def test_prepared_calls_skip_the_coordinate_pass_and_match_bitwise(M, capfd):
+    """mspmv_csrmv_prepare + mspmv_csrmv_prepared_*: the tile coordinates are computed once; results are
+    bitwise those of the stateless call, for plain and alpha/beta forms, large (3 launches -> 2) and
+    small (fused kernel: nothing to prepare) problems."""
+    rng = np.random.default_rng(21)
+    for dtype, rows, hi in ((np.float32, 300000, 60), (np.float64, 300000, 40), (np.float32, 3000, 30)):
+        csr = random_csr(rng, rows, rows, rng.integers(0, hi, rows), dtype)
+        x = rng.uniform(-1, 1, rows).astype(dtype)
+        d = [dev(a) for a in (csr.values, csr.row_offsets, csr.column_indices, x)]
+        y_ref = M.csrmv(*d)
+        tdt = torch.float32 if dtype == np.float32 else torch.float64
+        ws = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt).prepare(d[1])
+        capfd.readouterr()
+        y = M.csrmv(*d, workspace=ws, debug_synchronous=True)
+        log = capfd.readouterr().out
+        assert "coords_scatter_kernel" not in log and "search_kernel" not in log, log
+        assert torch.equal(y, y_ref)
+        for _ in range(3):                                  # the coordinates survive the calls
+            assert torch.equal(M.csrmv(*d, workspace=ws), y_ref)
+        assert torch.equal(M.csrmv(*d, workspace=M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)), y_ref)   # stateless path still fine
+        y0 = dev(rng.uniform(-1, 1, rows).astype(dtype))
+        a = M.csrmv(*d, y=y0.clone(), alpha=-0.5, beta=2.0)
+        b = M.csrmv(*d, y=y0.clone(), alpha=-0.5, beta=2.0, workspace=ws)
+        assert torch.equal(a, b)

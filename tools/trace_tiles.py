@@ -13,8 +13,8 @@ names = sys.argv[1:] or ["dense32d"]
 for label, A, x in sweep.workloads(names):
     vb = A.values.element_size()
     info = M.launch_info(A.rows, A.nnz, vb)
-    M.set_tuning(vb, info["block_threads"], info["items_per_thread"], 0x60000)
-    nblk = 4096
+    M.set_tuning(vb, info["block_threads"], info["items_per_thread"], 0x60000 | 0x400)    # stamps build, resident grid of 4 blocks per CU
+    nblk = 4 * 256 + 64
     buf = torch.zeros(nblk * 16 * 8, dtype=torch.int64, device="cuda")
     assert lib.mspmv_dev_set_trace(ctypes.c_void_p(buf.data_ptr())) == 0
     ws = M.CsrMVWorkspace(A.rows, A.nnz, A.values.dtype)
@@ -24,6 +24,7 @@ for label, A, x in sweep.workloads(names):
         M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=A.cols, workspace=ws)
     torch.cuda.synchronize()
     t = buf.cpu().numpy().reshape(nblk, 16, 8).astype(np.float64)
+    print("  stamps recorded per slot:", [(int((t[:, :, i] > 0).sum())) for i in range(8)])
     ok = (t[:, :, 5] > 0) & (t[:, :, 0] > 0)
     ok[:, :2] = False            # steady state only
     ok[:, 12:] = False
