@@ -56,6 +56,36 @@ struct DeviceSpmv {
                                                   num_nonzeros, alpha, beta, (mspmv_stream_t) stream,
                                                   debug_synchronous ? 1 : 0);
     }
+
+    // ---- iterated SpMV on one matrix (extension): find the tile coordinates once ...
+    template <typename ValueT>
+    static hipError_t CsrMVPrepare(void *d_temp_storage, size_t &temp_storage_bytes, const int *d_row_offsets, int num_rows,
+                                   int num_nonzeros, hipStream_t stream = 0, bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_prepare(d_temp_storage, &temp_storage_bytes, d_row_offsets, num_rows, num_nonzeros,
+                                                (int) sizeof(ValueT), (mspmv_stream_t) stream, debug_synchronous ? 1 : 0);
+    }
+    // ... then y = alpha*A*x + beta*y without the coordinate pass (d_temp_storage as left by CsrMVPrepare)
+    static hipError_t CsrMVPrepared(void *d_temp_storage, size_t &temp_storage_bytes, const float *d_values,
+                                    const int *d_row_offsets, const int *d_column_indices, const float *d_vector_x,
+                                    float *d_vector_y, int num_rows, int num_cols, int num_nonzeros, float alpha = 1.f,
+                                    float beta = 0.f, hipStream_t stream = 0, bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_prepared_f32(d_temp_storage, &temp_storage_bytes, d_values, d_row_offsets,
+                                                     d_column_indices, d_vector_x, d_vector_y, num_rows, num_cols,
+                                                     num_nonzeros, alpha, beta, (mspmv_stream_t) stream,
+                                                     debug_synchronous ? 1 : 0);
+    }
+    static hipError_t CsrMVPrepared(void *d_temp_storage, size_t &temp_storage_bytes, const double *d_values,
+                                    const int *d_row_offsets, const int *d_column_indices, const double *d_vector_x,
+                                    double *d_vector_y, int num_rows, int num_cols, int num_nonzeros, double alpha = 1.0,
+                                    double beta = 0.0, hipStream_t stream = 0, bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_prepared_f64(d_temp_storage, &temp_storage_bytes, d_values, d_row_offsets,
+                                                     d_column_indices, d_vector_x, d_vector_y, num_rows, num_cols,
+                                                     num_nonzeros, alpha, beta, (mspmv_stream_t) stream,
+                                                     debug_synchronous ? 1 : 0);
+    }
 };
 
 }  // namespace mspmv

@@ -17,7 +17,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import load_library, _check, CsrMVWorkspace, DeviceSpmv, _stream_handle, _value_bytes
+from . import load_library, _check, CsrMVWorkspace, DeviceSpmv, csrmv, _stream_handle, _value_bytes
 
 
 def partition(row_offsets_i64: np.ndarray, parts: int):
@@ -88,16 +88,16 @@ class ShardedCsrMV:
         self.carries = torch.zeros(shard.parts, dtype=shard.values.dtype, device=dev)
         self.workspace = None
         if local_spmv is None:
+            # the part's matrix is fixed for the life of this operator: its tile coordinates are found once
             self.workspace = CsrMVWorkspace(shard.local_rows, shard.local_nnz, shard.values.dtype, device=dev)
+            self.workspace.prepare(shard.row_offsets)
 
     def __call__(self, x):
         torch, s = self.torch, self.shard
         if self.local_spmv is not None:
             self.local_spmv(s, x, self.y_local)
         else:
-            st, _ = DeviceSpmv.CsrMV(self.workspace.buffer, self.workspace.bytes, s.values, s.row_offsets,
-                                     s.column_indices, x, self.y_local, s.local_rows, s.num_cols, s.local_nnz)
-            _check(st, "mspmv_csrmv (shard)")
+            csrmv(s.values, s.row_offsets, s.column_indices, x, y=self.y_local, num_cols=s.num_cols, workspace=self.workspace)
         if s.parts > 1:
             import torch.distributed as dist
             # the ONE exchange: every rank contributes its open-row partial
