@@ -29,6 +29,7 @@ namespace mspmv {
 constexpr int WAVE = 64;
 
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef double double2v __attribute__((ext_vector_type(2)));
 
@@ -311,6 +312,20 @@ __device__ __forceinline__ void st_lds4(double *p, const double (&v)[4])
 }
 __device__ __forceinline__ void st_lds4(int *p, const int (&v)[4])
 { int4v w; w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3]; *reinterpret_cast<int4v *>(p) = w; }
+// Tile-relative row ends as the flag/scan reduction keeps them: 16 bits each (a tile has < 65536
+// nonzeros; entries of rows outside the tile are never read, so truncating them is harmless).
+// LDS is what limits the resident blocks per CU, and residency is worth more than anything else
+// here: 6 KB per 256x11 tile.
+typedef unsigned short end16_t;
+__device__ __forceinline__ void st_lds4(end16_t *p, const int (&v)[4])
+{
+    int2v w;
+    w.x = (v[0] & 0xffff) | (v[1] << 16);
+    w.y = (v[2] & 0xffff) | (v[3] << 16);
+    *reinterpret_cast<int2v *>(p) = w;
+}
+template <bool FL> struct EndType { typedef int type; };
+template <> struct EndType<true> { typedef end16_t type; };
 
 // LDS index swizzle of the staged products.  Thread t of the walk reads products around index
 // t*IPT - (rows before it); when rows have a regular length the per-lane stride resonates with
@@ -527,7 +542,7 @@ __device__ __forceinline__ V block_exclusive_segsum(bool flag, V val, int *s_wav
 
 template <typename V, int BLOCK, int IPT, bool AXPBY>
 __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
-                                                   const int *s_end, V *s_prod_raw, unsigned *s_flag,
+                                                   const end16_t *s_end, V *s_prod_raw, unsigned *s_flag,
                                                    int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
                                                    int pshift, unsigned long long *tr = nullptr)
 {
@@ -673,7 +688,7 @@ template <typename V, int BLOCK, int IPT>
 constexpr int tile_blocks_per_cu()
 {
     constexpr int slots = (IPT / 4 + 1) * BLOCK * 4;
-    constexpr int lds = slots * (4 + (int) sizeof(V)) + 256;
+    constexpr int lds = slots * (2 + (int) sizeof(V)) + slots / 8 + 256;      // products, 16-bit row ends, flag bits
     constexpr int by_lds = 163840 / lds;
     constexpr int by_waves = 2048 / BLOCK;
     return by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
@@ -723,7 +738,7 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // and the block is synchronised.
 template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
-                                           const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
+                                           const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw, V *s_prod_raw,
                                            int last_full_nz, int last_full_ro, unsigned *s_flag)
 {
     constexpr int CPT = IPT / 4 + 1;
@@ -804,7 +819,7 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
         const int r = i - first;
         if (ro_tail && r >= 0 && r < tile_rows) {
             const int v = ld_stream<NT>(row_offsets + i) - c0.y;
-            s_end_raw[r + eshift] = v;
+            s_end_raw[r + eshift] = (typename EndType<FL>::type) v;
             if (FL && (unsigned) v < (unsigned) tile_nnz) atomicOr(&s_flag[((c0.y - a0) + v) >> 5], 1u << (((c0.y - a0) + v) & 31));
         }
     }
@@ -825,8 +840,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
 // for data the tile does not use).  This removes ~200 of the ~1100 instructions per wave per tile.
 template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
-                                                    const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw,
-                                                    V *s_prod_raw, unsigned *s_flag)
+                                                    const TileRegs<V, BLOCK, IPT> &regs,
+                                                    typename EndType<FL>::type *s_end_raw, V *s_prod_raw, unsigned *s_flag)
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = threadIdx.x;
@@ -897,8 +912,8 @@ __device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1,
 
 template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
-                                           const TileRegs<V, BLOCK, IPT> &regs, int *s_end_raw, V *s_prod_raw,
-                                           int last_full_nz, int last_full_ro, unsigned *s_flag)
+                                           const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw,
+                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag)
 {
     if (tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro))      // block-uniform
         stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag);
@@ -916,12 +931,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
     constexpr int NW = BLOCK / WAVE;
     constexpr int CPT = IPT / 4 + 1;
     constexpr int SLOTS = CPT * BLOCK * 4;         // >= TILE + 8
-    __shared__ __attribute__((aligned(16))) int s_end_raw[SLOTS];
+    constexpr bool FL = ABLATE != 7;
+    __shared__ __attribute__((aligned(16))) typename EndType<FL>::type s_end_raw[SLOTS];
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
-    __shared__ V s_wave_val[NW];
-    constexpr bool FL = ABLATE != 7;               // ABLATE 7 (development): the per-thread path walk instead
+    __shared__ V s_wave_val[NW];               // ABLATE 7 (development): the per-thread path walk instead
     constexpr bool TRACE = ABLATE == 6;
     int trace_iter = 0;
     unsigned long long *const trace = TRACE ? g_mspmv_trace : nullptr;
@@ -972,10 +987,10 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
         // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
         if (has_next) issue_nonzero_loads<V, BLOCK, IPT, NT>(p, n0, n1, regs);
         MSPMV_TR(3);
-        if (ABLATE == 1) {
+        if constexpr (ABLATE == 1) {
             // ablation (development): staging only -- keep the LDS data live, skip search/walk/scan
             if (s_prod_raw[tid] == (V) 12345.678 && s_end_raw[tid] == 77) carries[tile].key = 1;
-        } else if (FL)
+        } else if constexpr (FL)
             consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw, s_flag,
                                                      s_wave_key, s_wave_val, carries + tile, pshift,
                                                      (TRACE && trace && trace_iter < 16) ? trace + ((size_t) blockIdx.x * 16 + trace_iter) * 8 : nullptr);
@@ -1204,7 +1219,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     constexpr int CPT = IPT / 4 + 1;
     constexpr int SLOTS = CPT * BLOCK * 4;
     static_assert(BLOCK >= 2 * WAVE, "two waves search");
-    __shared__ __attribute__((aligned(16))) int s_end_raw[SLOTS];
+    __shared__ __attribute__((aligned(16))) end16_t s_end_raw[SLOTS];
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
