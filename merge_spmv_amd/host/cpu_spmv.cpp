@@ -109,10 +109,8 @@ float TimeMethod(const RunConfig &c, const CsrMatrix<V> &a, const V *x, const V 
 template <typename V>
 void Run(const RunConfig &c)
 {
-    CooMatrix<V> coo;
-    BuildInput(c, coo);
-    CsrMatrix<V> csr(coo);
-    coo.Clear();
+    CsrMatrix<V> csr;
+    BuildCsr(c, csr);
     ReportMatrix(c, csr);
 
     int iterations = c.timing_iterations;
@@ -153,7 +151,7 @@ int main(int argc, char **argv)
     CommandLineArgs args(argc, argv);
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--quiet] [--v] [--v2] [--threads=<OMP threads>] [--i=<timing iterations>] [--fp32] "
-               "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--no-strict]\n"
+               "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--no-strict] [--cache]\n"
                "\t--mtx=<matrix market file>\n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;

@@ -6,6 +6,8 @@
 // so eval_csrmv.sh-style tooling keeps working.
 #pragma once
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +28,7 @@ struct RunConfig {
     int threads = -1;                      // --threads (cpu_spmv.cpp:732)
     int device = 0;                        // --device  (utils.h:465-472)
     double peak_gbs = -1;                  // --peak-gbs: overrides the bus-width formula of utils.h:491
+    bool cache = false;                    // --cache: keep / reuse <mtx>.<fp32|fp64>.csrbin next to a Matrix Market file
 };
 
 inline RunConfig ParseCommon(const CommandLineArgs &args, bool gpu_driver)
@@ -38,6 +41,7 @@ inline RunConfig ParseCommon(const CommandLineArgs &args, bool gpu_driver)
     c.strict = !args.CheckCmdLineFlag("no-strict");
     args.GetCmdLineArgument("i", c.timing_iterations);
     args.GetCmdLineArgument("mtx", c.mtx);
+    c.cache = args.CheckCmdLineFlag("cache");
     args.GetCmdLineArgument("grid2d", c.grid2d);
     args.GetCmdLineArgument("grid3d", c.grid3d);
     args.GetCmdLineArgument("wheel", c.wheel);      // parsed by gpu_spmv.cu:719 only; cpu_spmv.cpp forgot it
@@ -86,6 +90,31 @@ void BuildInput(const RunConfig &c, CooMatrix<ValueT> &coo)
         exit(1);
     }
     fflush(stdout);
+}
+
+/// COO -> CSR for the chosen input; with --cache a Matrix Market input is served from / saved to a
+/// binary CSR image beside it (newer than the .mtx), skipping the parse and the sort.
+/// Returns the nonzero count (for the iteration count the GPU driver prints before converting).
+template <typename ValueT>
+void BuildCsr(const RunConfig &c, CsrMatrix<ValueT> &csr, void (*before_convert)(const RunConfig &, int) = nullptr)
+{
+    std::string bin;
+    if (c.cache && !c.mtx.empty()) {
+        bin = c.mtx + (sizeof(ValueT) == 4 ? ".fp32.csrbin" : ".fp64.csrbin");
+        struct stat sm, sb;
+        if (stat(c.mtx.c_str(), &sm) == 0 && stat(bin.c_str(), &sb) == 0 && sb.st_mtime >= sm.st_mtime && csr.LoadBinary(bin)) {
+            if (!c.quiet) { printf("Reading binary CSR image... done. "); fflush(stdout); }
+            if (csr.num_rows == 1 || csr.num_cols == 1 || csr.num_nonzeros == 1) { if (!c.quiet) printf("Trivial dataset\n"); exit(0); }
+            printf("%s, ", c.mtx.c_str()); fflush(stdout);
+            if (before_convert) before_convert(c, csr.num_nonzeros);
+            return;
+        }
+    }
+    CooMatrix<ValueT> coo;
+    BuildInput(c, coo);
+    if (before_convert) before_convert(c, coo.num_nonzeros());
+    csr.Init(coo);
+    if (!bin.empty() && !csr.SaveBinary(bin) && !c.quiet) fprintf(stderr, "(could not write %s)\n", bin.c_str());
 }
 
 /// Stats line / block, histogram and optional dump (gpu_spmv.cu:503-516).

@@ -229,13 +229,12 @@ float TestRocsparseHybmv(const RunConfig &c, const CsrMatrix<V> &a, const std::v
 template <typename V>
 void Run(const RunConfig &c, const Device &dev, bool vendor)
 {
-    CooMatrix<V> coo;
-    BuildInput(c, coo);
-    int iterations = c.timing_iterations;
-    if (iterations == -1) iterations = AdaptiveIterations(coo.num_nonzeros(), 50000ull);
-    if (!c.quiet) printf("\t%d timing iterations\n", iterations);      // gpu_spmv.cu:495-496
-    CsrMatrix<V> csr(coo);
-    coo.Clear();
+    CsrMatrix<V> csr;
+    BuildCsr<V>(c, csr, [](const RunConfig &cc, int nnz) {
+        const int it = cc.timing_iterations == -1 ? AdaptiveIterations(nnz, 50000ull) : cc.timing_iterations;
+        if (!cc.quiet) printf("\t%d timing iterations\n", it);          // gpu_spmv.cu:495-496 (printed before the conversion)
+    });
+    const int iterations = c.timing_iterations == -1 ? AdaptiveIterations(csr.num_nonzeros, 50000ull) : c.timing_iterations;
     ReportMatrix(c, csr);
 
     std::vector<V> x((size_t) csr.num_cols, (V) 1.0), y_in((size_t) csr.num_rows, (V) 1.0), gold((size_t) csr.num_rows);
@@ -279,7 +278,7 @@ int main(int argc, char **argv)
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
-               "[--no-strict] [--no-vendor]\n"
+               "[--no-strict] [--no-vendor] [--cache]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;

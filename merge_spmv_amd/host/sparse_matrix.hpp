@@ -294,6 +294,49 @@ struct CsrMatrix {
     CsrMatrix() = default;
     explicit CsrMatrix(const CooMatrix<ValueT> &coo) { Init(coo); }
 
+    /// Binary image of the CSR arrays ("optional binary CSR cache"): parsing and
+    /// sorting an Orkut-class .mtx takes seconds even in parallel, loading this takes a read().
+    /// Layout: "MSPMVCSR", u32 version = 1, u32 sizeof(ValueT), i32 rows, cols, nnz, then
+    /// row_offsets[rows+1], column_indices[nnz], values[nnz].  No reference counterpart.
+    bool SaveBinary(const std::string &path) const
+    {
+        FILE *f = fopen(path.c_str(), "wb");
+        if (!f) return false;
+        const char magic[8] = {'M', 'S', 'P', 'M', 'V', 'C', 'S', 'R'};
+        const uint32_t head[2] = {1u, (uint32_t) sizeof(ValueT)};
+        const int32_t dims[3] = {num_rows, num_cols, num_nonzeros};
+        bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(head, 4, 2, f) == 2 && fwrite(dims, 4, 3, f) == 3;
+        ok = ok && fwrite(row_offsets.data(), sizeof(int), row_offsets.size(), f) == row_offsets.size();
+        ok = ok && fwrite(column_indices.data(), sizeof(int), column_indices.size(), f) == column_indices.size();
+        ok = ok && fwrite(values.data(), sizeof(ValueT), values.size(), f) == values.size();
+        ok = (fclose(f) == 0) && ok;
+        if (!ok) remove(path.c_str());
+        return ok;
+    }
+    /// false (matrix left empty) when the file is missing, truncated, of another precision or inconsistent
+    bool LoadBinary(const std::string &path)
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        char magic[8]; uint32_t head[2]; int32_t dims[3];
+        bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "MSPMVCSR", 8) == 0 && fread(head, 4, 2, f) == 2 &&
+                  head[0] == 1u && head[1] == sizeof(ValueT) && fread(dims, 4, 3, f) == 3 && dims[0] >= 0 && dims[1] >= 0 &&
+                  dims[2] >= 0;
+        if (ok) {
+            num_rows = dims[0]; num_cols = dims[1]; num_nonzeros = dims[2];
+            row_offsets.resize((size_t) num_rows + 1); column_indices.resize((size_t) num_nonzeros); values.resize((size_t) num_nonzeros);
+            ok = fread(row_offsets.data(), sizeof(int), row_offsets.size(), f) == row_offsets.size() &&
+                 fread(column_indices.data(), sizeof(int), column_indices.size(), f) == column_indices.size() &&
+                 fread(values.data(), sizeof(ValueT), values.size(), f) == values.size() && fgetc(f) == EOF;
+            ok = ok && row_offsets.front() == 0 && row_offsets.back() == num_nonzeros;
+            for (size_t r = 0; ok && r < (size_t) num_rows; ++r) ok = row_offsets[r] <= row_offsets[r + 1];
+            for (size_t k = 0; ok && k < (size_t) num_nonzeros; ++k) ok = (unsigned) column_indices[k] < (unsigned) num_cols;
+        }
+        fclose(f);
+        if (!ok) { num_rows = num_cols = num_nonzeros = 0; row_offsets.clear(); column_indices.clear(); values.clear(); }
+        return ok;
+    }
+
     /// COO -> CSR (CsrMatrix::Init, sparse_matrix.h:666-728): same result as a stable
     /// sort of the tuples by (row, col).
     void Init(const CooMatrix<ValueT> &coo)

@@ -266,3 +266,38 @@ def test_parallel_market_reader_throughput(H, tmp_path):
     ser = _host_market(H, "mtx_serial", path, False); t2 = time.perf_counter()
     assert par[0] == "ok" and par == ser
     print(f"\nMatrix Market 1M entries (read + COO->CSR): all threads {t1 - t0:.3f} s, one thread {t2 - t1:.3f} s")
+
+
+def test_binary_csr_cache_of_the_drivers(tmp_path):
+    """--cache: the second run is served from <mtx>.<prec>.csrbin and reports the same
+    matrix; a newer .mtx, another precision or a damaged image are not trusted."""
+    import shutil, subprocess, time
+    exe = os.path.join(ROOT, "merge_spmv_amd", "cpu_spmv")
+    src = os.path.join(ROOT, "tests/golden/mtx/giant_row.mtx")
+    mtx = str(tmp_path / "m.mtx"); shutil.copy(src, mtx)
+    def run(*extra):
+        r = subprocess.run([exe, "--mtx=" + mtx, "--i=1", *extra], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+    def stats(out):                      # name + the 7 statistics fields of the quiet CSV line
+        return out.split(", OMP-row CsrMV")[0]
+    plain = run("--quiet")
+    first = run("--quiet", "--cache")
+    img = mtx + ".fp64.csrbin"
+    assert os.path.exists(img) and stats(first) == stats(plain)
+    assert "Reading binary CSR image" in run("--cache") and stats(run("--quiet", "--cache")) == stats(plain)
+    assert not os.path.exists(mtx + ".fp32.csrbin")
+    assert "Reading binary CSR image" not in run("--cache", "--fp32")            # other precision: parsed, own image written
+    assert os.path.exists(mtx + ".fp32.csrbin")
+    # damaged image -> ignored and rewritten
+    with open(img, "r+b") as f:
+        f.seek(40); f.write(b"\xff\xff\xff\x7f")
+    out = run("--cache")
+    assert "Reading binary CSR image" not in out and "PASS" in out
+    assert "Reading binary CSR image" in run("--cache")
+    # the .mtx changes -> the image is stale
+    time.sleep(1.1)
+    with open(mtx, "a") as f:
+        f.write("% touched\n")
+    os.utime(mtx, None)
+    assert "Reading binary CSR image" not in run("--cache")
