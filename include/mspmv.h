@@ -78,6 +78,25 @@ int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_valu
                           int32_t nnz, double alpha, double beta,
                           mspmv_stream_t stream, int debug_sync);
 
+/* ---- extension: SpMM, Y = alpha*A*X + beta*Y for k right-hand sides.
+ * X is cols x k and Y is rows x k, both ROW-major with leading dimensions ldx, ldy >= k (elements):
+ * the k entries X[col, :] that one column index needs are contiguous, so a single gather serves up
+ * to 16 bytes of right-hand sides and one pass over the matrix serves up to 4 (fp32) / 2 (fp64)
+ * vectors; wider blocks run in groups.  Same two-phase temp storage, ownership, stream and error
+ * conventions as mspmv_csrmv_*; with beta == 0 the old Y is never read.  Results per column are
+ * within the same tolerance as CsrMV and bitwise reproducible.  No reference counterpart (the
+ * reference ships CsrMV only). ---- */
+int mspmv_csrmm_f32(void *d_temp, size_t *temp_bytes, const float *d_values,
+                    const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                    const float *d_x, int32_t ldx, float *d_y, int32_t ldy,
+                    int32_t rows, int32_t cols, int32_t nnz, int32_t k,
+                    float alpha, float beta, mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmm_f64(void *d_temp, size_t *temp_bytes, const double *d_values,
+                    const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                    const double *d_x, int32_t ldx, double *d_y, int32_t ldy,
+                    int32_t rows, int32_t cols, int32_t nnz, int32_t k,
+                    double alpha, double beta, mspmv_stream_t stream, int debug_sync);
+
 /* ---- extension for iterated SpMV (solvers): the tile coordinates -- the output of the
  * reference's DeviceSpmvSearchKernel, dispatch_spmv_orig.cuh:104-143 -- depend on d_row_offsets
  * alone, yet the reference's stateless CsrMV recomputes them on every call (8-22 us here, 5-15 % of

@@ -17,7 +17,7 @@ import ctypes
 import os
 from typing import Optional, Tuple
 
-__all__ = ["DeviceSpmv", "csrmv", "CsrMVWorkspace", "library_path", "load_library", "launch_info",
+__all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "library_path", "load_library", "launch_info",
            "set_tuning", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
            "TUNE_XCD_REMAP", "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
@@ -81,6 +81,12 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_csrmv_prepared_f64.restype = ctypes.c_int
     lib.mspmv_csrmv_prepared_f64.argtypes = [vp, sz_p, vp, vp, vp, vp, vp, i32, i32, i32, ctypes.c_double,
                                              ctypes.c_double, vp, ctypes.c_int]
+    lib.mspmv_csrmm_f32.restype = ctypes.c_int
+    lib.mspmv_csrmm_f32.argtypes = [vp, sz_p, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, ctypes.c_float, ctypes.c_float,
+                                    vp, ctypes.c_int]
+    lib.mspmv_csrmm_f64.restype = ctypes.c_int
+    lib.mspmv_csrmm_f64.argtypes = [vp, sz_p, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, ctypes.c_double, ctypes.c_double,
+                                    vp, ctypes.c_int]
     lib.mspmv_error_string.restype = ctypes.c_char_p
     lib.mspmv_error_string.argtypes = [ctypes.c_int]
     lib.mspmv_version.restype = ctypes.c_int
@@ -230,6 +236,38 @@ def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int
                                  alpha=alpha, beta=beta)
     _check(status, "mspmv_csrmv")
     return y
+
+
+def csrmm(values, row_offsets, column_indices, X, Y=None, alpha: float = 1.0, beta: float = 0.0, temp=None, stream=None,
+          debug_synchronous: bool = False):
+    """Y = alpha*A*X + beta*Y (mspmv_csrmm_*).  X: [cols, k] CUDA tensor, row-major (stride (ldx, 1));
+    Y likewise [rows, k].  Returns Y."""
+    import torch
+    if not values.is_cuda or not X.is_cuda:
+        raise MspmvError("csrmm needs CUDA (HIP) tensors: the merge-path kernels only run on the GPU")
+    if X.dim() != 2 or X.stride(1) != 1:
+        raise MspmvError("X must be 2-D with unit stride along the right-hand-side index (row-major)")
+    rows, nnz, k = row_offsets.numel() - 1, values.numel(), X.shape[1]
+    if Y is None:
+        Y = torch.empty(rows, k, dtype=values.dtype, device=values.device)
+    if Y.dim() != 2 or Y.stride(1) != 1 or Y.shape != (rows, k):
+        raise MspmvError("Y must be a row-major [rows, k] tensor")
+    vb = _value_bytes(values)
+    fn = load_library().mspmv_csrmm_f32 if vb == 4 else load_library().mspmv_csrmm_f64
+    ct = ctypes.c_float if vb == 4 else ctypes.c_double
+    ldx = X.stride(0) if X.shape[0] > 1 else max(k, 1)
+    ldy = Y.stride(0) if Y.shape[0] > 1 else max(k, 1)
+    def call(tmp_ptr, size):
+        return int(fn(tmp_ptr, ctypes.byref(size), _ptr(values), _ptr(row_offsets), _ptr(column_indices), _ptr(X), int(ldx),
+                      _ptr(Y), int(ldy), rows, X.shape[0], nnz, k, ct(alpha), ct(beta), _stream_handle(stream),
+                      int(bool(debug_synchronous))))
+    size = ctypes.c_size_t(0)
+    _check(call(ctypes.c_void_p(0), size), "mspmv_csrmm (size query)")
+    if temp is None or temp.numel() < size.value:
+        temp = torch.empty(max(int(size.value), 1), dtype=torch.uint8, device=values.device)
+    size = ctypes.c_size_t(temp.numel())
+    _check(call(ctypes.c_void_p(temp.data_ptr()), size), "mspmv_csrmm")
+    return Y
 
 
 def launch_info(num_rows: int, num_nonzeros: int, value_bytes: int) -> dict:

@@ -15,6 +15,7 @@
 
 #include "../../include/mspmv.h"
 #include "mspmv_kernels.hpp"
+#include "mspmv_spmm.hpp"
 
 namespace mspmv {
 
@@ -341,6 +342,118 @@ static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const
     return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, phase);
 }
 
+// ---------------------------------------------------------------------------
+// SpMM: Y[rows x k] = alpha * A * X[cols x k] + beta * Y, X and Y row-major (mspmv_spmm.hpp).
+// One coordinate pass for the call, then per group of <= 16 bytes of right-hand sides one tile
+// kernel + one fix-up launch.  Tile 256 x 7 (LDS: 2048 packs of <= 16 bytes + the row ends).
+// ---------------------------------------------------------------------------
+constexpr int MM_BLOCK = 256, MM_IPT = 7, MM_TILE = MM_BLOCK * MM_IPT;
+
+// generic row-per-thread fallback (arrays not 16-byte aligned, or fewer than 4 nonzeros / 3 rows)
+template <typename T>
+__global__ void spmm_rowwise_kernel(const T *values, const int *row_offsets, const int *cols, const T *x, T *y, int rows, int k,
+                                    int ldx, int ldy, T alpha, T beta)
+{
+    const long long id = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (long long) rows * k) return;
+    const int r = (int) (id / k), c = (int) (id % k);
+    T sum = 0;
+    for (int j = row_offsets[r]; j < row_offsets[r + 1]; ++j) sum += values[j] * x[(size_t) cols[j] * ldx + c];
+    T *dst = y + (size_t) r * ldy + c;
+    *dst = alpha * sum + (beta == (T) 0 ? (T) 0 : beta * *dst);
+}
+
+struct MMLayout { int num_tiles; uint64_t coords_off, carries_off, total; };
+template <typename T>
+static MMLayout make_mm_layout(int rows, int nnz, int k)
+{
+    MMLayout L;
+    const long long total = (long long) rows + nnz;
+    L.num_tiles = (int) ((total + MM_TILE - 1) / MM_TILE);
+    constexpr int KMAX = 16 / (int) sizeof(T);
+    uint64_t off = 0;
+    L.coords_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(Coord));
+    const int groups = k / KMAX > 0 ? k / KMAX : 1;     // full groups share one launch, each with its own carry list
+    L.carries_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * groups * sizeof(CarryMM<T, KMAX>));
+    L.total = off;
+    return L;
+}
+
+template <typename T, int K>
+static hipError_t run_mm_group(const MMLayout &L, char *base, MMParams<T> p, int groups, bool axpby, bool nt, hipStream_t stream,
+                               int debug_sync)
+{
+    const Coord *coords = reinterpret_cast<const Coord *>(base + L.coords_off);
+    CarryMM<T, K> *carries = reinterpret_cast<CarryMM<T, K> *>(base + L.carries_off);
+    const uintptr_t pack_bytes = K * sizeof(T);
+    p.x_vec = (reinterpret_cast<uintptr_t>(p.x) % pack_bytes == 0 && ((uintptr_t) p.ldx * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
+    p.y_vec = (reinterpret_cast<uintptr_t>(p.y) % pack_bytes == 0 && ((uintptr_t) p.ldy * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
+    const unsigned grid = (unsigned) L.num_tiles;
+#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, MM_BLOCK, MM_IPT, AX, NTF>), dim3(grid), dim3(MM_BLOCK), 0, stream, p, coords, carries, L.num_tiles, groups)
+    if (axpby) { if (nt) MSPMV_MM_LAUNCH(true, true); else MSPMV_MM_LAUNCH(true, false); }
+    else { if (nt) MSPMV_MM_LAUNCH(false, true); else MSPMV_MM_LAUNCH(false, false); }
+#undef MSPMV_MM_LAUNCH
+    MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_tile_kernel", grid, MM_BLOCK));
+    if (L.num_tiles > 1) {
+        const unsigned fgrid = (unsigned) ((L.num_tiles + FIX_CHUNK - 1) / FIX_CHUNK);
+        hipLaunchKernelGGL((spmm_fixup_kernel<T, K, FIX_BLOCK, FIX_IPT>), dim3(fgrid, (unsigned) groups), dim3(FIX_BLOCK), 0, stream, carries, L.num_tiles,
+                           p.y, p.ldy, p.y_vec, p.rows, p.alpha);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_fixup_kernel", fgrid, FIX_BLOCK));
+    }
+    return hipSuccess;
+}
+
+template <typename T>
+static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const int32_t *d_row_offsets, const int32_t *d_cols,
+                      const T *d_x, int32_t ldx, T *d_y, int32_t ldy, int32_t rows, int32_t cols, int32_t nnz, int32_t k, T alpha,
+                      T beta, mspmv_stream_t stream_, int debug_sync)
+{
+    if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0 || k < 0 || ldx < k || ldy < k) return hipErrorInvalidValue;
+    if ((long long) rows + nnz > 0x7fffffffLL) return hipErrorInvalidValue;
+    const MMLayout L = make_mm_layout<T>(rows, nnz, k);
+    if (d_temp == nullptr) { *temp_bytes = (size_t) L.total; return hipSuccess; }
+    if (*temp_bytes < L.total) return hipErrorInvalidValue;
+    if (rows == 0 || k == 0) return hipSuccess;
+    if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const bool vec = nnz >= 4 && rows >= 3 &&
+                     ((reinterpret_cast<uintptr_t>(d_values) | reinterpret_cast<uintptr_t>(d_cols) |
+                       reinterpret_cast<uintptr_t>(d_row_offsets)) & 15) == 0;
+    if (!vec) {
+        const long long work = (long long) rows * k;
+        const unsigned grid = (unsigned) ((work + 255) / 256);
+        hipLaunchKernelGGL((spmm_rowwise_kernel<T>), dim3(grid), dim3(256), 0, stream, d_values, d_row_offsets, d_cols, d_x, d_y, rows,
+                           k, ldx, ldy, alpha, beta);
+        return (int) after_launch(stream, debug_sync, "spmm_rowwise_kernel", grid, 256);
+    }
+    char *base = static_cast<char *>(d_temp);
+    {   // tile coordinates, once for all groups
+        Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off);
+        const long long threads = ((long long) rows + 1 + 3) / 4;
+        const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
+        hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, MM_TILE, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream,
+                           d_row_offsets, rows, nnz, L.num_tiles, coords);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
+    }
+    const bool axpby = !(alpha == (T) 1 && beta == (T) 0);
+    const unsigned long long stream_bytes = (unsigned long long) nnz * (sizeof(T) + 4) + 4ull * rows;
+    const bool nt = stream_bytes > (200ull << 20);
+    MMParams<T> p;
+    p.values = d_values; p.row_end = d_row_offsets + 1; p.cols = d_cols; p.rows = rows; p.nnz = nnz; p.ldx = ldx; p.ldy = ldy;
+    p.alpha = alpha; p.beta = beta; p.x_vec = p.y_vec = 0;
+    constexpr int KMAX = 16 / (int) sizeof(T);
+    for (int c = 0; c < k;) {
+        const int left = k - c;
+        p.x = d_x + c; p.y = d_y + c;
+        hipError_t e;
+        if (left >= KMAX) { const int g = left / KMAX; e = run_mm_group<T, KMAX>(L, base, p, g, axpby, nt, stream, debug_sync); c += g * KMAX; }
+        else if (KMAX >= 4 && left >= 2) { e = run_mm_group<T, 2>(L, base, p, 1, axpby, nt, stream, debug_sync); c += 2; }
+        else { e = run_mm_group<T, 1>(L, base, p, 1, axpby, nt, stream, debug_sync); c += 1; }
+        if (e != hipSuccess) return (int) e;
+    }
+    return hipSuccess;
+}
+
 }  // namespace mspmv
 
 using namespace mspmv;
@@ -411,6 +524,22 @@ int mspmv_csrmv_prepared_f64(void *d_temp, size_t *temp_bytes, const double *d_v
     if (!d_temp) return hipErrorInvalidValue;
     return csrmv_impl<double>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, d_y, rows, cols, nnz,
                               alpha, beta, !(alpha == 1.0 && beta == 0.0), stream, debug_sync, PHASE_SKIP_COORDS);
+}
+
+int mspmv_csrmm_f32(void *d_temp, size_t *temp_bytes, const float *d_values, const int32_t *d_row_offsets,
+                    const int32_t *d_column_indices, const float *d_x, int32_t ldx, float *d_y, int32_t ldy, int32_t rows,
+                    int32_t cols, int32_t nnz, int32_t k, float alpha, float beta, mspmv_stream_t stream, int debug_sync)
+{
+    return csrmm_impl<float>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, ldx, d_y, ldy, rows, cols, nnz, k,
+                             alpha, beta, stream, debug_sync);
+}
+
+int mspmv_csrmm_f64(void *d_temp, size_t *temp_bytes, const double *d_values, const int32_t *d_row_offsets,
+                    const int32_t *d_column_indices, const double *d_x, int32_t ldx, double *d_y, int32_t ldy, int32_t rows,
+                    int32_t cols, int32_t nnz, int32_t k, double alpha, double beta, mspmv_stream_t stream, int debug_sync)
+{
+    return csrmm_impl<double>(d_temp, temp_bytes, d_values, d_row_offsets, d_column_indices, d_x, ldx, d_y, ldy, rows, cols, nnz, k,
+                              alpha, beta, stream, debug_sync);
 }
 
 int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)

@@ -424,3 +424,57 @@ def test_prepared_calls_skip_the_coordinate_pass_and_match_bitwise(M, capfd):
         a = M.csrmv(*d, y=y0.clone(), alpha=-0.5, beta=2.0)
         b = M.csrmv(*d, y=y0.clone(), alpha=-0.5, beta=2.0, workspace=ws)
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------
+# SpMM extension: every column of Y must satisfy the CsrMV tolerance against the
+# oracle's sequential fp64-accumulated sum of that column.
+# ---------------------------------------------------------------------------
+def _check_csrmm(M, csr, X, Y, alpha=1.0, beta=0.0, Y0=None):
+    for c in range(X.shape[1]):
+        g, s = O.spmv_gold_acc64(csr, np.ascontiguousarray(X[:, c]))
+        want = alpha * g + (beta * Y0[:, c].astype(np.float64) if beta != 0.0 else 0.0)
+        eps = 2.0 ** -24 if csr.values.dtype == np.float32 else 2.0 ** -53
+        lens = np.diff(csr.row_offsets.astype(np.int64))
+        cc = 2.0 * (np.ceil(np.log2(lens + 1)) + 8 + 8)            # 8 products per thread in the SpMM tile
+        tol = cc * eps * (abs(alpha) * s + (abs(beta) * np.abs(Y0[:, c]) if beta != 0.0 else 0.0)) + (0 if alpha == 1.0 and beta == 0.0 else 4 * eps * np.abs(want))
+        got = Y[:, c].astype(np.float64)
+        bad = np.abs(got - want) > tol
+        assert not bad.any(), (c, int(bad.sum()), float(np.abs(got - want).max()))
+        if alpha == 1.0 and beta == 0.0:
+            assert np.all(got[lens == 0] == 0.0)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8])
+def test_csrmm_matches_the_oracle_column_by_column(M, prec, k):
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(100 + k)
+    lens = np.minimum((rng.pareto(1.2, 30000) * 3).astype(np.int64), 20000)
+    lens[123] = 60000; lens[5000:5600] = 0
+    csr = random_csr(rng, 30000, 20000, lens, dtype)
+    X = rng.uniform(-1, 1, size=(csr.cols, k)).astype(dtype)
+    Y = M.csrmm(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(X))
+    _check_csrmm(M, csr, X, Y.cpu().numpy())
+    # reproducible bit for bit
+    Y2 = M.csrmm(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(X))
+    assert torch.equal(Y, Y2)
+    # alpha/beta, and a padded leading dimension (views into wider buffers: unaligned packs)
+    Xw = torch.zeros(csr.cols, k + 3, dtype=Y.dtype, device="cuda"); Xv = Xw[:, 1:1 + k]; Xv.copy_(dev(X))
+    Y0 = rng.uniform(-1, 1, size=(csr.rows, k)).astype(dtype)
+    Yw = torch.zeros(csr.rows, k + 2, dtype=Y.dtype, device="cuda"); Yv = Yw[:, 2:2 + k]; Yv.copy_(dev(Y0))
+    M.csrmm(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), Xv, Y=Yv, alpha=-1.5, beta=0.5)
+    _check_csrmm(M, csr, X, Yv.cpu().numpy(), alpha=-1.5, beta=0.5, Y0=Y0)
+    assert float(Yw[:, :2].abs().max()) == 0.0                      # nothing outside the view was written
+
+
+@pytest.mark.parametrize("shape", ["all_empty", "leading_trailing_empty", "one_giant_row", "giant_row_between_empties", "single_col", "single_tile", "one_row_one_nnz", "exact_tile_multiple"])
+def test_csrmm_degenerate_shapes(M, shape):
+    rng = np.random.default_rng(7)
+    rows, cols, lens = SHAPES[shape](rng)
+    for dtype in (np.float32, np.float64):
+        csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
+        X = rng.uniform(-1, 1, size=(cols, 4)).astype(dtype)
+        Y = M.csrmm(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(X))
+        assert not torch.isnan(Y).any()
+        _check_csrmm(M, csr, X, Y.cpu().numpy())
