@@ -684,24 +684,24 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(Params<V> p, const Coord *_
 // footprint admits (160 KiB per CU), at most 32 waves per CU.  Passed to __launch_bounds__ as
 // waves per SIMD: left alone, hipcc spent 92-104 VGPRs on these kernels (4-5 waves/SIMD); told
 // the target it fits 64-80 without spilling, which is what actually sets the residency.
-template <typename V, int BLOCK, int IPT>
+template <typename V, int BLOCK, int IPT, bool WIDE_ENDS = false>
 constexpr int tile_blocks_per_cu()
 {
     constexpr int slots = (IPT / 4 + 1) * BLOCK * 4;
-    constexpr int lds = slots * (2 + (int) sizeof(V)) + slots / 8 + 256;      // products, 16-bit row ends, flag bits
+    constexpr int lds = slots * ((WIDE_ENDS ? 4 : 2) + (int) sizeof(V)) + slots / 8 + 256;      // products, row ends (16-bit; 32 for the walk), flag bits
     constexpr int by_lds = 163840 / lds;
     constexpr int by_waves = 2048 / BLOCK;
     return by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
 }
-template <typename V, int BLOCK, int IPT, bool RELAX = false>
+template <typename V, int BLOCK, int IPT, bool RELAX = false, bool WIDE_ENDS = false>
 constexpr int tile_waves_per_simd()
 {
     // one wave less than the LDS footprint admits (never more than 6 for fp64): with both
     // staging paths in the kernel the tighter budget spills 3 registers per lane, and the
     // measured difference between the two choices is within noise
-    int w = (tile_blocks_per_cu<V, BLOCK, IPT>() * BLOCK + 255) / 256;
+    int w = (tile_blocks_per_cu<V, BLOCK, IPT, WIDE_ENDS>() * BLOCK + 255) / 256;
     if (sizeof(V) == 8 && w > 6) w = 6;
-    if (w > 4 && !RELAX) w -= 1;
+    if (w > 4 && (!RELAX || WIDE_ENDS)) w -= WIDE_ENDS && w > 5 ? 2 : 1;
     return w;
 }
 
@@ -925,7 +925,7 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
 __device__ unsigned long long *g_mspmv_trace = nullptr;
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles)
 {
     constexpr int NW = BLOCK / WAVE;
