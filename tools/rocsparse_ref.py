@@ -52,3 +52,34 @@ def time_csrmv(A, x, iters=30):
     avg = e0.elapsed_time(e1) / iters
     L.rocsparse_destroy_mat_info(info); L.rocsparse_destroy_mat_descr(descr); L.rocsparse_destroy_handle(handle)
     return analysis_ms, avg, y
+
+
+def time_csrmm(A, X, iters=10):
+    """rocSPARSE csrmm (legacy entry point) on a row-major X [cols, k] (passed as op(B) = B^T of the k x cols
+    column-major matrix with the same memory); C is written column-major [rows, k].  returns (avg_ms, C as [rows, k])."""
+    L = lib(); vp = ctypes.c_void_p; i32 = ctypes.c_int
+    handle, descr = vp(), vp()
+    assert L.rocsparse_create_handle(ctypes.byref(handle)) == 0
+    assert L.rocsparse_set_stream(handle, vp(torch.cuda.current_stream().cuda_stream)) == 0
+    assert L.rocsparse_create_mat_descr(ctypes.byref(descr)) == 0
+    f32 = A.values.dtype == torch.float32
+    mm = L.rocsparse_scsrmm if f32 else L.rocsparse_dcsrmm
+    ct = ctypes.c_float if f32 else ctypes.c_double
+    k = X.shape[1]
+    C = torch.empty(k, A.rows, dtype=A.values.dtype, device=X.device)         # column-major rows x k
+    alpha, beta = ct(1.0), ct(0.0)
+
+    def call():
+        st = mm(handle, i32(111), i32(112), i32(A.rows), i32(k), i32(A.cols), i32(A.nnz), ctypes.byref(alpha), descr,
+                vp(A.values.data_ptr()), vp(A.row_offsets.data_ptr()), vp(A.column_indices.data_ptr()), vp(X.data_ptr()), i32(k),
+                ctypes.byref(beta), vp(C.data_ptr()), i32(A.rows))
+        assert st == 0, st
+    for _ in range(2): call()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): call()
+    e1.record(); torch.cuda.synchronize()
+    avg = e0.elapsed_time(e1) / iters
+    L.rocsparse_destroy_mat_descr(descr); L.rocsparse_destroy_handle(handle)
+    return avg, C.t()

@@ -25,6 +25,12 @@ for label, A, x in sweep.workloads(sys.argv[1:] or ["c2", "dense32"]):
         # spot check of column 0 against CsrMV
         y0 = M.csrmv(A.values, A.row_offsets, A.column_indices, X[:, 0].contiguous(), num_cols=A.cols)
         err = float((Y[:, 0].double() - y0.double()).abs().max())
-        print(f"   k={k:2d}: SpMM {t:.4f} ms = {2*A.nnz*k/t/1e6:8.1f} GFLOP/s   ({k} CsrMV calls would take {k*t1:.4f} ms: {k*t1/t:.2f}x)   max|col0 - CsrMV| {err:.2e}", flush=True)
+        try:
+            import rocsparse_ref
+            tr, Cr = rocsparse_ref.time_csrmm(A, X)
+            vend = f"rocSPARSE csrmm {tr:.4f} ms ({tr/t:.2f}x ours, max diff {float((Cr.double() - Y.double()).abs().max()):.1e})"
+        except Exception as e:
+            vend = f"rocSPARSE csrmm unavailable: {e}"
+        print(f"   k={k:2d}: SpMM {t:.4f} ms = {2*A.nnz*k/t/1e6:8.1f} GFLOP/s   ({k} CsrMV calls: {k*t1:.4f} ms, {k*t1/t:.2f}x)   {vend}", flush=True)
     del A, x
     torch.cuda.empty_cache()
