@@ -192,7 +192,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     prof_mark(stream, slot, 1);
     {
         const unsigned grid = (unsigned) L.num_tiles;
-        const bool remap = (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;
+        const bool remap = !axpby && (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;   // (experiment: plain y = A*x only)
         if (vec) {
             // Default: one tile per block, the hardware's block scheduler does the load balancing.
             // The same kernel also runs "persistent" -- a block walks tiles b, b + grid, ... and
@@ -205,7 +205,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             const int forced = (L.flags >> 8) & 0xff;
             const int tpb_flag = (L.flags >> 20) & 0xf;
             const int tpb = tpb_flag ? tpb_flag : 1;
-            const int ablate = (L.flags >> 16) & 7;       // development: timing with a phase removed (wrong results)
+            const int ablate = axpby ? 0 : (L.flags >> 16) & 7;   // development builds of the kernel (plain y = A*x only)
 #define MSPMV_LAUNCH_P(...)                                                                                        \
             do {                                                                                                   \
                 auto kernel = tile_kernel_vec<V, BLOCK, IPT, __VA_ARGS__>;                                  \

@@ -478,3 +478,11 @@ def test_csrmm_degenerate_shapes(M, shape):
         Y = M.csrmm(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(X))
         assert not torch.isnan(Y).any()
         _check_csrmm(M, csr, X, Y.cpu().numpy())
+
+
+def test_randomized_differential_smoke(M):
+    """A few seconds of tools/fuzz.py (random shapes x precisions x alignments x tuning flags x
+    CsrMV / axpby / prepared / SpMM) -- the long runs are done by hand and noted in DESIGN.md."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz.py"), "6", "11"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all within tolerance" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

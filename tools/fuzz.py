@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""tools/fuzz.py [seconds] -- randomized differential test of the C ABI on the GPU: random CSR shapes
+(row-length families, empty rows, giant rows), precisions, array alignments (views at element offsets
+0..3: the unaligned ones take the scalar fallback), tuning flags, alpha/beta, SpMM widths and leading
+dimensions; results compared with an fp64 segment-sum on the GPU under the strict per-row bound."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import merge_spmv_amd as M
+
+FLAGS = [0, 0, 0, 2, 4, 8, 16, 17, 24, 48, 80, 128, 144, 0x200010, 0x310, 0x70010]
+SHAPES = {4: [(256, 7), (256, 5), (256, 9), (256, 11), (128, 7), (512, 7), (256, 15)],
+          8: [(256, 5), (256, 3), (256, 7), (256, 9), (128, 5), (512, 5), (256, 11)]}
+
+
+def random_lens(rng, rows):
+    fam = rng.integers(0, 7)
+    if fam == 0: lens = rng.integers(0, 8, rows)
+    elif fam == 1: lens = np.full(rows, rng.integers(1, 70))
+    elif fam == 2: lens = np.minimum((rng.pareto(1.1, rows) * 3).astype(np.int64), 50000)
+    elif fam == 3: lens = np.zeros(rows, np.int64); lens[rng.integers(0, rows, max(1, rows // 1000))] = rng.integers(1, 200000)
+    elif fam == 4: lens = np.where(rng.random(rows) < 0.9, 0, rng.integers(1, 40, rows))
+    elif fam == 5: lens = rng.integers(0, 3, rows); lens[rng.integers(0, rows)] = rng.integers(10000, 400000)
+    else: lens = np.zeros(rows, np.int64)
+    return np.asarray(lens, np.int64)
+
+
+def offset_view(t, off):
+    """a view whose data pointer is `off` elements past an aligned allocation"""
+    buf = torch.empty(t.numel() + 8, dtype=t.dtype, device=t.device)
+    v = buf[off: off + t.numel()]
+    v.copy_(t)
+    return v
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    t_end = time.time() + budget
+    cases = 0
+    worst = 0.0
+    while time.time() < t_end:
+        f32 = bool(rng.integers(0, 2))
+        tdt = torch.float32 if f32 else torch.float64
+        vb = 4 if f32 else 8
+        rows = int(rng.choice([1, 2, 3, 5, 17, 100, 1000, 5000, 40000, 300000]))
+        cols = int(rng.choice([1, 2, 7, 64, 1000, 100000]))
+        lens = random_lens(rng, rows)
+        if lens.sum() > 1_500_000: lens = lens // (lens.sum() // 1_500_000 + 1)
+        off = np.zeros(rows + 1, np.int64); np.cumsum(lens, out=off[1:])
+        nnz = int(off[-1])
+        col = torch.randint(0, cols, (nnz,), device="cuda", dtype=torch.int32)
+        val = (torch.rand(nnz, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+        offs = torch.from_numpy(off.astype(np.int32)).cuda()
+        a_off, c_off, r_off = (int(rng.integers(0, 4)) if rng.random() < 0.25 else 0 for _ in range(3))
+        val_v, col_v, off_v = offset_view(val, a_off), offset_view(col, c_off), offset_view(offs, r_off)
+        lens_i = torch.from_numpy(lens).cuda()
+        segsum = lambda data: torch.segment_reduce(data, "sum", lengths=lens_i, axis=0, unsafe=True)
+        flags = int(rng.choice(FLAGS))
+        shape = SHAPES[vb][int(rng.integers(0, 7))] if rng.random() < 0.5 else (0, 0)
+        eps = 2.0 ** -24 if f32 else 2.0 ** -53
+        lens_t = torch.from_numpy(lens).cuda().double()
+        cfac = 2.0 * (torch.ceil(torch.log2(lens_t + 1)) + 16 + 8)
+        try:
+            M.set_tuning(vb, shape[0], shape[1], flags)
+            mode = rng.integers(0, 3)
+            if mode < 2:                               # CsrMV / axpby (+ prepared)
+                x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+                alpha, beta = (1.0, 0.0) if mode == 0 else (float(rng.uniform(-2, 2)), float(rng.choice([0.0, 0.5, -1.0])))
+                y0 = (torch.rand(rows, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+                y = y0.clone()
+                ws = M.CsrMVWorkspace(rows, nnz, tdt)
+                if rng.random() < 0.3: ws.prepare(off_v)
+                M.csrmv(val_v, off_v, col_v, x, y=y, num_cols=cols, workspace=ws,
+                        alpha=None if mode == 0 else alpha, beta=None if mode == 0 else beta)
+                prod = val.double() * x.double()[col.long()]
+                g = segsum(prod)
+                s = segsum(prod.abs())
+                want = alpha * g + beta * y0.double()
+                tol = cfac * eps * (abs(alpha) * s + abs(beta) * y0.double().abs()) + (0 if mode == 0 else 4 * eps * want.abs())
+                err = (y.double() - want).abs()
+                bad = err > tol
+                if mode == 0: bad |= (lens_t == 0) & (y != 0)
+                ratio = float((err / (tol + 1e-300)).max()) if rows else 0.0
+            else:                                      # SpMM
+                k = int(rng.integers(1, 10)); padx, pady = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+                Xw = (torch.rand(cols, k + padx, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt); X = Xw[:, padx:]
+                Yw = torch.zeros(rows, k + pady, dtype=tdt, device="cuda"); Y = Yw[:, pady:]
+                M.csrmm(val_v, off_v, col_v, X, Y=Y)
+                prod = val.double()[:, None] * X.double()[col.long()]
+                g = segsum(prod)
+                s = segsum(prod.abs())
+                err = (Y.double() - g).abs(); tol = cfac[:, None] * eps * s
+                bad = (err > tol) | ((lens_t == 0)[:, None] & (Y != 0))
+                if pady: bad = bad | (Yw[:, :pady] != 0).any(dim=1, keepdim=True)
+                ratio = float((err / (tol + 1e-300)).max()) if rows else 0.0
+            if bool(bad.any()):
+                print(f"MISMATCH seed={seed} case={cases}: f32={f32} rows={rows} cols={cols} nnz={nnz} flags={flags:#x} shape={shape} "
+                      f"offsets={a_off, c_off, r_off} mode={mode} bad={int(bad.sum())}", flush=True)
+                sys.exit(1)
+            worst = max(worst, ratio)
+        finally:
+            M.set_tuning(vb)
+        cases += 1
+    torch.cuda.synchronize()
+    print(f"fuzz: {cases} cases in {budget:.0f} s, all within tolerance (worst |err|/bound = {worst:.3f})")
+
+
+if __name__ == "__main__":
+    main()
