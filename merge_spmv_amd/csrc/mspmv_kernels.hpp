@@ -336,10 +336,11 @@ template <> struct EndType<true> { typedef end16_t type; };
 __device__ __forceinline__ int swz_prod(int i) { return i ^ (((i >> 5) & 7) << 2); }
 
 // ---------------------------------------------------------------------------
-// The LDS phases of a tile, shared by both tile kernels: per-thread merge-path
-// search on diagonal tid*IPT, the IPT-step path walk, the block-wide carry
-// scan, the y stores and the tile's carry-out.
-// ref: agent_spmv_orig.cuh:539-634,906-913.  Everything is tile-relative
+// The reference's in-tile algorithm (agent_spmv_orig.cuh:539-634,906-913), tuned for CDNA4:
+// per-thread merge-path search on diagonal tid*IPT, the IPT-step path walk, the block-wide
+// carry scan, the y stores and the tile's carry-out.  Used by the dword-per-lane fallback
+// kernel (tile_kernel) and selectable in tile_kernel_vec for comparison (tuning flag 0x70000);
+// the production kernels use consume_tile_flags below.  Everything is tile-relative
 // (row 0 == c0.x, nonzero 0 == c0.y).
 //   s_end[r]  = tile-relative nonzero index where tile row r ends (r <
 //               tile_rows), +inf for the row left open at the tile end (the
@@ -347,7 +348,7 @@ __device__ __forceinline__ int swz_prod(int i) { return i ^ (((i >> 5) & 7) << 2
 //               array for the last tile);
 //   s_prod[j] = values[j] * x[cols[j]] for the tile's nonzeros.
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int IPT, bool AXPBY, int ABLATE = 0, bool SWZ = false>
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool SWZ = false>
 __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
                                                  const int *s_end, const V *s_prod, V *s_y, int *s_wave_key,
                                                  V *s_wave_val, Carry<V> *__restrict__ carry_out, int pshift = 0)
@@ -366,8 +367,6 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
     // (the predicate is monotone in r, Appendix B.2; the bounds max(diag - nnz, 0) and
     // min(diag, rows) of the reference's search are implied by it).  Uniform trip count.
     int row = 0;
-    if (ABLATE == 4) row = (int) ((long long) diag * tile_rows / (tile_items > 0 ? tile_items : 1));   // no search (wrong results)
-    else
     for (int step = 1 << (31 - __builtin_clz(tile_rows | 1)); step > 0; step >>= 1) {
         const int q = row + step;                      // candidate count
         const int e = s_end[q - 1 < tile_rows ? q - 1 : tile_rows];   // clamped: slot tile_rows holds +inf
@@ -385,7 +384,7 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
     // k), so all products are read in a second batch and the segmented sum runs in registers.
     unsigned mask = 0;
 #pragma unroll
-    for (int j = 0; j < (ABLATE == 3 ? 1 : IPT); ++j) {
+    for (int j = 0; j < IPT; ++j) {
         const int pos = s_end[row + j] - nz + j;       // +inf sentinel (2^30) stays out of range
         mask |= pos < IPT ? 1u << pos : 0u;
     }
@@ -393,7 +392,7 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
     {
         int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
+        for (int k = 0; k < IPT; ++k) {
             prod[k] = SWZ ? s_prod[swz_prod(pshift + nz + k - cnt)] : s_prod[nz + k - cnt];
             cnt += (mask >> k) & 1u;
         }
@@ -402,7 +401,7 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
     V ended[IPT];
     V total = 0;
 #pragma unroll
-    for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
+    for (int k = 0; k < IPT; ++k) {
         const bool end = (mask >> k) & 1u;
         ended[k] = total;
         total = end ? (V) 0 : total + prod[k];
@@ -411,8 +410,6 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
     // ---- carry between threads: block-wide exclusive reduce-by-key scan (has a barrier
     //      inside: after it every thread has finished reading s_prod, which s_y aliases)
     int prev_key, agg_key; V carry_in, agg_val;
-    if (ABLATE == 2) { prev_key = row; carry_in = total; agg_key = row; agg_val = total; }   // no scan (wrong results)
-    else
     block_exclusive_rbk<V, BLOCK>(row + done_all, total, s_wave_key, s_wave_val, prev_key, carry_in, agg_key, agg_val);
     // ---- row totals -> LDS (scattered 4/8-byte LDS writes are cheap; scattered global
     //      stores were not: ~1.3 rows per L2 write request, as many requests as the
@@ -423,7 +420,7 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
         const V first_carry = (tid > 0 && prev_key == first_row) ? carry_in : (V) 0;
         int done = 0;
 #pragma unroll
-        for (int k = 0; k < (ABLATE == 3 ? 1 : IPT); ++k) {
+        for (int k = 0; k < IPT; ++k) {
             if ((mask >> k) & 1u) {
                 s_y[row + done] = done == 0 ? ended[k] + first_carry : ended[k];
                 ++done;
@@ -995,7 +992,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
                                                      s_wave_key, s_wave_val, carries + tile, pshift,
                                                      (TRACE && trace && trace_iter < 16) ? trace + ((size_t) blockIdx.x * 16 + trace_iter) * 8 : nullptr);
         else
-            consume_tile_lds<V, BLOCK, IPT, AXPBY, 0, true>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw,
+            consume_tile_lds<V, BLOCK, IPT, AXPBY, true>(p, c0, tile_rows, tile_nnz, s_end_raw + eshift, s_prod_raw,
                                                             s_prod_raw, s_wave_key, s_wave_val, carries + tile, pshift);
         MSPMV_TR(4);
         if (!has_next) break;
@@ -1202,9 +1199,8 @@ __global__ __launch_bounds__(BLOCK) void fixup_onepass_kernel(const Carry<V> *__
 // Small problems (at most one resident wave of tiles, <= 2048): every block finds
 // its own two tile coordinates -- wave 0 searches the tile's start diagonal and
 // wave 1 its end diagonal, concurrently, with the 64-ary wave search -- so the
-// coordinate pass (a launch and 6-9 us) disappears; the persistent kernel's
-// prefetch has nothing to overlap with at this size anyway.  Measured: -5 % on a
-// 3 M-nnz R-MAT matrix; +8 % (worse) at 11 000 tiles, hence the threshold.
+// coordinate pass (a launch and 6-9 us) disappears.  Measured: -5 % on a 3 M-nnz R-MAT
+// matrix; +10-35 % (worse) from 11 000 tiles up, hence the threshold.
 // Tried and removed: applying the carries in the same launch (last block to take
 // a ticket runs the fix-up after an agent-scope release/acquire, CDNA guide G16):
 // ~1800 release fences + ticket atomics on one word cost ~80 us, against ~10 us
