@@ -344,10 +344,19 @@ static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const
 
 // ---------------------------------------------------------------------------
 // SpMM: Y[rows x k] = alpha * A * X[cols x k] + beta * Y, X and Y row-major (mspmv_spmm.hpp).
-// One coordinate pass for the call, then per group of <= 16 bytes of right-hand sides one tile
-// kernel + one fix-up launch.  Tile 256 x 7 (LDS: 2048 packs of <= 16 bytes + the row ends).
+// The right-hand sides are taken in groups of one pack: 64- and 32-byte packs first (a whole row
+// of X per gather; small tiles -- 128x3 / 256x3 path items -- because a tile's products must fit
+// LDS), then 16, 8, 4 bytes on 256x7 tiles.  One coordinate pass per tile size used by the call;
+// all groups of one pack width share one tile-kernel launch and one fix-up launch.
 // ---------------------------------------------------------------------------
-constexpr int MM_BLOCK = 256, MM_IPT = 7, MM_TILE = MM_BLOCK * MM_IPT;
+template <typename T, int K> struct MMShape {
+    static constexpr int PACK = K * (int) sizeof(T);
+    static constexpr int BLOCK = PACK >= 64 ? 128 : 256;
+    static constexpr int IPT = PACK >= 32 ? 3 : 7;
+    static constexpr int TILE = BLOCK * IPT;
+};
+constexpr int MM_TILES[3] = {256 * 7, 256 * 3, 128 * 3};      // tile sizes in use: index 0 narrow packs, 1: 32-byte, 2: 64-byte
+template <typename T, int K> constexpr int mm_tile_index() { return MMShape<T, K>::PACK >= 64 ? 2 : MMShape<T, K>::PACK >= 32 ? 1 : 0; }
 
 // generic row-per-thread fallback (arrays not 16-byte aligned, or fewer than 4 nonzeros / 3 rows)
 template <typename T>
@@ -363,18 +372,44 @@ __global__ void spmm_rowwise_kernel(const T *values, const int *row_offsets, con
     *dst = alpha * sum + (beta == (T) 0 ? (T) 0 : beta * *dst);
 }
 
-struct MMLayout { int num_tiles; uint64_t coords_off, carries_off, total; };
+// how a block of k right-hand sides is cut into groups: count[i] groups of width[i] columns
+template <typename T> struct MMPlan { int width[5], count[5], n; };
+// Wide packs (32 / 64 bytes: a whole row of X per gather, but small tiles and few resident waves) pay
+// when the gathers miss -- X larger than a cache -- and cost when they hit anyway: measured, a 2 KB X
+// (dense 32-column matrix) runs k = 16 in 1.00 ms with four 16-byte groups and 1.42 ms with one 64-byte
+// pack, a 200 MB X (C2) in 7.4 ms vs 1.9 ms.  The X footprint decides.
 template <typename T>
-static MMLayout make_mm_layout(int rows, int nnz, int k)
+static MMPlan<T> make_mm_plan(int k, bool wide)
 {
-    MMLayout L;
+    MMPlan<T> pl; pl.n = 0;
+    for (int w = (wide ? 64 : 16) / (int) sizeof(T); w >= 1; w >>= 1) {
+        pl.width[pl.n] = w; pl.count[pl.n] = k / w; k -= pl.count[pl.n] * w; ++pl.n;
+    }
+    return pl;
+}
+
+struct MMLayout { int num_tiles[3]; uint64_t coords_off[3], carries_off, total; };
+template <typename T>
+static MMLayout make_mm_layout(int rows, int nnz, int k, bool wide)
+{
+    MMLayout L; memset(&L, 0, sizeof(L));
     const long long total = (long long) rows + nnz;
-    L.num_tiles = (int) ((total + MM_TILE - 1) / MM_TILE);
-    constexpr int KMAX = 16 / (int) sizeof(T);
-    uint64_t off = 0;
-    L.coords_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(Coord));
-    const int groups = k / KMAX > 0 ? k / KMAX : 1;     // full groups share one launch, each with its own carry list
-    L.carries_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * groups * sizeof(CarryMM<T, KMAX>));
+    const MMPlan<T> pl = make_mm_plan<T>(k, wide);
+    uint64_t off = 0, carry_bytes = 256;
+    bool used[3] = {false, false, false};
+    for (int i = 0; i < pl.n; ++i) {
+        if (pl.count[i] == 0) continue;
+        const int pack = pl.width[i] * (int) sizeof(T);
+        const int ti = pack >= 64 ? 2 : pack >= 32 ? 1 : 0;
+        used[ti] = true;
+        const uint64_t tiles = (uint64_t) ((total + MM_TILES[ti] - 1) / MM_TILES[ti]);
+        carry_bytes = std::max<uint64_t>(carry_bytes, (tiles > 0 ? tiles : 1) * pl.count[i] * (uint64_t) (sizeof(T) + pack));   // sizeof(CarryMM): key padded to the element size
+    }
+    for (int ti = 0; ti < 3; ++ti) {
+        L.num_tiles[ti] = (int) ((total + MM_TILES[ti] - 1) / MM_TILES[ti]);
+        if (used[ti]) { L.coords_off[ti] = off; off = align256(off + uint64_t(L.num_tiles[ti] + 1) * sizeof(Coord)); }
+    }
+    L.carries_off = off; off = align256(off + carry_bytes);
     L.total = off;
     return L;
 }
@@ -383,24 +418,37 @@ template <typename T, int K>
 static hipError_t run_mm_group(const MMLayout &L, char *base, MMParams<T> p, int groups, bool axpby, bool nt, hipStream_t stream,
                                int debug_sync)
 {
-    const Coord *coords = reinterpret_cast<const Coord *>(base + L.coords_off);
+    typedef MMShape<T, K> S;
+    constexpr int ti = mm_tile_index<T, K>();
+    const Coord *coords = reinterpret_cast<const Coord *>(base + L.coords_off[ti]);
     CarryMM<T, K> *carries = reinterpret_cast<CarryMM<T, K> *>(base + L.carries_off);
+    static_assert(sizeof(CarryMM<T, K>) == sizeof(T) + K * sizeof(T), "carry layout assumed by make_mm_layout");
     const uintptr_t pack_bytes = K * sizeof(T);
     p.x_vec = (reinterpret_cast<uintptr_t>(p.x) % pack_bytes == 0 && ((uintptr_t) p.ldx * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
     p.y_vec = (reinterpret_cast<uintptr_t>(p.y) % pack_bytes == 0 && ((uintptr_t) p.ldy * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
-    const unsigned grid = (unsigned) L.num_tiles;
-#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, MM_BLOCK, MM_IPT, AX, NTF>), dim3(grid), dim3(MM_BLOCK), 0, stream, p, coords, carries, L.num_tiles, groups)
+    const int num_tiles = L.num_tiles[ti];
+    const unsigned grid = (unsigned) num_tiles;
+#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, S::BLOCK, S::IPT, AX, NTF>), dim3(grid), dim3(S::BLOCK), 0, stream, p, coords, carries, num_tiles, groups)
     if (axpby) { if (nt) MSPMV_MM_LAUNCH(true, true); else MSPMV_MM_LAUNCH(true, false); }
     else { if (nt) MSPMV_MM_LAUNCH(false, true); else MSPMV_MM_LAUNCH(false, false); }
 #undef MSPMV_MM_LAUNCH
-    MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_tile_kernel", grid, MM_BLOCK));
-    if (L.num_tiles > 1) {
-        const unsigned fgrid = (unsigned) ((L.num_tiles + FIX_CHUNK - 1) / FIX_CHUNK);
-        hipLaunchKernelGGL((spmm_fixup_kernel<T, K, FIX_BLOCK, FIX_IPT>), dim3(fgrid, (unsigned) groups), dim3(FIX_BLOCK), 0, stream, carries, L.num_tiles,
+    MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_tile_kernel", grid, S::BLOCK));
+    if (num_tiles > 1) {
+        const unsigned fgrid = (unsigned) ((num_tiles + FIX_CHUNK - 1) / FIX_CHUNK);
+        hipLaunchKernelGGL((spmm_fixup_kernel<T, K, FIX_BLOCK, FIX_IPT>), dim3(fgrid, (unsigned) groups), dim3(FIX_BLOCK), 0, stream, carries, num_tiles,
                            p.y, p.ldy, p.y_vec, p.rows, p.alpha);
         MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_fixup_kernel", fgrid, FIX_BLOCK));
     }
     return hipSuccess;
+}
+
+template <typename T, int W>
+static hipError_t run_mm_width(int width, const MMLayout &L, char *base, const MMParams<T> &p, int groups, bool axpby, bool nt,
+                               hipStream_t stream, int debug_sync)
+{
+    if (width == W) return run_mm_group<T, W>(L, base, p, groups, axpby, nt, stream, debug_sync);
+    if constexpr (W > 1) return run_mm_width<T, W / 2>(width, L, base, p, groups, axpby, nt, stream, debug_sync);
+    return hipErrorInvalidValue;
 }
 
 template <typename T>
@@ -410,7 +458,8 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0 || k < 0 || ldx < k || ldy < k) return hipErrorInvalidValue;
     if ((long long) rows + nnz > 0x7fffffffLL) return hipErrorInvalidValue;
-    const MMLayout L = make_mm_layout<T>(rows, nnz, k);
+    const bool wide = (unsigned long long) cols * (unsigned long long) ldx * sizeof(T) > (1ull << 20);
+    const MMLayout L = make_mm_layout<T>(rows, nnz, k, wide);
     if (d_temp == nullptr) { *temp_bytes = (size_t) L.total; return hipSuccess; }
     if (*temp_bytes < L.total) return hipErrorInvalidValue;
     if (rows == 0 || k == 0) return hipSuccess;
@@ -427,29 +476,33 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
         return (int) after_launch(stream, debug_sync, "spmm_rowwise_kernel", grid, 256);
     }
     char *base = static_cast<char *>(d_temp);
-    {   // tile coordinates, once for all groups
-        Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off);
-        const long long threads = ((long long) rows + 1 + 3) / 4;
-        const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
-        hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, MM_TILE, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream,
-                           d_row_offsets, rows, nnz, L.num_tiles, coords);
-        MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
-    }
+    const MMPlan<T> pl = make_mm_plan<T>(k, wide);
+    bool have_coords[3] = {false, false, false};
     const bool axpby = !(alpha == (T) 1 && beta == (T) 0);
     const unsigned long long stream_bytes = (unsigned long long) nnz * (sizeof(T) + 4) + 4ull * rows;
     const bool nt = stream_bytes > (200ull << 20);
     MMParams<T> p;
     p.values = d_values; p.row_end = d_row_offsets + 1; p.cols = d_cols; p.rows = rows; p.nnz = nnz; p.ldx = ldx; p.ldy = ldy;
     p.alpha = alpha; p.beta = beta; p.x_vec = p.y_vec = 0;
-    constexpr int KMAX = 16 / (int) sizeof(T);
-    for (int c = 0; c < k;) {
-        const int left = k - c;
+    int c = 0;
+    for (int i = 0; i < pl.n; ++i) {
+        if (pl.count[i] == 0) continue;
+        const int pack = pl.width[i] * (int) sizeof(T);
+        const int ti = pack >= 64 ? 2 : pack >= 32 ? 1 : 0;
+        if (!have_coords[ti]) {                   // tile coordinates for this tile size, once
+            Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off[ti]);
+            const long long threads = ((long long) rows + 1 + 3) / 4;
+            const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
+            if (ti == 0) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 7, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[0], coords);
+            else if (ti == 1) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[1], coords);
+            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 128 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[2], coords);
+            MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
+            have_coords[ti] = true;
+        }
         p.x = d_x + c; p.y = d_y + c;
-        hipError_t e;
-        if (left >= KMAX) { const int g = left / KMAX; e = run_mm_group<T, KMAX>(L, base, p, g, axpby, nt, stream, debug_sync); c += g * KMAX; }
-        else if (KMAX >= 4 && left >= 2) { e = run_mm_group<T, 2>(L, base, p, 1, axpby, nt, stream, debug_sync); c += 2; }
-        else { e = run_mm_group<T, 1>(L, base, p, 1, axpby, nt, stream, debug_sync); c += 1; }
+        const hipError_t e = run_mm_width<T, 64 / (int) sizeof(T)>(pl.width[i], L, base, p, pl.count[i], axpby, nt, stream, debug_sync);
         if (e != hipSuccess) return (int) e;
+        c += pl.count[i] * pl.width[i];
     }
     return hipSuccess;
 }

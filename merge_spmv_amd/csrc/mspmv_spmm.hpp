@@ -9,7 +9,9 @@
 // the K entries X[col, c0 .. c0+K) that one gather brings in.  One pass over A serves K vectors,
 // and a gather moves K * sizeof(T) useful bytes instead of one element of a 128-byte line, which
 // is what bounds CsrMV on matrices without column locality.
-// A pack is at most 16 bytes (fp32: 4, fp64: 2); wider blocks are processed in groups.
+// Packs of 4 .. 64 bytes are compiled (fp32: K = 1, 2, 4, 8, 16; fp64: K = 1, 2, 4, 8): a wide pack
+// consumes a whole 32- or 64-byte row of X per gather, at the price of small tiles (the products of a
+// tile must fit LDS) and few resident waves; wider blocks are processed in groups of the widest pack.
 #pragma once
 
 #include "mspmv_kernels.hpp"
@@ -105,21 +107,53 @@ __device__ __forceinline__ void store_pack(T *__restrict__ p, const Pack<T, K> &
     }
 }
 
-// 16-byte units of the LDS pack array (a unit holds 16 / sizeof(P) packs); same XOR swizzle rule
-// as prod_unit: a thread of the nonzero phase owns UPT consecutive units
-template <typename P, int CPT>
+// The staged products / running sums live in LDS as 16-byte units.  A pack of sizeof(P) bytes is a
+// fraction of a unit (4, 8 bytes), one unit, or several consecutive logical units (32, 64 bytes); a
+// thread of the nonzero phase owns UPT = NPT * sizeof(P) / 16 consecutive logical units.  Logical
+// unit u is stored at u ^ ((u >> 4) & (UPT - 1)) (UPT a power of two): the threads of a quarter
+// wave then start in different banks, and a group of 16 logical units stays a group.
+template <typename P, int NPT>
 __device__ __forceinline__ int mm_unit(int u)
 {
-    constexpr int UPT = CPT * 4 * (int) sizeof(P) / 16;
-    return (UPT == 2 || UPT == 4 || UPT == 8) ? u ^ ((u >> 4) & (UPT - 1)) : u;
+    constexpr int UPT = NPT * (int) sizeof(P) / 16;
+    constexpr bool POW2 = UPT >= 2 && UPT <= 16 && (UPT & (UPT - 1)) == 0;
+    return POW2 ? u ^ ((u >> 4) & (UPT - 1)) : u;
 }
-template <typename P, int CPT>
-__device__ __forceinline__ int mm_slot(int e)
+template <typename P, int NPT>
+__device__ __forceinline__ P lds_load_pack(const int4v *s_units, int e)
 {
-    constexpr int EPU = 16 / (int) sizeof(P);
-    return mm_unit<P, CPT>(e / EPU) * EPU + (e % EPU);
+    P r;
+    if (sizeof(P) <= 16) {
+        constexpr int PPU = sizeof(P) <= 16 ? 16 / (int) sizeof(P) : 1;
+        const char *base = reinterpret_cast<const char *>(&s_units[mm_unit<P, NPT>(e / PPU)]) + (e % PPU) * sizeof(P);
+        r = *reinterpret_cast<const P *>(base);
+    } else {
+        constexpr int UPP = sizeof(P) > 16 ? (int) sizeof(P) / 16 : 1;
+#pragma unroll
+        for (int w = 0; w < UPP; ++w) {
+            const int4v v = s_units[mm_unit<P, NPT>(e * UPP + w)];
+            __builtin_memcpy(reinterpret_cast<char *>(&r) + 16 * w, &v, 16);
+        }
+    }
+    return r;
 }
-template <typename P> struct alignas(16) Unit16 { P e[16 / sizeof(P)]; };
+template <typename P, int NPT>
+__device__ __forceinline__ void lds_store_pack(int4v *s_units, int e, const P &val)
+{
+    if (sizeof(P) <= 16) {
+        constexpr int PPU = sizeof(P) <= 16 ? 16 / (int) sizeof(P) : 1;
+        char *base = reinterpret_cast<char *>(&s_units[mm_unit<P, NPT>(e / PPU)]) + (e % PPU) * sizeof(P);
+        *reinterpret_cast<P *>(base) = val;
+    } else {
+        constexpr int UPP = sizeof(P) > 16 ? (int) sizeof(P) / 16 : 1;
+#pragma unroll
+        for (int w = 0; w < UPP; ++w) {
+            int4v v;
+            __builtin_memcpy(&v, reinterpret_cast<const char *>(&val) + 16 * w, 16);
+            s_units[mm_unit<P, NPT>(e * UPP + w)] = v;
+        }
+    }
+}
 
 // One tile per block.  BLOCK x IPT path items; the staging is the predicated ("careful") form of
 // mspmv_kernels.hpp for every tile (nothing outside the tile or the arrays is used).
@@ -128,16 +162,16 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
                                                           CarryMM<T, K> *__restrict__ carries, int num_tiles, int groups)
 {
     typedef Pack<T, K> P;
-    static_assert(sizeof(P) <= 16 && 16 % sizeof(P) == 0, "a pack is 4, 8 or 16 bytes");
+    static_assert(sizeof(P) == 4 || sizeof(P) == 8 || sizeof(P) % 16 == 0, "a pack is 4 or 8 bytes or whole 16-byte units");
     constexpr int NW = BLOCK / WAVE;
     constexpr int CPT = IPT / 4 + 1;
     constexpr int SLOTS = CPT * BLOCK * 4;
     constexpr int NPT = CPT * 4;
-    constexpr int EPU = 16 / (int) sizeof(P);
-    constexpr int UPT = NPT / EPU;
+    constexpr int UPT = NPT * (int) sizeof(P) / 16;        // 16-byte units per thread of the nonzero phase
     constexpr int FLAG_WORDS = SLOTS / 32 + 1;
+    static_assert(FLAG_WORDS <= BLOCK && NPT <= 16, "flag word handling");
     __shared__ __attribute__((aligned(16))) end16_t s_end_raw[SLOTS];
-    __shared__ __attribute__((aligned(16))) P s_prod_raw[SLOTS];
+    __shared__ int4v s_units[SLOTS * sizeof(P) / 16];
     __shared__ unsigned s_flag[FLAG_WORDS];
     __shared__ int s_wave_flag[NW];
     __shared__ P s_wave_val[NW];
@@ -237,14 +271,14 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
-                    s_prod_raw[mm_slot<P, CPT>(4 * chunk + i)] = in ? regs.val[k].get(i) * xv[k][i] : P((T) 0);
+                    lds_store_pack<P, NPT>(s_units, 4 * chunk + i, in ? regs.val[k].get(i) * xv[k][i] : P((T) 0));
                 }
             }
             if (nz_tail) {                             // block-uniform; <= 3 nonzeros of the ragged array tail
                 __syncthreads();
                 const int j = last_full_nz + 4 + tid;
                 if (j < c1.y && j >= c0.y)
-                    s_prod_raw[mm_slot<P, CPT>(j - a0)] = p.values[j] * load_pack<T, K>(xg + (size_t) (unsigned) p.cols[j] * (unsigned) p.ldx, p.x_vec != 0);
+                    lds_store_pack<P, NPT>(s_units, j - a0, p.values[j] * load_pack<T, K>(xg + (size_t) (unsigned) p.cols[j] * (unsigned) p.ldx, p.x_vec != 0));
             }
             __syncthreads();
         }
@@ -252,9 +286,8 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
         P s[NPT];
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
-            const Unit16<P> w = *reinterpret_cast<const Unit16<P> *>(&s_prod_raw[mm_unit<P, CPT>(tid * UPT + u) * EPU]);
-#pragma unroll
-            for (int e = 0; e < EPU; ++e) s[u * EPU + e] = w.e[e];
+            const int4v w = s_units[mm_unit<P, NPT>(tid * UPT + u)];
+            __builtin_memcpy(reinterpret_cast<char *>(s) + 16 * u, &w, 16);
         }
         const unsigned lo = s_flag[base >> 5], hi = s_flag[(base >> 5) + 1];
         const unsigned m = (unsigned) ((((unsigned long long) hi << 32) | lo) >> (base & 31)) & ((1u << NPT) - 1u);
@@ -270,17 +303,16 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
         for (int k = 0; k < NPT; ++k) s[k] += ((lead >> k) & 1u) ? carry_in : P((T) 0);
 #pragma unroll
         for (int u = 0; u < UPT; ++u) {
-            Unit16<P> w;
-#pragma unroll
-            for (int e = 0; e < EPU; ++e) w.e[e] = s[u * EPU + e];
-            *reinterpret_cast<Unit16<P> *>(&s_prod_raw[mm_unit<P, CPT>(tid * UPT + u) * EPU]) = w;
+            int4v w;
+            __builtin_memcpy(&w, reinterpret_cast<const char *>(s) + 16 * u, 16);
+            s_units[mm_unit<P, NPT>(tid * UPT + u)] = w;
         }
         __syncthreads();
         // row phase: Y[row, group] = running sum at the row's last nonzero
         for (int r = tid; r < tile_rows; r += BLOCK) {
             const int e = s_end[r];
             const int e0 = r > 0 ? s_end[r - 1] : 0;
-            P sum = e > e0 ? s_prod_raw[mm_slot<P, CPT>(pshift + e - 1)] : P((T) 0);
+            P sum = e > e0 ? lds_load_pack<P, NPT>(s_units, pshift + e - 1) : P((T) 0);
             T *dst = yg + (size_t) r * (unsigned) p.ldy;
             if (AXPBY) {
                 sum = p.alpha * sum;
@@ -291,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
         if (tid == BLOCK - 1) {
             const int e_last = tile_rows > 0 ? s_end[tile_rows - 1] : 0;
             CarryMM<T, K> c; c.key = c0.x + tile_rows;
-            c.value = tile_nnz > e_last ? s_prod_raw[mm_slot<P, CPT>(pshift + tile_nnz - 1)] : P((T) 0);
+            c.value = tile_nnz > e_last ? lds_load_pack<P, NPT>(s_units, pshift + tile_nnz - 1) : P((T) 0);
             carries[(size_t) g * num_tiles + tile] = c;
         }
     }

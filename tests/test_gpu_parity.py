@@ -446,7 +446,7 @@ def _check_csrmm(M, csr, X, Y, alpha=1.0, beta=0.0, Y0=None):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 13, 16, 23, 33])
 def test_csrmm_matches_the_oracle_column_by_column(M, prec, k):
     dtype, vb = DT[prec]
     rng = np.random.default_rng(100 + k)

@@ -85,7 +85,7 @@ def main():
                 if mode == 0: bad |= (lens_t == 0) & (y != 0)
                 ratio = float((err / (tol + 1e-300)).max()) if rows else 0.0
             else:                                      # SpMM
-                k = int(rng.integers(1, 10)); padx, pady = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+                k = int(rng.integers(1, 40)); padx, pady = int(rng.integers(0, 3)), int(rng.integers(0, 3))
                 Xw = (torch.rand(cols, k + padx, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt); X = Xw[:, padx:]
                 Yw = torch.zeros(rows, k + pady, dtype=tdt, device="cuda"); Y = Yw[:, pady:]
                 M.csrmm(val_v, off_v, col_v, X, Y=Y)
