@@ -80,9 +80,10 @@ int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_valu
 
 /* ---- extension: SpMM, Y = alpha*A*X + beta*Y for k right-hand sides.
  * X is cols x k and Y is rows x k, both ROW-major with leading dimensions ldx, ldy >= k (elements):
- * the k entries X[col, :] that one column index needs are contiguous, so a single gather serves up
- * to 16 bytes of right-hand sides and one pass over the matrix serves up to 4 (fp32) / 2 (fp64)
- * vectors; wider blocks run in groups.  Same two-phase temp storage, ownership, stream and error
+ * the k entries X[col, :] that one column index needs are contiguous, so one gather serves a pack
+ * of right-hand sides -- up to 16 bytes of them on the CsrMV-sized tiles, and 32 or 64 bytes (a whole
+ * row of X) on smaller tiles when X is larger than 1 MiB, i.e. when its gathers miss the caches;
+ * wider blocks run as several groups of the widest pack inside one pass over the matrix.  Same two-phase temp storage, ownership, stream and error
  * conventions as mspmv_csrmv_*; with beta == 0 the old Y is never read.  Results per column are
  * within the same tolerance as CsrMV and bitwise reproducible.  No reference counterpart (the
  * reference ships CsrMV only). ---- */
