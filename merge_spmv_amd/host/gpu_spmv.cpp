@@ -132,11 +132,15 @@ void Verify(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, 
 // TestGpuMergeCsrmv (gpu_spmv.cu:376-435)
 template <typename V>
 float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
-                const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms)
+                const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms, bool prepared = false)
 {
     setup_ms = 0;
     const bool plain = c.alpha == 1.0f && c.beta == 0.0f;
     auto call = [&](void *temp, size_t &bytes, bool debug) {
+        // --prepared (extension): the tile coordinates were found once, outside the timed loop
+        if (prepared && temp)
+            return mspmv::DeviceSpmv::CsrMVPrepared(temp, bytes, p.d_values, p.d_row_offsets, p.d_cols, p.d_x, p.d_y, p.rows,
+                                                    p.cols, p.nnz, (V) c.alpha, (V) c.beta, (hipStream_t) 0, debug);
         return plain ? mspmv::DeviceSpmv::CsrMV(temp, bytes, p.d_values, p.d_row_offsets, p.d_cols, p.d_x, p.d_y, p.rows, p.cols,
                                                 p.nnz, (hipStream_t) 0, debug)
                      : mspmv::DeviceSpmv::CsrMV(temp, bytes, p.d_values, p.d_row_offsets, p.d_cols, p.d_x, p.d_y, p.rows, p.cols,
@@ -146,6 +150,11 @@ float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> 
     void *d_temp = nullptr;
     HIP_OK(call(nullptr, temp_bytes, false));
     HIP_OK(hipMalloc(&d_temp, temp_bytes));
+    if (prepared) {
+        GpuTimer setup; setup.Start();
+        HIP_OK(mspmv::DeviceSpmv::CsrMVPrepare<V>(d_temp, temp_bytes, p.d_row_offsets, p.rows, p.nnz));
+        setup.Stop(); setup_ms = setup.ElapsedMillis();
+    }
     HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));
     HIP_OK(call(d_temp, temp_bytes, !c.quiet));                      // warm-up (+ launch log, like debug_synchronous)
     if (!c.quiet) Verify(c, a, x, gold, p.d_y, plain);
@@ -227,7 +236,7 @@ float TestRocsparseHybmv(const RunConfig &c, const CsrMatrix<V> &a, const std::v
 }
 
 template <typename V>
-void Run(const RunConfig &c, const Device &dev, bool vendor)
+void Run(const RunConfig &c, const Device &dev, bool vendor, bool prepared_too)
 {
     CsrMatrix<V> csr;
     BuildCsr<V>(c, csr, [](const RunConfig &cc, int nnz) {
@@ -253,6 +262,11 @@ void Run(const RunConfig &c, const Device &dev, bool vendor)
     avg_ms = TestMerge(c, csr, x, y_in, gold, p, iterations, setup_ms);
     DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
     if (!c.quiet) DisplayRoofline((int) sizeof(V), avg_ms, csr.num_rows, csr.num_cols, csr.num_nonzeros, dev.giga_bandwidth);
+    if (prepared_too && !c.quiet) {            // extra method line, never in the CSV (its column layout is the reference's)
+        printf("\n\nMerge-based CsrMV (prepared: coordinates found once), "); fflush(stdout);
+        avg_ms = TestMerge(c, csr, x, y_in, gold, p, iterations, setup_ms, true);
+        DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+    }
 
     if (vendor) {
         rocsparse_handle handle;
@@ -278,7 +292,7 @@ int main(int argc, char **argv)
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
-               "[--no-strict] [--no-vendor] [--cache]\n"
+               "[--no-strict] [--no-vendor] [--cache] [--prepared]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;
@@ -286,7 +300,8 @@ int main(int argc, char **argv)
     const RunConfig c = ParseCommon(args, true);
     const Device dev = DeviceInit(c);
     const bool vendor = !args.CheckCmdLineFlag("no-vendor");
-    if (c.fp32) Run<float>(c, dev, vendor); else Run<double>(c, dev, vendor);
+    const bool prepared_too = args.CheckCmdLineFlag("prepared");
+    if (c.fp32) Run<float>(c, dev, vendor, prepared_too); else Run<double>(c, dev, vendor, prepared_too);
     HIP_OK(hipDeviceSynchronize());
     printf("\n");
     return 0;
