@@ -486,3 +486,43 @@ def test_randomized_differential_smoke(M):
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz.py"), "6", "11"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all within tolerance" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------
+# The GPU driver binary with the reference's command line: same report
+# lines, same --quiet CSV, PASS under the reference's rule and under the strict check.
+# ---------------------------------------------------------------------------
+def _gpu_spmv(*args, timeout=300):
+    import subprocess
+    exe = os.path.join(ROOT, "merge_spmv_amd", "gpu_spmv")
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_gpu_driver_reports_like_the_reference(M):
+    out = _gpu_spmv("--grid2d=300", "--i=20")
+    assert "grid2d_300, " in out and "20 timing iterations" in out and "num_rows: 90000" in out
+    for method in ("Merge-based CsrMV, ", "rocSPARSE CsrMV, ", "rocSPARSE HybMV, "):
+        assert method in out
+    assert out.count("\tPASS") == 3 and "FAIL" not in out
+    assert out.count("strict check: PASS") == 3
+    import re
+    assert re.search(r"fp64: [0-9.]+ setup ms, [0-9.]+ avg ms, [0-9.]+ gflops, [0-9.]+ effective GB/s \([0-9.]+% peak\)", out)
+    # fp32, alpha/beta honoured by the merge kernel and by the gold (the reference parses them but computes with 1/0)
+    out = _gpu_spmv("--grid3d=40", "--fp32", "--alpha=2.5", "--beta=-0.5", "--i=5", "--no-vendor", "--prepared")
+    assert "fp32:" in out and out.count("\tPASS") == 2 and "FAIL" not in out and "prepared: coordinates found once" in out
+
+
+def test_gpu_driver_quiet_csv_and_matrix_market_input(M):
+    mtx = os.path.join(ROOT, "tests/golden/mtx/giant_row.mtx")
+    line = _gpu_spmv("--quiet", "--mtx=" + mtx, "--i=3").strip()
+    f = [s.strip() for s in line.split(",")]
+    # file, 7 statistics, device, precision, then (method, setup_ms, avg_ms, gflops, GB/s) x 3 (eval_csrmv.sh:8, gpu_spmv.cu:467-471,532-534)
+    assert f[0] == mtx and f[9] == "fp64" and len(f) >= 10 + 3 * 5
+    assert f[10] == "Merge-based CsrMV" and f[15] == "rocSPARSE CsrMV" and f[20] == "rocSPARSE HybMV"
+    for i in (11, 12, 13, 14, 16, 17, 18, 19, 21, 22, 23, 24):
+        float(f[i])
+    # symmetric file: mirrored entries (sparse_matrix.h:362-368) -> verified against the gold inside the driver
+    out = _gpu_spmv("--mtx=" + os.path.join(ROOT, "tests/golden/mtx/symmetric.mtx"), "--i=2", "--no-vendor")
+    assert "\tPASS" in out and "FAIL" not in out
