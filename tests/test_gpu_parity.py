@@ -495,6 +495,8 @@ def test_randomized_differential_smoke(M):
 def _gpu_spmv(*args, timeout=300):
     import subprocess
     exe = os.path.join(ROOT, "merge_spmv_amd", "gpu_spmv")
+    if not os.path.exists(exe):                  # normally built by __graft_entry__.build(); hipcc is on the GPU box too
+        subprocess.run(["make", "-C", os.path.join(ROOT, "merge_spmv_amd"), "gpu_spmv"], check=True, capture_output=True, timeout=600)
     r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
