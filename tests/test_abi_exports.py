@@ -97,3 +97,26 @@ def test_mg_partition_matches_oracle_search(parts):
         assert lo[0] == 0 and lo[-1] == nz_split[g + 1] - nz_split[g]
         assert lo.size == row_split[g + 1] - row_split[g] + 2
         assert np.all(np.diff(lo) >= 0)
+
+
+def test_extension_entry_points_follow_the_same_conventions():
+    """mspmv_csrmv_prepare / mspmv_csrmm_*: NULL temp -> size query and nothing else; bad arguments ->
+    hipErrorInvalidValue; prepare asks for exactly the CsrMV temp size (the two share the buffer)."""
+    lib = M.load_library()
+    size = ctypes.c_size_t(0)
+    for vb in (4, 8):
+        assert lib.mspmv_csrmv_prepare(None, ctypes.byref(size), None, 1000, 50000, vb, None, 0) == 0
+        assert size.value == M.launch_info(1000, 50000, vb)["temp_bytes"]
+    assert lib.mspmv_csrmv_prepare(None, ctypes.byref(size), None, 1000, 50000, 2, None, 0) == 1
+    for fn in (lib.mspmv_csrmm_f32, lib.mspmv_csrmm_f64):
+        sizes = []
+        for k, cols in ((1, 1000), (4, 1000), (16, 1000), (16, 10_000_000)):      # narrow packs ... 64-byte packs (X > 1 MiB)
+            st = fn(None, ctypes.byref(size), None, None, None, None, k, None, k, 1000, cols, 50000, k, 1.0, 0.0, None, 0)
+            assert st == 0 and size.value > 0
+            sizes.append(size.value)
+        assert sizes[1] >= sizes[0] and sizes[3] > sizes[2]          # more / wider carries, smaller tiles
+        assert fn(None, ctypes.byref(size), None, None, None, None, 3, None, 4, 1000, 1000, 50000, 4, 1.0, 0.0, None, 0) == 1   # ldx < k
+        assert fn(None, ctypes.byref(size), None, None, None, None, 4, None, 4, -1, 1000, 5, 4, 1.0, 0.0, None, 0) == 1
+        small = ctypes.c_size_t(16)
+        assert fn(ctypes.c_void_p(256), ctypes.byref(small), None, None, None, None, 4, None, 4, 1000, 1000, 50000, 4, 1.0, 0.0, None, 0) == 1
+    assert lib.mspmv_csrmv_prepared_f32(None, ctypes.byref(size), None, None, None, None, None, 10, 10, 10, 1.0, 0.0, None, 0) == 1   # needs a prepared buffer
