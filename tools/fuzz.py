@@ -45,10 +45,12 @@ def main():
         f32 = bool(rng.integers(0, 2))
         tdt = torch.float32 if f32 else torch.float64
         vb = 4 if f32 else 8
-        rows = int(rng.choice([1, 2, 3, 5, 17, 100, 1000, 5000, 40000, 300000]))
+        big = rng.random() < 0.04            # now and then a problem beyond the fused small-problem path (> 2048 tiles)
+        rows = int(rng.choice([1_000_000, 3_000_000])) if big else int(rng.choice([1, 2, 3, 5, 17, 100, 1000, 5000, 40000, 300000]))
         cols = int(rng.choice([1, 2, 7, 64, 1000, 100000]))
         lens = random_lens(rng, rows)
-        if lens.sum() > 1_500_000: lens = lens // (lens.sum() // 1_500_000 + 1)
+        cap = 30_000_000 if big else 1_500_000
+        if lens.sum() > cap: lens = lens // (lens.sum() // cap + 1)
         off = np.zeros(rows + 1, np.int64); np.cumsum(lens, out=off[1:])
         nnz = int(off[-1])
         col = torch.randint(0, cols, (nnz,), device="cuda", dtype=torch.int32)
