@@ -72,3 +72,11 @@ def test_rmat_csr_valid_and_range_consistent():
     B = G.rmat_csr(scale, edges, dtype=torch.float64, device="cpu", row_lo=100, row_hi=400)
     a, b = off[100], off[400]
     assert torch.equal(B.column_indices, A.column_indices[a:b]) and torch.equal(B.values, A.values[a:b])
+
+
+def test_tools_and_entry_points_compile():
+    """the development scripts under tools/, bench.py and __graft_entry__.py at least parse"""
+    import glob, os, py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
