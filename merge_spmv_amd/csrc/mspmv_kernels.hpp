@@ -471,7 +471,8 @@ template <typename V, int CPT>
 __device__ __forceinline__ int prod_unit(int u)
 {
     constexpr int UPT = CPT * 4 * (int) sizeof(V) / 16;
-    return UPT == 4 ? u ^ ((u >> 4) & 3) : UPT == 2 ? u ^ ((u >> 4) & 1) : u;
+    // UPT == 6 (fp64, 12 products per thread): lanes 8 apart start 48 units apart = the same banks
+    return UPT == 4 ? u ^ ((u >> 4) & 3) : UPT == 2 ? u ^ ((u >> 4) & 1) : UPT == 6 ? u ^ ((u / 48) & 1) : u;
 }
 template <typename V, int CPT>
 __device__ __forceinline__ int prod_slot(int e)      // element index (>= 0) in raw order -> LDS element index
