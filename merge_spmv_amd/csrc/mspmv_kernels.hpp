@@ -924,7 +924,7 @@ __device__ unsigned long long *g_mspmv_trace = nullptr;
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
-                                                                Carry<V> *__restrict__ carries, int num_tiles)
+                                                                Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2)
 {
     constexpr int NW = BLOCK / WAVE;
     constexpr int CPT = IPT / 4 + 1;
@@ -947,10 +947,22 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
     // b % 8, observed; only speed depends on it); give each XCD's private L2 a
     // contiguous range of tiles.  Bijective for any num_tiles.
     auto physical = [&](int t) {
-        if (!XCD_REMAP) return t;
-        const int q = num_tiles / 8, r = num_tiles % 8;
-        const int xcd = t % 8, idx = t / 8;
-        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if (XCD_REMAP) {
+            const int q = num_tiles / 8, r = num_tiles % 8;
+            const int xcd = t % 8, idx = t / 8;
+            return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        // chunked form: inside every group of 8*G blocks, XCD k (blocks k, k+8, ...) takes G CONSECUTIVE
+        // tiles -- neighbouring tiles gather neighbouring x, which then stays in that XCD's L2 -- while
+        // the XCDs still advance through the matrix together (no per-XCD ranges to fall out of balance)
+        if (xcd_chunk_log2 > 0) {
+            const int G = 1 << xcd_chunk_log2, span = 8 * G;
+            if (t < (num_tiles / span) * span) {
+                const int q = t / span, r = t % span;
+                return (q * 8 + (r & 7)) * G + (r >> 3);
+            }
+        }
+        return t;
     };
     int seq = blockIdx.x;
     if (seq >= num_tiles) return;
