@@ -20,6 +20,8 @@
 namespace mspmv {
 
 constexpr int SEARCH_BLOCK = 256;
+constexpr int FUSED_CHUNK_LOG2 = 0;      // XCD-chunked mapping (see the tile_kernel_vec dispatch): no measurable effect below 2048 tiles
+constexpr int MM_CHUNK_LOG2 = 6;         // ... 0-3 % on the SpMM tiles
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
@@ -162,8 +164,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         prof_mark(stream, slot, 1);
         const unsigned grid = (unsigned) L.num_tiles;
         // (small problems always fit the Infinity Cache: ordinary loads)
-        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
-        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
+        const int fchunk_flag = (L.flags >> 24) & 0xf;
+        const int fchunk = fchunk_flag == 0 ? FUSED_CHUNK_LOG2 : fchunk_flag == 15 ? 0 : fchunk_flag;
+        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, fchunk);
+        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, fchunk);
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
     } else {
     // 1. tile boundary coordinates
@@ -434,7 +438,8 @@ static hipError_t run_mm_group(const MMLayout &L, char *base, MMParams<T> p, int
     p.y_vec = (reinterpret_cast<uintptr_t>(p.y) % pack_bytes == 0 && ((uintptr_t) p.ldy * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
     const int num_tiles = L.num_tiles[ti];
     const unsigned grid = (unsigned) num_tiles;
-#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, S::BLOCK, S::IPT, AX, NTF>), dim3(grid), dim3(S::BLOCK), 0, stream, p, coords, carries, num_tiles, groups)
+    constexpr int mm_chunk = MM_CHUNK_LOG2;
+#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, S::BLOCK, S::IPT, AX, NTF>), dim3(grid), dim3(S::BLOCK), 0, stream, p, coords, carries, num_tiles, groups, mm_chunk)
     if (axpby) { if (nt) MSPMV_MM_LAUNCH(true, true); else MSPMV_MM_LAUNCH(true, false); }
     else { if (nt) MSPMV_MM_LAUNCH(false, true); else MSPMV_MM_LAUNCH(false, false); }
 #undef MSPMV_MM_LAUNCH

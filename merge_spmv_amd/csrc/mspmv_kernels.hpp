@@ -919,6 +919,23 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
         stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
 }
 
+// Block -> tile mapping of the one-tile-per-block launches.  Blocks are dealt round-robin to the 8
+// XCDs (block b runs on XCD b % 8: observed; only speed depends on it).  Inside every group of 8*G
+// blocks, XCD k takes G CONSECUTIVE tiles: neighbouring tiles gather neighbouring x (which then stays in
+// that XCD's private L2) and each XCD reads longer contiguous pieces of the CSR arrays, while the XCDs
+// still advance through the matrix together.  Bijective for any num_tiles; log2 G = 0 turns it off.
+__device__ __forceinline__ int xcd_chunked_tile(int b, int num_tiles, int chunk_log2)
+{
+    if (chunk_log2 > 0) {
+        const int G = 1 << chunk_log2, span = 8 * G;
+        if (b < (num_tiles / span) * span) {
+            const int q = b / span, r = b % span;
+            return (q * 8 + (r & 7)) * G + (r >> 3);
+        }
+    }
+    return b;
+}
+
 // development: per-phase cycle stamps of the first 16 tiles of every block (ABLATE == 6 variant)
 __device__ unsigned long long *g_mspmv_trace = nullptr;
 
@@ -952,17 +969,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
             const int xcd = t % 8, idx = t / 8;
             return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-        // chunked form: inside every group of 8*G blocks, XCD k (blocks k, k+8, ...) takes G CONSECUTIVE
-        // tiles -- neighbouring tiles gather neighbouring x, which then stays in that XCD's L2 -- while
-        // the XCDs still advance through the matrix together (no per-XCD ranges to fall out of balance)
-        if (xcd_chunk_log2 > 0) {
-            const int G = 1 << xcd_chunk_log2, span = 8 * G;
-            if (t < (num_tiles / span) * span) {
-                const int q = t / span, r = t % span;
-                return (q * 8 + (r & 7)) * G + (r >> 3);
-            }
-        }
-        return t;
+        return xcd_chunked_tile(t, num_tiles, xcd_chunk_log2);
     };
     int seq = blockIdx.x;
     if (seq >= num_tiles) return;
@@ -1221,7 +1228,7 @@ __global__ __launch_bounds__(BLOCK) void fixup_onepass_kernel(const Carry<V> *__
 // ---------------------------------------------------------------------------
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>())) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
-                                                           Carry<V> *__restrict__ carries, int num_tiles)
+                                                           Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2)
 {
     constexpr int TILE = BLOCK * IPT;
     constexpr int NW = BLOCK / WAVE;
@@ -1236,7 +1243,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     __shared__ Coord s_coord[2];
 
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     const long long total = (long long) p.rows + p.nnz;
     {

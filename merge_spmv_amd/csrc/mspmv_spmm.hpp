@@ -159,7 +159,8 @@ __device__ __forceinline__ void lds_store_pack(int4v *s_units, int e, const P &v
 // mspmv_kernels.hpp for every tile (nothing outside the tile or the arrays is used).
 template <typename T, int K, int BLOCK, int IPT, bool AXPBY, bool NT>
 __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const Coord *__restrict__ coords,
-                                                          CarryMM<T, K> *__restrict__ carries, int num_tiles, int groups)
+                                                          CarryMM<T, K> *__restrict__ carries, int num_tiles, int groups,
+                                                          int xcd_chunk_log2)
 {
     typedef Pack<T, K> P;
     static_assert(sizeof(P) == 4 || sizeof(P) == 8 || sizeof(P) % 16 == 0, "a pack is 4 or 8 bytes or whole 16-byte units");
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
     __shared__ P s_wave_val[NW];
 
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     if (tid < FLAG_WORDS) s_flag[tid] = 0u;
     const Coord c0 = coords[tile];
     const Coord c1 = coords[tile + 1];
