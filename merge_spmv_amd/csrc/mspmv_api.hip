@@ -4,8 +4,8 @@
 // (cub/device/dispatch/dispatch_spmv_orig.cuh:544-752) -- without that
 // dispatcher's per-call device-attribute / occupancy queries and texture
 // bind/unbind (all inside the reference's timed loop): grid shapes here are
-// pure arithmetic on (rows, nnz), so a call is three kernel launches and
-// nothing else.
+// pure arithmetic on (rows, nnz), so a call is two or three kernel launches
+// and nothing else.  Also here: the prepared-call and SpMM entry points.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>

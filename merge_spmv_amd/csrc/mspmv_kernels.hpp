@@ -5,21 +5,27 @@
 // any CUB/hipCUB/rocPRIM primitive) is used.  The algorithm contract is
 // SURVEY.md Appendix B.
 //
-// Three device passes per SpMV, all on the caller's stream:
-//   1. search_kernel : one WAVE per tile boundary does a 64-ary merge-path
-//                      search (4 dependent loads for 2^24 rows instead of 24)
-//                      -> coords[tile]           (ref: DeviceSpmvSearchKernel)
-//   2. tile_kernel   : one 256-thread block per merge tile: coalesced stream
-//                      of (col,val), gather of x, products and row-end
-//                      offsets staged in LDS, per-thread merge-path walk,
-//                      wave64 shuffle segmented scan for the partial-row
-//                      carries, y stored for rows ending in the tile, one
-//                      (row, partial) carry per tile     (ref: DeviceSpmvKernel)
-//   3. fixup_kernel  : deterministic reduce-by-key over the per-tile carries,
-//                      y[row] += sum.  Chunked two-level instead of the
-//                      reference's decoupled look-back (no spin-waits, no
-//                      forward-progress assumption) and instead of its fp32
-//                      atomics (run-to-run reproducible). (ref: DeviceSegmentFixupKernel)
+// Device passes per SpMV, all on the caller's stream (mspmv_api.hip picks):
+//   1. coords_scatter_kernel : tile boundaries of the merge path in ONE coalesced pass over
+//                      row_offsets (row end r sits at path position r + row_end[r]); or
+//                      search_kernel: one WAVE per boundary, 64-ary search (option)
+//                      -> coords[tile]                       (ref: DeviceSpmvSearchKernel)
+//   2. tile_kernel_vec : one 256-thread block per merge tile (XCD-chunked tile order),
+//                      16-byte streaming of (col, val) and row offsets, gather of x, products
+//                      and 16-bit tile-relative row ends staged in LDS, one bit per row start;
+//                      segmented running sums over 12 consecutive products per thread + one
+//                      block-wide DPP segmented scan (consume_tile_flags), y stored per row from
+//                      registers, one (row, partial) carry per tile  (ref: DeviceSpmvKernel)
+//      tile_kernel_fused : the same for <= 2048 tiles, each block searching its own two
+//                      coordinates (no pass 1);
+//      tile_kernel     : dword-per-lane fallback for unaligned arrays, with the reference's
+//                      per-thread search + path walk (consume_tile_lds)
+//   3. fixup_onepass_kernel : deterministic reduce-by-key over the per-tile carries in one
+//                      launch (every run of equal keys has one owner block), y[row] += sum;
+//                      no decoupled look-back, no spin-waits, no atomics: bitwise reproducible
+//                      (ref: DeviceSegmentFixupKernel).  fixup_kernel / fixup_atomic_kernel:
+//                      multi-level and atomic options.
+// mspmv_spmm.hpp builds the SpMM kernels on the same pieces.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
