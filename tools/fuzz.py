@@ -45,7 +45,7 @@ def main():
         f32 = bool(rng.integers(0, 2))
         tdt = torch.float32 if f32 else torch.float64
         vb = 4 if f32 else 8
-        big = rng.random() < 0.04            # now and then a problem beyond the fused small-problem path (> 2048 tiles)
+        big = rng.random() < float(os.environ.get("FUZZ_BIG", "0.04"))   # now and then a problem beyond the fused small-problem path (> 2048 tiles)
         rows = int(rng.choice([1_000_000, 3_000_000])) if big else int(rng.choice([1, 2, 3, 5, 17, 100, 1000, 5000, 40000, 300000]))
         cols = int(rng.choice([1, 2, 7, 64, 1000, 100000]))
         lens = random_lens(rng, rows)
