@@ -44,6 +44,12 @@ def workloads(names):
             c = O.make("grid2d", 2000, dtype=np.float64)
             A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
             yield "grid2d_2000_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "grid3d":
+            import numpy as np
+            from oracle import oracle as O
+            c = O.make("grid3d", 200, dtype=np.float64)
+            A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+            yield "grid3d_200_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "band":
             # banded: 5 nnz/row near the diagonal (grid-like locality)
             rows = 16_000_000
