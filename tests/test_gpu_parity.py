@@ -528,3 +528,55 @@ def test_gpu_driver_quiet_csv_and_matrix_market_input(M):
     # symmetric file: mirrored entries (sparse_matrix.h:362-368) -> verified against the gold inside the driver
     out = _gpu_spmv("--mtx=" + os.path.join(ROOT, "tests/golden/mtx/symmetric.mtx"), "--i=2", "--no-vendor")
     assert "\tPASS" in out and "FAIL" not in out
+
+
+def _guarded(t, fill, guard=64):
+    """t inside a larger buffer whose surroundings hold `fill`; returns (view, whole buffer)"""
+    buf = torch.full((t.numel() + 2 * guard,), fill, dtype=t.dtype, device="cuda")
+    buf[guard:guard + t.numel()] = t
+    return buf[guard:guard + t.numel()], buf
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("flags", [0, 16, 4, 0x200010])
+def test_nothing_outside_the_arrays_is_used_or_written(M, prec, flags):
+    """Every array sits between guard regions: NaN around values and x (a product with anything read from
+    there would poison y), a pattern around y and around the temp storage that must survive the call.
+    Shapes with ragged array tails (nnz and rows not multiples of 4) on all dispatch paths, CsrMV and SpMM."""
+    dtype, vb = DT[prec]
+    tdt = torch.float32 if vb == 4 else torch.float64
+    rng = np.random.default_rng(5 + flags)
+    for rows, cols, hi in ((1001, 333, 9), (40003, 1777, 40), (7, 5, 3)):
+        csr = random_csr(rng, rows, cols, rng.integers(0, hi, rows), dtype)
+        if csr.nnz == 0:
+            continue
+        x = rng.uniform(-1, 1, cols).astype(dtype)
+        val, _ = _guarded(dev(csr.values), float("nan"))
+        col, _ = _guarded(dev(csr.column_indices), 0)
+        off, _ = _guarded(dev(csr.row_offsets), 0)
+        xv, _ = _guarded(dev(x), float("nan"))
+        y, ybuf = _guarded(torch.zeros(rows, dtype=tdt, device="cuda"), 12345.0)
+        info = M.launch_info(rows, csr.nnz, vb)
+        ws = M.CsrMVWorkspace(rows, csr.nnz, tdt)
+        tbuf = torch.full((ws.bytes + 512,), 0xAB, dtype=torch.uint8, device="cuda")
+        ws.buffer = tbuf[256:256 + ws.bytes]
+        try:
+            M.set_tuning(vb, 0, 0, flags)
+            M.csrmv(val, off, col, xv, y=y, num_cols=cols, workspace=ws)
+        finally:
+            M.set_tuning(vb)
+        torch.cuda.synchronize()
+        assert not torch.isnan(y).any()
+        check_strict(M, csr, x, y.cpu().numpy())
+        assert bool((ybuf[:64] == 12345.0).all()) and bool((ybuf[-64:] == 12345.0).all())
+        assert bool((tbuf[:256] == 0xAB).all()) and bool((tbuf[-256:] == 0xAB).all())
+        # SpMM on the same guarded arrays
+        k = 5
+        X = rng.uniform(-1, 1, (cols, k)).astype(dtype)
+        Xv, _ = _guarded(dev(X).reshape(-1), float("nan"))
+        Yv, Ybuf = _guarded(torch.zeros(rows * k, dtype=tdt, device="cuda"), 12345.0)
+        M.csrmm(val, off, col, Xv.view(cols, k), Y=Yv.view(rows, k))
+        torch.cuda.synchronize()
+        assert not torch.isnan(Yv).any()
+        _check_csrmm(M, csr, X, Yv.view(rows, k).cpu().numpy())
+        assert bool((Ybuf[:64] == 12345.0).all()) and bool((Ybuf[-64:] == 12345.0).all())
