@@ -27,7 +27,8 @@ def random_lens(rng, rows):
 
 def offset_view(t, off):
     """a view whose data pointer is `off` elements past an aligned allocation"""
-    buf = torch.empty(t.numel() + 8, dtype=t.dtype, device=t.device)
+    # surroundings: NaN for floating-point arrays (anything read from there and used shows in the result), 0 for indices
+    buf = torch.full((t.numel() + 8,), float("nan") if t.is_floating_point() else 0, dtype=t.dtype, device=t.device)
     v = buf[off: off + t.numel()]
     v.copy_(t)
     return v
