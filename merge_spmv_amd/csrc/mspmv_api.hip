@@ -50,9 +50,13 @@ static Shape pick_shape(int value_bytes, long long items, int &flags)
     if (t.block.load() > 0) return Shape{t.block.load(), t.ipt.load()};
     static const int ipts32[] = {7, 9, 11, 15}, ipts64[] = {5, 7, 9, 11};
     const int *ipts = value_bytes == 8 ? ipts64 : ipts32;
-    if (!(flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED)))
+    if (!(flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED))) {
+        // a problem that fits ONE compiled tile needs no carry fix-up: one launch (~7 us) instead of two (~13 us)
+        for (int i = 0; i < 4; ++i)
+            if (items <= 256LL * ipts[i]) return Shape{256, ipts[i]};
         for (int i = 0; i < 4; ++i)
             if ((items + 256LL * ipts[i] - 1) / (256LL * ipts[i]) <= FUSED_MAX_TILES) return Shape{256, ipts[i]};
+    }
     return Shape{256, 11};
 }
 
