@@ -580,3 +580,35 @@ def test_nothing_outside_the_arrays_is_used_or_written(M, prec, flags):
         assert not torch.isnan(Yv).any()
         _check_csrmm(M, csr, X, Yv.view(rows, k).cpu().numpy())
         assert bool((Ybuf[:64] == 12345.0).all()) and bool((Ybuf[-64:] == 12345.0).all())
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("flags", [0, 16, 4])
+def test_nan_and_inf_stay_in_their_rows(M, prec, flags):
+    """Non-finite products must poison exactly the rows they belong to: every cross-thread / cross-tile
+    combination selects instead of multiplying by zero (a NaN * 0 would leak into the neighbours)."""
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(17)
+    rows = 30000
+    lens = rng.integers(0, 12, rows); lens[500] = 9000; lens[20000] = 40000
+    csr = random_csr(rng, rows, 5000, lens, dtype)
+    x = rng.uniform(-1, 1, 5000).astype(dtype)
+    bad_rows = [3, 500, 777, 20000, rows - 1]
+    vals = csr.values.copy()
+    off = csr.row_offsets
+    for i, r in enumerate(bad_rows):
+        if off[r + 1] > off[r]:
+            vals[off[r] + (off[r + 1] - off[r]) // 2] = np.nan if i % 2 == 0 else np.inf
+    poisoned = O.Csr(csr.rows, csr.cols, csr.row_offsets, csr.column_indices, vals)
+    try:
+        M.set_tuning(vb, 0, 0, flags)
+        y_clean, _ = run_gpu(M, csr, x)
+        y_bad, _ = run_gpu(M, poisoned, x)
+    finally:
+        M.set_tuning(vb)
+    touched = np.zeros(rows, bool)
+    for r in bad_rows:
+        if off[r + 1] > off[r]:
+            touched[r] = True
+            assert not np.isfinite(y_bad[r]), r
+    assert np.array_equal(y_bad[~touched], y_clean[~touched])          # bit for bit
