@@ -29,7 +29,8 @@
  * Deliberate differences (the reference's out-of-bounds habits, SURVEY.md
  * Appendix B, are NOT inherited): nothing outside [0,rows] of d_row_offsets,
  * [0,nnz) of values/columns, [0,cols) of x or [0,rows) of y is touched.
- * Requires rows >= 0, cols >= 0, nnz >= 0 and rows + nnz < 2^31.
+ * Requires rows >= 0, cols >= 0, nnz >= 0 and rows + nnz <= 2^31 - 65537 (int32 path
+ * arithmetic with one tile of slack).
  */
 #ifndef MSPMV_H_
 #define MSPMV_H_
@@ -152,30 +153,22 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
                            int32_t *h_carry_keys, void *h_carry_values,
                            mspmv_stream_t stream);
 
-/* Tuning override for experiments (process-global; 0 = library default):
- * selects one of the compiled tile shapes for value_bytes.  Returns 0, or
- * hipErrorInvalidValue if that shape was not compiled in. */
-#define MSPMV_TUNE_XCD_REMAP  1   /* one contiguous tile range per XCD instead of round-robin (slower on skewed matrices) */
+/* Tuning override for experiments (process-global atomics; 0 = library default): selects one of the
+ * compiled tile shapes for value_bytes and/or the option bits below.  Returns 0, or
+ * hipErrorInvalidValue if that shape was not compiled in or a bit is not one of these.  Every
+ * combination accepted here computes correct results; kernels that exist only for timing
+ * experiments are not part of this library (they live in the -DMSPMV_DEV build, include/mspmv_dev.h). */
 #define MSPMV_TUNE_ATOMIC_FIX 2   /* single-launch atomicAdd fix-up (non-deterministic) */
-#define MSPMV_TUNE_NO_VEC     4   /* force the one-block-per-tile dword-per-lane kernel (the path taken for unaligned arrays) */
+#define MSPMV_TUNE_NO_VEC     4   /* force the dword-per-lane kernel with the reference's per-thread path walk (the path taken for unaligned arrays) */
 #define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by per-boundary wave search instead of the one-pass scatter */
 #define MSPMV_TUNE_NO_FUSED   16  /* never use the single-launch small-problem kernel */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
 #define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
 #define MSPMV_TUNE_MULTILEVEL_FIX 128 /* carry fix-up in two/three chunked levels (one launch each) instead of the one-launch owner-computes kernel */
-/* The vectorised tile kernel runs one tile per block by default.  Its persistent form (a block walks
- * several tiles and prefetches the next tile's nonzeros) is selected by either of
- *   bits  8..15: resident blocks per CU (grid = that x CUs), or
- *   bits 20..23: tiles per block (grid = tiles / that, at least the resident count).
- * bits 16..18 select development builds of the kernel: 1 = staging only (WRONG results, timing
- * ablation), 6 = per-phase cycle stamps written to the buffer given to mspmv_dev_set_trace,
- * 7 = the reference's per-thread merge-path walk inside the tile instead of flags + segmented scan. */
+/* bits 24..27: block -> tile mapping of the tile kernel: 0 = default (runs of 64 consecutive tiles per XCD),
+ * 15 = plain round-robin, else log2 of the run length. */
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
-
-/* Development: device buffer (16 x 8 uint64 per block) receiving the clock64() stamps of the
- * "6" build above (tools/trace_tiles.py); NULL turns it off. */
-int mspmv_dev_set_trace(void *d_buf);
 
 /* Opt-in per-kernel timing with hipEvents recorded on the caller's stream
  * around each of the three passes (the counterpart of the reference's
@@ -183,7 +176,9 @@ int mspmv_dev_set_trace(void *d_buf);
  * csrmv call (up to max_calls) records 4 events; mspmv_profile_end
  * synchronises them, returns the number of profiled calls and the AVERAGE
  * milliseconds per call of the search, tile and fix-up passes, and turns
- * profiling off.  Process-global; not for concurrent host threads. */
+ * profiling off.  Process-global measuring aid for ONE host thread (a mutex
+ * keeps concurrent callers from corrupting it, nothing more); calls that only
+ * run the coordinate pass (mspmv_csrmv_prepare) and SpMM calls are not recorded. */
 int mspmv_profile_begin(int32_t max_calls);
 int mspmv_profile_end(int32_t *calls, float *search_ms, float *tile_ms, float *fixup_ms);
 
@@ -210,11 +205,14 @@ int mspmv_mg_local_offsets(const int64_t *h_row_offsets, int64_t rows,
                            int64_t nz_begin, int64_t nz_end_,
                            int32_t *h_local_offsets);
 
+#define MSPMV_MG_MAX_PARTS 64   /* parts a carry exchange can address (one mask bit each) */
+
 /* After the one exchange (all-gather of every part's carry value into
  * d_carries[parts]): add to d_y_local[0] every carry of parts j < part whose
  * key row_split[j+1] equals row_split[part] ... i.e. the rows this part owns
  * that were begun earlier.  keys are given by the HOST array row_split.
- * Deterministic (rank order).  value_bytes = 4 or 8. */
+ * Deterministic (rank order).  value_bytes = 4 or 8.  parts <= MSPMV_MG_MAX_PARTS
+ * (mspmv_mg_partition itself has no such limit). */
 int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries,
                            const int64_t *row_split, int32_t parts,
                            int32_t part, int32_t value_bytes,

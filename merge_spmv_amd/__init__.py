@@ -19,13 +19,12 @@ from typing import Optional, Tuple
 
 __all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "library_path", "load_library", "launch_info",
            "set_tuning", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
-           "TUNE_XCD_REMAP", "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
+           "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libmspmv.so"
 _lib: Optional[ctypes.CDLL] = None
 
-TUNE_XCD_REMAP = 1
 TUNE_ATOMIC_FIX = 2
 TUNE_NO_VEC = 4
 
@@ -35,7 +34,9 @@ class MspmvError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    """libmspmv.so next to this file; MSPMV_LIB=<path> selects another build of the same ABI
+    (the -DMSPMV_DEV library the tuning tools use)."""
+    return os.environ.get("MSPMV_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 class _LaunchInfo(ctypes.Structure):
@@ -137,6 +138,50 @@ def _stream_handle(stream) -> ctypes.c_void_p:
     return ctypes.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
 
 
+def _validate(values, row_offsets, column_indices, x, y, rows: int, cols: int, nnz: int, what: str,
+              x_rows: Optional[int] = None) -> None:
+    """The checks the C ABI cannot make (it sees raw pointers): every csrmv / csrmm / DeviceSpmv.CsrMV
+    call goes through here, so a wrong dtype, device, stride or length is an MspmvError instead of
+    a reinterpretation of memory.  x / y may be 1-D (CsrMV) or 2-D row-major (SpMM)."""
+    import torch
+    dev = y.device if y is not None else values.device
+    if dev.type != "cuda":
+        raise MspmvError(f"{what} needs CUDA (HIP) tensors: the merge-path kernels only run on the GPU")
+    if y is None or y.dtype not in (torch.float32, torch.float64):
+        raise MspmvError(f"{what}: y must be a float32 or float64 tensor (gpu_spmv.cu:730,734)")
+    if rows < 0 or cols < 0 or nnz < 0:
+        raise MspmvError(f"{what}: negative size")
+    for t, name, need in ((row_offsets, "row_offsets", rows + 1), (column_indices, "column_indices", nnz)):
+        if need == 0 and (t is None or t.numel() == 0):
+            continue
+        if t is None or t.dtype != torch.int32:
+            raise MspmvError(f"{what}: {name} must be int32 (OffsetT=int, gpu_spmv.cu:730,734), got {None if t is None else t.dtype}")
+        if t.device != dev or not t.is_contiguous() or t.numel() < need:
+            raise MspmvError(f"{what}: {name} must be a contiguous tensor on {dev} with at least {need} entries")
+    if nnz > 0:
+        if values is None or values.dtype != y.dtype or values.device != dev or not values.is_contiguous() or values.numel() < nnz:
+            raise MspmvError(f"{what}: values must be a contiguous {y.dtype} tensor on {dev} with at least {nnz} entries")
+    for t, name, need in ((x, "x", cols if x_rows is None else x_rows), (y, "y", rows)):
+        if t is None:
+            if need == 0 or (name == "x" and nnz == 0):
+                continue
+            raise MspmvError(f"{what}: {name} is missing")
+        if t.dtype != y.dtype or t.device != dev:
+            raise MspmvError(f"{what}: {name} must be {y.dtype} on {dev}, got {t.dtype} on {t.device}")
+        if t.dim() == 1:
+            if t.numel() > 1 and t.stride(0) != 1:
+                raise MspmvError(f"{what}: {name} must have unit stride")
+            if t.numel() < need and not (name == "x" and nnz == 0):
+                raise MspmvError(f"{what}: {name} has {t.numel()} entries, needs {need}")
+        elif t.dim() == 2:
+            if t.shape[1] > 1 and t.stride(1) != 1:
+                raise MspmvError(f"{what}: {name} must be row-major (unit stride along the right-hand-side index)")
+            if t.shape[0] < need and not (name == "x" and nnz == 0):
+                raise MspmvError(f"{what}: {name} has {t.shape[0]} rows, needs {need}")
+        else:
+            raise MspmvError(f"{what}: {name} must be 1-D or 2-D")
+
+
 class DeviceSpmv:
     """Mirror of ``cub::DeviceSpmv`` (reference cub/device/device_spmv.cuh:70-170)."""
 
@@ -152,7 +197,8 @@ class DeviceSpmv:
         at least the queried size.  All d_* arguments are CUDA tensors (int32
         offsets/indices, float32|float64 values/x/y).  ``alpha``/``beta`` select the
         y = alpha*A*x + beta*y extension (mspmv_csrmv_axpby_*); leave None for the
-        reference semantics.
+        reference semantics.  Wrong dtypes / devices / strides / lengths raise MspmvError
+        before anything reaches the library.
         """
         lib = load_library()
         vb = _value_bytes(d_vector_y)
@@ -160,6 +206,10 @@ class DeviceSpmv:
         if d_temp_storage is None:
             temp_ptr = ctypes.c_void_p(0)
         else:
+            _validate(d_values, d_row_offsets, d_column_indices, d_vector_x, d_vector_y, int(num_rows), int(num_cols),
+                      int(num_nonzeros), "DeviceSpmv.CsrMV")
+            if not d_temp_storage.is_cuda or not d_temp_storage.is_contiguous():
+                raise MspmvError("DeviceSpmv.CsrMV: d_temp_storage must be a contiguous CUDA tensor")
             size = ctypes.c_size_t(min(int(temp_storage_bytes), d_temp_storage.numel() * d_temp_storage.element_size()))
             temp_ptr = ctypes.c_void_p(d_temp_storage.data_ptr())
         args = [temp_ptr, ctypes.byref(size), _ptr(d_values), _ptr(d_row_offsets), _ptr(d_column_indices),
@@ -184,20 +234,32 @@ class CsrMVWorkspace:
         import torch
         self.rows, self.nnz, self.dtype = int(num_rows), int(num_nonzeros), dtype
         probe = torch.empty(0, dtype=dtype)
-        info = launch_info(self.rows, self.nnz, _value_bytes(probe))
+        self.value_bytes = _value_bytes(probe)
+        info = launch_info(self.rows, self.nnz, self.value_bytes)
         self.bytes = int(info["temp_bytes"])
         self.buffer = torch.empty(self.bytes, dtype=torch.uint8, device=device)
-        self.prepared_for = None
+        self.prepared_for = None        # the row_offsets TENSOR the coordinates in `buffer` belong to
+        self.prepared_info = None       # launch_info at prepare time (tile shape / flags / tile count)
 
     def prepare(self, row_offsets, stream=None):
         """Run the tile-coordinate pass once for this matrix (mspmv_csrmv_prepare); later
-        ``csrmv(..., workspace=ws)`` calls with the same row_offsets tensor skip it."""
+        ``csrmv(..., workspace=ws)`` calls with the SAME row_offsets tensor (identity, not address)
+        and unchanged tuning skip it."""
+        import torch
+        if row_offsets.dtype != torch.int32 or not row_offsets.is_cuda or not row_offsets.is_contiguous() or \
+                row_offsets.numel() < self.rows + 1:
+            raise MspmvError("prepare: row_offsets must be a contiguous int32 CUDA tensor with rows + 1 entries")
         size = ctypes.c_size_t(self.bytes)
         _check(load_library().mspmv_csrmv_prepare(ctypes.c_void_p(self.buffer.data_ptr()), ctypes.byref(size), _ptr(row_offsets),
-                                                  self.rows, self.nnz, _value_bytes(self.buffer.new_empty(0, dtype=self.dtype)),
+                                                  self.rows, self.nnz, self.value_bytes,
                                                   _stream_handle(stream), 0), "mspmv_csrmv_prepare")
-        self.prepared_for = (row_offsets.data_ptr(), self.rows, self.nnz)
+        self.prepared_for = row_offsets           # keeps the tensor alive: its address cannot be recycled
+        self.prepared_info = launch_info(self.rows, self.nnz, self.value_bytes)
         return self
+
+    def is_prepared_for(self, row_offsets, rows: int, nnz: int, dtype) -> bool:
+        return (self.prepared_for is row_offsets and rows == self.rows and nnz == self.nnz and dtype == self.dtype and
+                self.prepared_info == launch_info(rows, nnz, self.value_bytes))
 
 
 def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int] = None,
@@ -208,9 +270,6 @@ def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int
     import torch
     if not values.is_cuda or not row_offsets.is_cuda or not x.is_cuda:
         raise MspmvError("csrmv needs CUDA (HIP) tensors: the merge-path kernels only run on the GPU")
-    for t, name in ((values, "values"), (row_offsets, "row_offsets"), (column_indices, "column_indices"), (x, "x")):
-        if not t.is_contiguous():
-            raise MspmvError(f"{name} must be contiguous")
     if row_offsets.dtype != torch.int32 or column_indices.dtype != torch.int32:
         raise TypeError("row_offsets/column_indices must be int32 (OffsetT=int, gpu_spmv.cu:730,734)")
     rows = row_offsets.numel() - 1
@@ -218,9 +277,12 @@ def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int
     cols = int(num_cols) if num_cols is not None else x.numel()
     if y is None:
         y = torch.empty(rows, dtype=values.dtype, device=values.device)
+    _validate(values, row_offsets, column_indices, x, y, rows, cols, nnz, "csrmv")
     if workspace is None:
         workspace = CsrMVWorkspace(rows, nnz, values.dtype, device=values.device)
-    if workspace.prepared_for == (row_offsets.data_ptr(), rows, nnz):
+    elif workspace.rows != rows or workspace.nnz != nnz or workspace.dtype != values.dtype:
+        raise MspmvError("csrmv: the workspace was sized for another matrix shape or precision")
+    if workspace.is_prepared_for(row_offsets, rows, nnz, values.dtype):
         # coordinates already in the workspace (CsrMVWorkspace.prepare): mspmv_csrmv_prepared_*
         vb = _value_bytes(values)
         fn = load_library().mspmv_csrmv_prepared_f32 if vb == 4 else load_library().mspmv_csrmv_prepared_f64
@@ -245,18 +307,21 @@ def csrmm(values, row_offsets, column_indices, X, Y=None, alpha: float = 1.0, be
     import torch
     if not values.is_cuda or not X.is_cuda:
         raise MspmvError("csrmm needs CUDA (HIP) tensors: the merge-path kernels only run on the GPU")
-    if X.dim() != 2 or X.stride(1) != 1:
+    if X.dim() != 2 or (X.shape[1] > 1 and X.stride(1) != 1):
         raise MspmvError("X must be 2-D with unit stride along the right-hand-side index (row-major)")
     rows, nnz, k = row_offsets.numel() - 1, values.numel(), X.shape[1]
     if Y is None:
         Y = torch.empty(rows, k, dtype=values.dtype, device=values.device)
-    if Y.dim() != 2 or Y.stride(1) != 1 or Y.shape != (rows, k):
+    if Y.dim() != 2 or (k > 1 and Y.stride(1) != 1) or Y.shape != (rows, k):
         raise MspmvError("Y must be a row-major [rows, k] tensor")
+    _validate(values, row_offsets, column_indices, X, Y, rows, X.shape[0], nnz, "csrmm")
     vb = _value_bytes(values)
     fn = load_library().mspmv_csrmm_f32 if vb == 4 else load_library().mspmv_csrmm_f64
     ct = ctypes.c_float if vb == 4 else ctypes.c_double
     ldx = X.stride(0) if X.shape[0] > 1 else max(k, 1)
     ldy = Y.stride(0) if Y.shape[0] > 1 else max(k, 1)
+    if ldx < k or ldy < k:
+        raise MspmvError("csrmm: leading dimensions must be at least k (no overlapping / broadcast rows)")
     def call(tmp_ptr, size):
         return int(fn(tmp_ptr, ctypes.byref(size), _ptr(values), _ptr(row_offsets), _ptr(column_indices), _ptr(X), int(ldx),
                       _ptr(Y), int(ldy), rows, X.shape[0], nnz, k, ct(alpha), ct(beta), _stream_handle(stream),

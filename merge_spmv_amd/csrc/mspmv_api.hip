@@ -11,9 +11,11 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mspmv.h"
+#include "mspmv_internal.hpp"
 #include "mspmv_kernels.hpp"
 #include "mspmv_spmm.hpp"
 
@@ -27,7 +29,7 @@ constexpr int FIX_IPT = 2;              // little serial work per thread: the fi
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 constexpr int FUSED_MAX_TILES = 2048;            // up to here: tiles search their own coordinates (one launch less)
 
-static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
+static_assert(TILE_MAP_CONTIGUOUS_CODE == TILE_MAP_CONTIGUOUS, "mapping code shared with the kernels");
 
 // Tile shapes compiled in (selectable with mspmv_set_tuning; defaults: pick_shape).
 struct Shape { int block, ipt; };
@@ -113,14 +115,22 @@ static int device_cus()
     return v;
 }
 
-// opt-in per-kernel event timing (mspmv_profile_begin/_end)
+// opt-in per-kernel event timing (mspmv_profile_begin/_end).  Process-global and meant for ONE
+// measuring host thread (mspmv.h says so); the mutex only keeps concurrent callers from corrupting it.
 struct Profiler {
     std::vector<hipEvent_t> events;   // 4 per profiled call
     int capacity = 0, calls = 0;
     bool active = false;
+    std::mutex lock;
 };
 static Profiler g_prof;
 
+static inline int prof_take_slot()
+{
+    if (!g_prof.active) return -1;
+    std::lock_guard<std::mutex> g(g_prof.lock);
+    return (g_prof.active && g_prof.calls < g_prof.capacity) ? g_prof.calls++ : -1;
+}
 static inline void prof_mark(hipStream_t stream, int slot, int which)
 {
     if (slot >= 0) (void) hipEventRecord(g_prof.events[size_t(slot) * 4 + which], stream);
@@ -139,20 +149,62 @@ static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *n
     return e;
 }
 
-// phase: what a call does -- everything (the reference's stateless call), only the tile-coordinate
-// pass (mspmv_csrmv_prepare), or everything but it (mspmv_csrmv_prepared_*: the coordinates in d_temp
-// depend on row_offsets alone and are reused across the SpMVs of a solver)
-enum { PHASE_ALL = 0, PHASE_COORDS_ONLY = 1, PHASE_SKIP_COORDS = 2 };
+#ifdef MSPMV_DEV
+// ---- development variants of the tile kernel (libmspmv_dev.so only; `make -C merge_spmv_amd dev`) ----
+// tuning bits, all rejected by the product library:
+//   bit 0        one contiguous tile range per XCD, persistent form (the old XCD_REMAP experiment)
+//   bits  8..15  persistent form: resident blocks per CU (grid = that x CUs)
+//   bits 20..23  persistent form: tiles per block
+//   bits 16..18  1 = staging only (WRONG results, timing ablation), 6 = per-phase cycle stamps written to the
+//                buffer given to mspmv_dev_set_trace, 7 = the reference's per-thread merge-path walk in the tile
+constexpr int MSPMV_DEV_FLAG_BITS = 1 | 0xff00 | 0x70000 | 0xf00000;
+template <typename V, int BLOCK, int IPT>
+static bool launch_dev_variant(const Layout &L, const Params<V> &p, bool axpby, bool nt, const Coord *coords, Carry<V> *carries,
+                               int chunk_log2, hipStream_t stream)
+{
+    const int forced = (L.flags >> 8) & 0xff;
+    const int tpb_flag = (L.flags >> 20) & 0xf;
+    const int tpb = tpb_flag ? tpb_flag : 1;
+    const bool remap = !axpby && (L.flags & 1) != 0;
+    const int ablate = axpby ? 0 : (L.flags >> 16) & 7;
+    if (!(tpb_flag || forced || remap || ablate)) return false;
+#define MSPMV_LAUNCH_P(...)                                                                                        \
+    do {                                                                                                   \
+        auto kernel = tile_kernel_vec<V, BLOCK, IPT, __VA_ARGS__>;                                          \
+        static std::atomic<int> resident{0};      /* one per kernel variant */                              \
+        int per_cu = forced ? forced : resident.load(std::memory_order_relaxed);                            \
+        if (per_cu == 0) {                                                                                 \
+            int n = 0;                                                                                     \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n < 1) n = 4; \
+            per_cu = std::min(n, 2048 / BLOCK);                                                            \
+            resident.store(per_cu, std::memory_order_relaxed);                                             \
+        }                                                                                                  \
+        long long want = (long long) per_cu * device_cus();                                                \
+        if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
+        const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
+        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, chunk_log2);   \
+    } while (0)
+    if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
+    else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
+    else if (ablate == 7) MSPMV_LAUNCH_P(false, false, true, 7, true);
+    else if (remap) { if (nt) MSPMV_LAUNCH_P(false, true, true, 0, true); else MSPMV_LAUNCH_P(false, true, false, 0, true); }
+    else if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true, 0, true); else MSPMV_LAUNCH_P(true, false, false, 0, true); }
+    else if (nt) MSPMV_LAUNCH_P(false, false, true, 0, true);
+    else MSPMV_LAUNCH_P(false, false, false, 0, true);
+#undef MSPMV_LAUNCH_P
+    return true;
+}
+#endif
 
 template <typename V, int BLOCK, int IPT>
 static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, bool axpby, hipStream_t stream,
-                            int debug_sync, int phase)
+                            int debug_sync, const CallExtra &ex)
 {
     char *base = static_cast<char *>(d_temp);
     Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off);
     Carry<V> *carries = reinterpret_cast<Carry<V> *>(base + L.carries_off);
     const int tile_items = BLOCK * IPT;
-    const int slot = (g_prof.active && g_prof.calls < g_prof.capacity) ? g_prof.calls++ : -1;
+    int phase = ex.phase;
 
     // 16-byte streaming needs 16-byte aligned array bases (hipMalloc gives 256) and at
     // least one full 4-element chunk in each array
@@ -162,6 +214,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     const bool fused = L.fused && vec;
     if (phase == PHASE_COORDS_ONLY && L.fused) return hipSuccess;      // those tiles search their own coordinates
     if (phase == PHASE_SKIP_COORDS && L.fused && !vec) phase = PHASE_ALL;   // (unaligned arrays: nothing was prepared)
+    // a profiler slot is taken only by calls that run all the passes it brackets
+    const int slot = phase == PHASE_COORDS_ONLY ? -1 : prof_take_slot();
     if (fused) {
         // small problems: the tiles search their own coordinates (no coordinate pass)
         prof_mark(stream, slot, 0);
@@ -200,67 +254,32 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     prof_mark(stream, slot, 1);
     {
         const unsigned grid = (unsigned) L.num_tiles;
-        const bool remap = !axpby && (L.flags & MSPMV_TUNE_XCD_REMAP) != 0;   // (experiment: plain y = A*x only)
         if (vec) {
-            // Default: one tile per block, the hardware's block scheduler does the load balancing.
-            // The same kernel also runs "persistent" -- a block walks tiles b, b + grid, ... and
-            // requests the next tile's nonzeros before the LDS phases of the current one (tuning
-            // flags: tiles per block in bits 20-23, or blocks per CU in bits 8-15).  That form won
-            // 10-20 % while the in-tile reduction was the reference's per-thread path walk; with the
-            // flag/segmented-scan reduction a resident grid is 7-10 % SLOWER on streaming matrices
-            // (the blocks of a CU march through load bursts and LDS phases together, and the prefetch
-            // registers cost a wave of occupancy), and 2-4 tiles per block are within +-3 % of one.
-            const int forced = (L.flags >> 8) & 0xff;
-            const int tpb_flag = (L.flags >> 20) & 0xf;
-            // XCD-chunked block -> tile mapping of the one-tile-per-block launch (tile_kernel_vec): runs of
-            // 2^6 consecutive tiles per XCD.  Measured against plain round-robin: grid2d -19 %, C4 -7 %,
-            // dense32 -5 %, band5 -3 %, nothing slower (16 and 256 are within 1-2 % of 64).  Tuning bits
-            // 24-27: 0 = default, 15 = off, else log2 of the run length.
+            // One tile per block: the hardware's block scheduler balances the load and de-phases the
+            // blocks of a CU.  (A persistent, software-prefetching form of the same kernel exists in
+            // the -DMSPMV_DEV build; with the flag/segmented-scan reduction it measured 7-10 % slower
+            // on streaming matrices)
+            // XCD-chunked block -> tile mapping: runs of 2^6 consecutive tiles per XCD.  Measured against
+            // plain round-robin: grid2d -19 %, C4 -7 %, dense32 -5 %, band5 -3 %, nothing slower (16 and
+            // 256 are within 1-2 % of 64).  Tuning bits 24-27: 0 = default, 15 = off, else log2 of the
+            // run length.  Prepared band-major plans ask for one contiguous tile range per XCD instead.
             const int chunk_flag = (L.flags >> 24) & 0xf;
-            const int chunk_log2 = chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
-            const int tpb = tpb_flag ? tpb_flag : 1;
-            const int ablate = axpby ? 0 : (L.flags >> 16) & 7;   // development builds of the kernel (plain y = A*x only)
-#define MSPMV_LAUNCH_P(...)                                                                                        \
-            do {                                                                                                   \
-                auto kernel = tile_kernel_vec<V, BLOCK, IPT, __VA_ARGS__>;                                  \
-                if (!persist) {                                                                                    \
-                    hipLaunchKernelGGL(kernel, dim3((unsigned) L.num_tiles), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, chunk_log2); \
-                    break;                                                                                         \
-                }                                                                                                  \
-                static std::atomic<int> resident{0};      /* one per kernel variant */                              \
-                int per_cu = forced ? forced : resident.load(std::memory_order_relaxed);                            \
-                if (per_cu == 0) {                                                                                 \
-                    int n = 0;                                                                                     \
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, BLOCK, 0) != hipSuccess || n < 1) n = 4; \
-                    per_cu = std::min(n, 2048 / BLOCK);                                                            \
-                    resident.store(per_cu, std::memory_order_relaxed);                                             \
-                }                                                                                                  \
-                long long want = (long long) per_cu * device_cus();                                                \
-                if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
-                const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
-                hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, chunk_log2);   \
-            } while (0)
+            const int chunk_log2 = ex.tile_map ? ex.tile_map : chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
             // CSR streams: ordinary loads while the matrix fits the 256 MB Infinity Cache (it then
             // stays there between the SpMVs of a solver), non-temporal loads beyond (they keep x in L2)
             const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
             const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (200ull << 20));
-            // development variants (always the persistent form): 1 = staging only (wrong results),
-            // 6 = cycle stamps (tools/trace_tiles.py), 7 = the per-thread path walk of the reference
-            bool persist = tpb_flag != 0 || forced != 0 || remap || ablate != 0;
-            if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
-            else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
-            else if (ablate == 7) MSPMV_LAUNCH_P(false, false, true, 7, true);
-            else if (remap) { if (nt) MSPMV_LAUNCH_P(false, true, true, 0, true); else MSPMV_LAUNCH_P(false, true, false, 0, true); }
-            else if (persist) {
-                if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true, 0, true); else MSPMV_LAUNCH_P(true, false, false, 0, true); }
-                else if (nt) MSPMV_LAUNCH_P(false, false, true, 0, true);
-                else MSPMV_LAUNCH_P(false, false, false, 0, true);
-            } else {
-                if (axpby) { if (nt) MSPMV_LAUNCH_P(true, false, true, 0, false); else MSPMV_LAUNCH_P(true, false, false, 0, false); }
-                else if (nt) MSPMV_LAUNCH_P(false, false, true, 0, false);
-                else MSPMV_LAUNCH_P(false, false, false, 0, false);
+            bool launched = false;
+#ifdef MSPMV_DEV
+            launched = launch_dev_variant<V, BLOCK, IPT>(L, p, axpby, nt, coords, carries, chunk_log2, stream);
+#endif
+#define MSPMV_LAUNCH(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, chunk_log2)
+            if (!launched) {
+                if (axpby) { if (nt) MSPMV_LAUNCH(true, true); else MSPMV_LAUNCH(true, false); }
+                else if (nt) MSPMV_LAUNCH(false, true);
+                else MSPMV_LAUNCH(false, false);
             }
-#undef MSPMV_LAUNCH_P
+#undef MSPMV_LAUNCH
         } else {
             if (axpby) hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, true>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
             else       hipLaunchKernelGGL((tile_kernel<V, BLOCK, IPT, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles);
@@ -300,14 +319,14 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
 
 template <typename V>
 static hipError_t dispatch_shape(const Layout &L, void *d_temp, const Params<V> &p, bool axpby, hipStream_t stream,
-                                 int debug_sync, int phase);
+                                 int debug_sync, const CallExtra &ex);
 
 #define MSPMV_SHAPE_CASE(V, B, I) \
-    if (L.shape.block == B && L.shape.ipt == I) return run_shape<V, B, I>(L, d_temp, p, axpby, stream, debug_sync, phase);
+    if (L.shape.block == B && L.shape.ipt == I) return run_shape<V, B, I>(L, d_temp, p, axpby, stream, debug_sync, ex);
 
 template <>
 hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<float> &p, bool axpby, hipStream_t stream,
-                                 int debug_sync, int phase)
+                                 int debug_sync, const CallExtra &ex)
 {
     MSPMV_SHAPE_CASE(float, 256, 7)
     MSPMV_SHAPE_CASE(float, 256, 5)
@@ -321,7 +340,7 @@ hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<flo
 
 template <>
 hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<double> &p, bool axpby,
-                                  hipStream_t stream, int debug_sync, int phase)
+                                  hipStream_t stream, int debug_sync, const CallExtra &ex)
 {
     MSPMV_SHAPE_CASE(double, 256, 5)
     MSPMV_SHAPE_CASE(double, 256, 3)
@@ -334,12 +353,12 @@ hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<do
 }
 
 template <typename V>
-static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets,
-                      const int32_t *d_cols, const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha,
-                      V beta, bool axpby, mspmv_stream_t stream_, int debug_sync, int phase = PHASE_ALL)
+int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets, const int32_t *d_cols,
+               const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha, V beta, bool axpby,
+               hipStream_t stream, int debug_sync, const CallExtra &ex)
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
-    if ((long long) rows + nnz > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((long long) rows + nnz > MAX_ITEMS) return hipErrorInvalidValue;
     const Layout L = make_layout(rows, nnz, (int) sizeof(V));
     if (d_temp == nullptr) {                      // size query (dispatch_spmv_orig.cuh:651-655)
         *temp_bytes = (size_t) L.total;
@@ -347,13 +366,28 @@ static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const
     }
     if (*temp_bytes < L.total) return hipErrorInvalidValue;   // util_device.cuh:90-93
     if (rows == 0) return hipSuccess;             // nothing to write
-    if (phase == PHASE_COORDS_ONLY) { if (!d_row_offsets) return hipErrorInvalidValue; }
+    if (ex.phase == PHASE_COORDS_ONLY) { if (!d_row_offsets) return hipErrorInvalidValue; }
     else if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     Params<V> p;
     p.values = d_values; p.row_end = d_row_offsets + 1; p.cols = d_cols; p.x = d_x; p.y = d_y;
     p.rows = rows; p.nnz = nnz; p.alpha = alpha; p.beta = beta;
-    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, phase);
+    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, ex);
+}
+template int csrmv_call<float>(void *, size_t *, const float *, const int32_t *, const int32_t *, const float *, float *, int32_t,
+                               int32_t, int32_t, float, float, bool, hipStream_t, int, const CallExtra &);
+template int csrmv_call<double>(void *, size_t *, const double *, const int32_t *, const int32_t *, const double *, double *,
+                                int32_t, int32_t, int32_t, double, double, bool, hipStream_t, int, const CallExtra &);
+
+uint64_t csrmv_temp_bytes(int32_t rows, int32_t nnz, int32_t value_bytes) { return make_layout(rows, nnz, value_bytes).total; }
+
+template <typename V>
+static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets,
+                      const int32_t *d_cols, const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha,
+                      V beta, bool axpby, mspmv_stream_t stream_, int debug_sync, int phase = PHASE_ALL)
+{
+    CallExtra ex; ex.phase = phase;
+    return csrmv_call<V>(d_temp, temp_bytes, d_values, d_row_offsets, d_cols, d_x, d_y, rows, cols, nnz, alpha, beta, axpby,
+                         reinterpret_cast<hipStream_t>(stream_), debug_sync, ex);
 }
 
 // ---------------------------------------------------------------------------
@@ -472,7 +506,7 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
                       T beta, mspmv_stream_t stream_, int debug_sync)
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0 || k < 0 || ldx < k || ldy < k) return hipErrorInvalidValue;
-    if ((long long) rows + nnz > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((long long) rows + nnz > MAX_ITEMS) return hipErrorInvalidValue;
     const bool wide = (unsigned long long) cols * (unsigned long long) ldx * sizeof(T) > (1ull << 20);
     const MMLayout L = make_mm_layout<T>(rows, nnz, k, wide);
     if (d_temp == nullptr) { *temp_bytes = (size_t) L.total; return hipSuccess; }
@@ -613,7 +647,7 @@ int mspmv_csrmm_f64(void *d_temp, size_t *temp_bytes, const double *d_values, co
 int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)
 {
     if (!info || (value_bytes != 4 && value_bytes != 8) || rows < 0 || nnz < 0 ||
-        (long long) rows + nnz > 0x7fffffffLL)
+        (long long) rows + nnz > MAX_ITEMS)
         return hipErrorInvalidValue;
     const Layout L = make_layout(rows, nnz, value_bytes);
     memset(info, 0, sizeof(*info));
@@ -661,7 +695,12 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    if (flags & ~(MSPMV_TUNE_XCD_REMAP | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED | MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xff00 | 0x70000 | 0xf00000 | 0xf000000)) return hipErrorInvalidValue;
+    int allowed = MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
+                  MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xf000000;
+#ifdef MSPMV_DEV
+    allowed |= MSPMV_DEV_FLAG_BITS;        // development kernels (mspmv_dev.hpp): never in the product library
+#endif
+    if (flags & ~allowed) return hipErrorInvalidValue;
     Tuning &t = g_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)
@@ -675,7 +714,8 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
 int mspmv_profile_begin(int32_t max_calls)
 {
     if (max_calls < 1 || max_calls > (1 << 20)) return hipErrorInvalidValue;
-    for (hipEvent_t e : g_prof.events) (void) hipEventDestroy(e);
+    std::lock_guard<std::mutex> g(g_prof.lock);
+    for (hipEvent_t e : g_prof.events) if (e) (void) hipEventDestroy(e);
     g_prof.events.assign(size_t(max_calls) * 4, nullptr);
     for (auto &e : g_prof.events) MSPMV_CHECK(hipEventCreate(&e));
     g_prof.capacity = max_calls; g_prof.calls = 0; g_prof.active = true;
@@ -684,30 +724,33 @@ int mspmv_profile_begin(int32_t max_calls)
 
 int mspmv_profile_end(int32_t *calls, float *search_ms, float *tile_ms, float *fixup_ms)
 {
+    std::lock_guard<std::mutex> g(g_prof.lock);
     g_prof.active = false;
     double acc[3] = {0, 0, 0};
+    int n = 0;
+    hipError_t first_error = hipSuccess;
     for (int c = 0; c < g_prof.calls; ++c) {
-        MSPMV_CHECK(hipEventSynchronize(g_prof.events[size_t(c) * 4 + 3]));
-        for (int k = 0; k < 3; ++k) {
-            float ms = 0;
-            MSPMV_CHECK(hipEventElapsedTime(&ms, g_prof.events[size_t(c) * 4 + k], g_prof.events[size_t(c) * 4 + k + 1]));
-            acc[k] += ms;
-        }
+        // a slot whose four marks were not all recorded (a call that failed half way) is skipped
+        float ms[3]; bool ok = hipEventSynchronize(g_prof.events[size_t(c) * 4 + 3]) == hipSuccess;
+        for (int k = 0; k < 3 && ok; ++k)
+            ok = hipEventElapsedTime(&ms[k], g_prof.events[size_t(c) * 4 + k], g_prof.events[size_t(c) * 4 + k + 1]) == hipSuccess;
+        if (!ok) { (void) hipGetLastError(); continue; }
+        for (int k = 0; k < 3; ++k) acc[k] += ms[k];
+        ++n;
     }
-    const int n = g_prof.calls;
     if (calls) *calls = n;
     if (search_ms) *search_ms = n ? float(acc[0] / n) : 0.f;
     if (tile_ms) *tile_ms = n ? float(acc[1] / n) : 0.f;
     if (fixup_ms) *fixup_ms = n ? float(acc[2] / n) : 0.f;
-    for (hipEvent_t e : g_prof.events) (void) hipEventDestroy(e);
+    for (hipEvent_t e : g_prof.events) if (e) (void) hipEventDestroy(e);     // always cleaned up
     g_prof.events.clear(); g_prof.capacity = 0; g_prof.calls = 0;
-    return hipSuccess;
+    return first_error;
 }
 
 int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries, const int64_t *row_split, int32_t parts,
                            int32_t part, int32_t value_bytes, mspmv_stream_t stream_)
 {
-    if (!d_y_local || !d_carries || !row_split || parts < 1 || parts > 64 || part < 0 || part >= parts ||
+    if (!d_y_local || !d_carries || !row_split || parts < 1 || parts > MSPMV_MG_MAX_PARTS || part < 0 || part >= parts ||
         (value_bytes != 4 && value_bytes != 8))
         return hipErrorInvalidValue;
     // this part owns y for global rows [row_split[part], row_split[part+1]); a
@@ -730,9 +773,11 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries, const int64_t
 
 }  // extern "C"
 
+#ifdef MSPMV_DEV
 // development: where tile_kernel_vec<..., ABLATE = 6> writes its cycle stamps (device pointer, 16*8 u64 per block)
 extern "C" int mspmv_dev_set_trace(void *d_buf)
 {
     unsigned long long *ptr = static_cast<unsigned long long *>(d_buf);
     return (int) hipMemcpyToSymbol(HIP_SYMBOL(mspmv::g_mspmv_trace), &ptr, sizeof(ptr));
 }
+#endif

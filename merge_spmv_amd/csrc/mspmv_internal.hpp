@@ -1,0 +1,41 @@
+// mspmv_internal.hpp -- what the translation units of libmspmv.so share below the C ABI:
+// the dispatcher of mspmv_api.hip as a C++ function (the prepared band-major plan, mspmv_plan.hip,
+// and the multi-GPU plan, mspmv_mg_plan.hip, run the ordinary merge-path CsrMV on matrices they own).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mspmv.h"
+
+namespace mspmv {
+
+// what a call does -- everything (the reference's stateless call), only the tile-coordinate pass
+// (mspmv_csrmv_prepare), or everything but it (mspmv_csrmv_prepared_*: the coordinates in d_temp
+// depend on row_offsets alone and are reused across the SpMVs of a solver)
+enum { PHASE_ALL = 0, PHASE_COORDS_ONLY = 1, PHASE_SKIP_COORDS = 2 };
+
+struct CallExtra {
+    int phase = PHASE_ALL;
+    int tile_map = 0;       // 0: library default (XCD-chunked runs of 64 tiles); else the chunk_log2 code of
+                            // xcd_chunked_tile (TILE_MAP_CONTIGUOUS_CODE: one contiguous tile range per XCD)
+};
+constexpr int TILE_MAP_CONTIGUOUS_CODE = 30;
+
+// The dispatcher behind mspmv_csrmv_* / _axpby_* / _prepare / _prepared_*; same conventions
+// (two-phase temp storage, caller-owned buffers, asynchronous on `stream`).
+template <typename V>
+int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets, const int32_t *d_cols,
+               const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha, V beta, bool axpby,
+               hipStream_t stream, int debug_sync, const CallExtra &extra);
+
+// bytes of temp storage csrmv_call needs (what the size query returns)
+uint64_t csrmv_temp_bytes(int32_t rows, int32_t nnz, int32_t value_bytes);
+
+// largest rows + nnz one call accepts: 2^31 minus room for the chunk arithmetic of the
+// vectorised staging, which indexes up to one tile (+ one chunk row) past the last item in int32
+constexpr long long MAX_ITEMS = 0x7fffffffLL - 65536;
+
+static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
+
+}  // namespace mspmv

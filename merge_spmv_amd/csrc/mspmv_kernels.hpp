@@ -930,8 +930,16 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
 // blocks, XCD k takes G CONSECUTIVE tiles: neighbouring tiles gather neighbouring x (which then stays in
 // that XCD's private L2) and each XCD reads longer contiguous pieces of the CSR arrays, while the XCDs
 // still advance through the matrix together.  Bijective for any num_tiles; log2 G = 0 turns it off.
+constexpr int TILE_MAP_CONTIGUOUS = 30;       // chunk_log2 value selecting one contiguous tile range per XCD
 __device__ __forceinline__ int xcd_chunked_tile(int b, int num_tiles, int chunk_log2)
 {
+    if (chunk_log2 == TILE_MAP_CONTIGUOUS) {
+        // XCD k takes tiles [k*T/8, (k+1)*T/8): what the band-major prepared plan wants (each XCD's L2
+        // then only ever sees the x slice of the band(s) its range covers); bijective for any T
+        const int q = num_tiles / 8, r = num_tiles % 8;
+        const int xcd = b & 7, idx = b >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     if (chunk_log2 > 0) {
         const int G = 1 << chunk_log2, span = 8 * G;
         if (b < (num_tiles / span) * span) {
@@ -942,8 +950,10 @@ __device__ __forceinline__ int xcd_chunked_tile(int b, int num_tiles, int chunk_
     return b;
 }
 
+#ifdef MSPMV_DEV
 // development: per-phase cycle stamps of the first 16 tiles of every block (ABLATE == 6 variant)
 __device__ unsigned long long *g_mspmv_trace = nullptr;
+#endif
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
@@ -960,7 +970,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
     __shared__ V s_wave_val[NW];               // ABLATE 7 (development): the per-thread path walk instead
     constexpr bool TRACE = ABLATE == 6;
     int trace_iter = 0;
+#ifdef MSPMV_DEV
     unsigned long long *const trace = TRACE ? g_mspmv_trace : nullptr;
+#else
+    static_assert(ABLATE == 0 && !PERSIST && !XCD_REMAP, "development variants need -DMSPMV_DEV");
+    unsigned long long *const trace = nullptr;
+#endif
 #define MSPMV_TR(i) do { if (TRACE && trace && threadIdx.x == 0 && trace_iter < 16) trace[((size_t) blockIdx.x * 16 + trace_iter) * 8 + (i)] = clock64(); } while (0)
 
     const int tid = threadIdx.x;

@@ -22,53 +22,11 @@
 #include <vector>
 
 #include "driver_common.hpp"
+#include "merge_csrmv.hpp"
 
 using namespace mspmv_host;
 
 namespace {
-
-struct PathPoint { int row, nz; };
-
-// Diagonal search over row END offsets vs the natural numbers
-// (cpu_spmv.cpp:223-245): first row whose end offset exceeds diagonal - row - 1.
-inline PathPoint SearchDiagonal(int diagonal, const int *row_end, int rows, int nnz)
-{
-    int lo = std::max(diagonal - nnz, 0), hi = std::min(diagonal, rows);
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (row_end[mid] <= diagonal - mid - 1) lo = mid + 1; else hi = mid;
-    }
-    return PathPoint{std::min(lo, rows), diagonal - lo};
-}
-
-// y = A*x by merge-path decomposition over `segments` equal path segments
-// (OmpMergeCsrmv, cpu_spmv.cpp:292-353).  The association order depends on
-// `segments` only.
-template <typename V>
-void MergeCsrmv(int segments, int rows, int nnz, const int *row_end, const int *cols, const V *vals, const V *x, V *y,
-                std::vector<int> &carry_row, std::vector<V> &carry_val)
-{
-    carry_row.resize(segments); carry_val.resize(segments);
-    const long long total = (long long) rows + nnz;
-    const long long per_segment = (total + segments - 1) / segments;
-#pragma omp parallel for schedule(static) num_threads(segments)
-    for (int s = 0; s < segments; ++s) {
-        const int d0 = (int) std::min(per_segment * s, total);
-        const int d1 = (int) std::min((long long) d0 + per_segment, total);
-        PathPoint p = SearchDiagonal(d0, row_end, rows, nnz);
-        const PathPoint end = SearchDiagonal(d1, row_end, rows, nnz);
-        for (; p.row < end.row; ++p.row) {           // rows that end inside the segment
-            V sum = 0;
-            for (; p.nz < row_end[p.row]; ++p.nz) sum += vals[p.nz] * x[cols[p.nz]];
-            y[p.row] = sum;
-        }
-        V sum = 0;                                    // the row left open at the segment end
-        for (; p.nz < end.nz; ++p.nz) sum += vals[p.nz] * x[cols[p.nz]];
-        carry_row[s] = end.row; carry_val[s] = sum;
-    }
-    for (int s = 0; s + 1 < segments; ++s)            // cpu_spmv.cpp:348-352
-        if (carry_row[s] < rows) y[carry_row[s]] += carry_val[s];
-}
 
 template <typename V>
 void RowParallelCsrmv(int threads, int rows, const int *row_offsets, const int *cols, const V *vals, const V *x, V *y)

@@ -346,6 +346,8 @@ struct CsrMatrix {
         row_offsets.assign((size_t) num_rows + 1, 0);
         for (size_t k = 0; k < n; ++k) {
             if (coo.row[k] < 0 || coo.row[k] >= num_rows) throw MarketError("row index out of range");
+            // (the reference never checks: a column outside [0, num_cols) becomes an out-of-bounds gather of x)
+            if ((unsigned) coo.col[k] >= (unsigned) num_cols) throw MarketError("col index out of range");
             ++row_offsets[(size_t) coo.row[k] + 1];
         }
         for (int r = 0; r < num_rows; ++r) row_offsets[(size_t) r + 1] += row_offsets[r];

@@ -54,6 +54,10 @@ def test_size_query_two_phase_convention():
         assert st == 1
         st = fn(None, ctypes.byref(size), None, None, None, None, None, 2**30, 5, 2**30 + 5, None, 0)
         assert st == 1  # rows + nnz must stay below 2^31
+        st = fn(None, ctypes.byref(size), None, None, None, None, None, 1000, 5, 2**31 - 1 - 65536 - 1000 + 1, None, 0)
+        assert st == 1  # ... with one tile of slack for the int32 chunk arithmetic of the staging
+        st = fn(None, ctypes.byref(size), None, None, None, None, None, 1000, 5, 2**31 - 1 - 65536 - 1000, None, 0)
+        assert st == 0
 
 
 def test_tuning_rejects_unknown_shapes():
@@ -72,6 +76,15 @@ def test_tuning_rejects_unknown_shapes():
     assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 11
     with pytest.raises(M.MspmvError):
         M.set_tuning(4, 250, 7)
+    # the product library has no timing-experiment kernels: their flag bits (persistent grid, staging-only
+    # ablation that returns wrong y, cycle stamps, XCD remap; include/mspmv_dev.h) are rejected
+    for dev_bits in (1, 0x100, 0x10000, 0x60000, 0x70000, 0x100000):
+        with pytest.raises(M.MspmvError):
+            M.set_tuning(4, 0, 0, dev_bits)
+        with pytest.raises(M.MspmvError):
+            M.set_tuning(8, 256, 9, dev_bits | 16)
+    assert not hasattr(M.load_library(), "mspmv_dev_set_trace")
+    assert M.launch_info(10, 10, 4)["flags"] == 0
 
 
 @pytest.mark.parametrize("parts", [1, 2, 3, 4, 8])

@@ -136,19 +136,20 @@ SHAPES = {
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("path", ["single_launch", "multi_launch", "persistent", "reference_walk"])
+@pytest.mark.parametrize("path", ["single_launch", "multi_launch", "contiguous_map", "reference_walk"])
 def test_random_and_degenerate_shapes(M, shape, prec, path):
     """Every dispatch path on the same inputs: small problems take tile_kernel_fused (own coordinate
     search); MSPMV_TUNE_NO_FUSED forces the large-problem pipeline (coordinate pass + tile_kernel_vec,
-    one tile per block + fix-up launches); "persistent" = the same kernel walking 2 tiles per block
-    with prefetch; "reference_walk" = the per-thread merge-path walk inside the tile."""
+    one tile per block + fix-up launches); "contiguous_map" = the same with runs of 2^14 tiles per XCD (the
+    mapping family the prepared plan uses); "reference_walk" = the dword-per-lane kernel with the reference's
+    per-thread merge-path search + walk inside the tile (MSPMV_TUNE_NO_VEC)."""
     dtype, vb = DT[prec]
     rng = np.random.default_rng(sum(map(ord, shape)))
     rows, cols, lens = SHAPES[shape](rng)
     csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
     x = rng.uniform(-1, 1, size=cols).astype(dtype)
     try:
-        M.set_tuning(vb, 0, 0, {"single_launch": 0, "multi_launch": 16, "persistent": 0x200010, "reference_walk": 0x70010}[path])
+        M.set_tuning(vb, 0, 0, {"single_launch": 0, "multi_launch": 16, "contiguous_map": 0xE000010, "reference_walk": 4 | 16}[path])
         y, ws = run_gpu(M, csr, x)
         assert not np.isnan(y).any(), "a row was never written"
         check_strict(M, csr, x, y)
@@ -197,10 +198,10 @@ def test_all_ones_giant_row_is_exact(M):
 
 @pytest.mark.parametrize("vb,block,ipt", [(4, 256, 5), (4, 256, 9), (4, 256, 11), (4, 128, 7), (4, 512, 7), (4, 256, 15),
                                           (8, 256, 3), (8, 256, 7), (8, 256, 9), (8, 128, 5), (8, 512, 5), (8, 256, 11)])
-# 16 = no fused small-problem kernel (so the coordinate pass + tile kernel run), +1 XCD remap, +2 atomic fix-up,
-# +8 binary-search coordinate pass, 32/64 forced stream policy; 0x200000 = persistent form, 2 tiles per block;
-# 128 = multi-level fix-up (default: one launch); 0x300 = persistent form, 3 blocks per CU; 0x70000 = the reference's per-thread path walk inside the tile
-@pytest.mark.parametrize("flags", [0, 2, 4, 16, 17, 18, 24, 48, 80, 128, 144, 0x200010, 0x310, 0x70010])
+# 16 = no fused small-problem kernel (so the coordinate pass + tile kernel run), +2 atomic fix-up, 4 = dword-per-lane
+# kernel with the reference's in-tile walk, +8 binary-search coordinate pass, 32/64 forced stream policy,
+# 128 = multi-level fix-up (default: one launch); bits 24-27 = block->tile mapping (0xF: round-robin, 3: runs of 8)
+@pytest.mark.parametrize("flags", [0, 2, 4, 16, 18, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)
@@ -214,8 +215,7 @@ def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
         assert (info["block_threads"], info["items_per_thread"], info["flags"]) == (block, ipt, flags)
         y, ws = run_gpu(M, csr, x)
         check_strict(M, csr, x, y)
-        if not (flags & 1):
-            check_tiles(M, csr, x, ws)
+        check_tiles(M, csr, x, ws)
     finally:
         M.set_tuning(vb)
 
@@ -227,7 +227,7 @@ def test_axpby_extension(M):
         x = rng.uniform(-1, 1, 4000).astype(dtype)
         y0 = rng.uniform(-1, 1, 4000).astype(dtype)
         g, s = O.spmv_gold_acc64(csr, x)
-        for flags in (0, 16, 0x200010):          # fused small-problem kernel, one tile per block, persistent
+        for flags in (0, 16, 20):          # fused small-problem kernel, one tile per block, dword-per-lane fallback
             M.set_tuning(csr.values.dtype.itemsize, 0, 0, flags)
             try:
                 for alpha, beta in ((1.0, 0.0), (2.5, 0.0), (1.0, 1.0), (-0.5, 3.0)):
@@ -538,7 +538,7 @@ def _guarded(t, fill, guard=64):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("flags", [0, 16, 4, 0x200010])
+@pytest.mark.parametrize("flags", [0, 16, 4, 0xF000010])
 def test_nothing_outside_the_arrays_is_used_or_written(M, prec, flags):
     """Every array sits between guard regions: NaN around values and x (a product with anything read from
     there would poison y), a pattern around y and around the temp storage that must survive the call.

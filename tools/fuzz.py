@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import merge_spmv_amd as M
 
-FLAGS = [0, 0, 0, 2, 4, 8, 16, 17, 24, 48, 80, 128, 144, 0x200010, 0x310, 0x70010]
+FLAGS = [0, 0, 0, 2, 4, 8, 16, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0xE000010]
 SHAPES = {4: [(256, 7), (256, 5), (256, 9), (256, 11), (128, 7), (512, 7), (256, 15)],
           8: [(256, 5), (256, 3), (256, 7), (256, 9), (128, 5), (512, 5), (256, 11)]}
 
