@@ -4,27 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one y = A*x through the C ABI (include/mspmv.h) on the synthetic
-CSR workload BASELINE.json's metric is quoted on for one GPU -- config C2:
-fp32, 3 125 000 x 3 125 000, exactly 32 nnz/row = 100 000 000 nnz, uniform
-random columns.  Inputs are resident in HBM before timing.
-With N GPUs the matrix has N x 3 125 000 rows over the SAME 3 125 000 columns
-(per-GPU rows, nonzeros and x working set all fixed: weak scaling; growing
-the column space with N would instead measure how the x gather falls out of
-cache), is merge-partitioned by diagonal across the ranks
-(merge_spmv_amd/multi_gpu.py) and each step adds the one RCCL all-gather of the
-boundary-row carries.  Rank 0 prints ONE JSON line.
+A "step" is one y = A*x through the C ABI (include/mspmv.h); inputs are resident in HBM before timing.
+
+N = 1 (default workload "c2"): BASELINE.json config 2, the configuration the metric is quoted on for one
+GPU -- fp32, 3 125 000 x 3 125 000, exactly 32 nnz/row = 100 000 000 nnz, uniform random sorted columns
+ -- through the stateless drop-in call mspmv_csrmv_f32.  The same line carries a
+`prepared_plan` sub-record: the opt-in band-major plan (mspmv_csrmv_plan_*; set-up reported separately,
+like the reference reports the HYB conversion, gpu_spmv.cu:106-257) on the same matrix.
+
+N > 1 (default workload "c5"): BASELINE.json config 5 -- fp64 R-MAT scale 26 (67 108 864^2), 2 000 000 000
+edges, ONE matrix independent of N, merge-partitioned by diagonal into N swaths (mspmv_mg_partition);
+every rank builds its swath in its own HBM from the counter-based generator and drives it through the C
+multi-GPU operator (mspmv_mg_plan_*: the part's CsrMV launches + ONE RCCL all-gather of the N
+boundary-row carries + the owner's add, all below the C ABI).  Strong scaling: `value` = 2 * nnz_total /
+max-over-ranks time.  Rank 0 then also runs the WHOLE matrix alone on its GPU in the same job
+(`single_gpu_same_workload`), so the line is self-contained for an efficiency figure.
+"c2" can also be run sharded (--workload c2 --gpus N: weak scaling, N x 3 125 000 rows over the same
+3 125 000 columns); "dense32" is C2's pure-streaming variant (--dense=32 --size=100000000).
 
 value           = 2 * nnz_total / t  (GFLOP/s, whole job; reference formula gpu_spmv.cu:451-465)
-roofline        = algorithmic (compulsory) bytes of one tile_kernel launch / its
-                  average duration from hipEvents recorded on the launch stream
-                  (mspmv_profile_begin/_end), against the 8 TB/s HBM3E peak
-cpu_baseline    = the oracle's OpenMP merge-path port (oracle/merge_oracle.c,
-                  restating cpu_spmv.cpp:292-353) on the same matrix on this
-                  box's host cores, bounded sample; a checker timed beside the
-                  product, never used by it.
+roofline        = algorithmic (compulsory) bytes of one tile_kernel launch / its average duration from
+                  hipEvents recorded on the launch stream (mspmv_profile_begin/_end), against the 8 TB/s
+                  HBM3E peak
+cpu_baseline    = the PRODUCT's OpenMP merge-path kernel (merge_spmv_amd/host/merge_csrmv.hpp, what cpu_spmv
+                  runs; pinned bit for bit against the oracle by tests/test_cpu_product_parity.py) on the
+                  same matrix on this box's host cores: private first-touched arrays, threads = the cgroup
+                  CPU quota, bound to distinct cores of socket 0 when the cpuset allows; bounded sample.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -37,12 +45,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (rows per GPU, nnz per row, default dtype).  "c2" is the headline (BASELINE config 2,
-    # uniform random columns); "dense32" is its reference-compatible pure-streaming variant
-    # (--dense=32 --size=100000000, gpu_spmv.cu:645-650): same sizes, x has 32 entries.
-    "c2": (3_125_000, 32, "f32"),
-    "dense32": (3_125_000, 32, "f32"),
+    # name: default dtype.  "c2" is the N = 1 headline (BASELINE config 2); "dense32" its reference-compatible
+    # pure-streaming variant (--dense=32 --size=100000000, gpu_spmv.cu:645-650); "c5" = BASELINE config 5.
+    "c2": "f32",
+    "dense32": "f32",
+    "c5": "f64",
 }
+C2_ROWS_PER_GPU, C2_NPR = 3_125_000, 32
 
 
 def algorithmic_bytes(rows, cols, nnz, vb):
@@ -55,22 +64,46 @@ def effective_bytes(rows, nnz, vb):
     return nnz * (2 * vb + 4) + rows * (4 + vb)
 
 
-def cpu_baseline(A, x, budget_s=12.0, max_iters=40):
-    """Time the oracle port on the host cores (rank 0, N = 1 only)."""
+def cpu_baseline(A, x, label, budget_s=12.0, max_iters=40):
+    """Time the product's OpenMP merge-path kernel on the host cores (rank 0, N = 1 only)."""
     import numpy as np
-    from oracle import oracle as O
-    csr = O.Csr(A.rows, A.cols, A.row_offsets.cpu().numpy(), A.column_indices.cpu().numpy(),
-                A.values.cpu().numpy())
+    H = ctypes.CDLL(os.path.join(ROOT, "merge_spmv_amd", "libmspmv_host.so"))
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    H.mspmv_host_usable_cpus.restype = i
+    H.mspmv_host_hardware_threads.restype = i
+    off = A.row_offsets.cpu().numpy(); col = A.column_indices.cpu().numpy(); val = A.values.cpu().numpy()
     xh = x.cpu().numpy()
-    threads = O.max_threads()
-    O.omp_merge_csrmv(csr, xh, threads)                      # warm-up (cf. cpu_spmv.cpp:390-392)
-    t0 = time.perf_counter(); iters = 0
-    while iters < max_iters and (time.perf_counter() - t0) < budget_s:
-        O.omp_merge_csrmv(csr, xh, threads); iters += 1
-    dt = (time.perf_counter() - t0) / max(iters, 1)
-    return {"value": round(2.0 * csr.nnz / dt / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"same C2 matrix ({csr.nnz} nnz), {iters} OpenMP merge-path SpMVs, {dt * 1e3:.2f} ms each",
-            "effective_GBs": round(effective_bytes(csr.rows, csr.nnz, csr.values.dtype.itemsize) / dt / 1e9, 2)}
+    f32 = val.dtype == np.float32
+    fn = H.mspmv_host_merge_csrmv_bench_f32 if f32 else H.mspmv_host_merge_csrmv_bench_f64
+    fn.restype = i
+    fn.argtypes = [i, i, i, i, i, vp, vp, vp, vp, ctypes.c_double, i, vp, vp, vp, vp, vp]
+    threads = int(H.mspmv_host_usable_cpus())
+    avg = ctypes.c_double(); iters = ctypes.c_int(); pinned = ctypes.c_int(); packages = ctypes.c_int()
+    st = fn(threads, 1, A.rows, A.cols, int(val.size), off.ctypes.data, col.ctypes.data, val.ctypes.data, xh.ctypes.data,
+            float(budget_s), int(max_iters), ctypes.byref(avg), ctypes.byref(iters), ctypes.byref(pinned),
+            ctypes.byref(packages), None)
+    if st != 0:
+        return {"error": f"mspmv_host_merge_csrmv_bench returned {st}"}
+    quota = "unlimited"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = "unlimited" if q == "max" else f"{int(q) / int(per):g} CPUs (cpu.max {q} {per})"
+    except (OSError, ValueError):
+        pass
+    try:
+        cpuset = open("/sys/fs/cgroup/cpuset.cpus.effective").read().strip()
+    except OSError:
+        cpuset = "?"
+    dt = avg.value * 1e-3
+    nnz = int(val.size)
+    return {"value": round(2.0 * nnz / dt / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "kernel": "merge_spmv_amd/host/merge_csrmv.hpp (product OpenMP merge-path CsrMV; -O3 -march=x86-64-v3 -ffp-contract=off)",
+            "sample": f"{label} ({nnz} nnz), {iters.value} SpMVs after 4 warm-ups, {avg.value:.2f} ms each",
+            "threads": threads, "hardware_threads": int(H.mspmv_host_hardware_threads()), "cpu_quota": quota, "cpuset": cpuset,
+            "binding": (f"one thread per physical core of socket 0 ({packages.value} socket(s) visible)" if pinned.value
+                        else "unbound (socket 0 has fewer allowed cores than threads, or affinity calls are refused)"),
+            "first_touch": "every thread first-touches the swath of the arrays it streams",
+            "effective_GBs": round(effective_bytes(A.rows, nnz, val.dtype.itemsize) / dt / 1e9, 2)}
 
 
 def main():
@@ -78,9 +111,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU, c5 (one R-MAT matrix cut N ways) on N > 1")
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
+    ap.add_argument("--c5-scale", type=int, default=26)
+    ap.add_argument("--c5-edges", type=int, default=2_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plan", action="store_true", help="skip the prepared_plan sub-record (N = 1, c2)")
+    ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1, c5: skip rank 0's whole-matrix run")
     ap.add_argument("--tune", default=None, help="development: BLOCKxIPT[:flags] passed to mspmv_set_tuning")
     args = ap.parse_args()
 
@@ -97,66 +135,123 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP merge-path kernels have no CPU fallback)")
     # MSPMV_BENCH_ONE_DEVICE=1 + MSPMV_BENCH_BACKEND=gloo: exercise the multi-rank path on a
-    # single-GPU box (all ranks on cuda:0, carries exchanged through gloo) -- a functional
-    # check of the sharding / exchange code, not a measurement
-    if os.environ.get("MSPMV_BENCH_ONE_DEVICE") == "1":
+    # single-GPU box (all ranks on cuda:0, carries exchanged through gloo by the Python twin of the C
+    # operator, because RCCL admits one rank per device) -- a functional check of the sharding /
+    # exchange / reporting code, not a measurement
+    one_device = os.environ.get("MSPMV_BENCH_ONE_DEVICE") == "1"
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     M.load_library()
     dist = None
+    backend = os.environ.get("MSPMV_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MSPMV_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
 
-    rows_per_gpu, npr, default_dtype = WORKLOADS[args.workload]
-    dtype_name = args.dtype or default_dtype
+    workload = args.workload or ("c2" if world == 1 else "c5")
+    dtype_name = args.dtype or WORKLOADS[workload]
     if args.tune:
         shape, _, fl = args.tune.partition(":")
         b, _, i = shape.partition("x")
         M.set_tuning(4 if dtype_name == "f32" else 8, int(b or 0), int(i or 0), int(fl or "0", 0))
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
-    rows = rows_per_gpu * world
-    cols = rows_per_gpu if args.workload == "c2" else npr
-    nnz_total = rows * npr
-    if args.workload != "c2" and world > 1:
-        raise SystemExit("only the c2 workload is sharded across GPUs")
+    if workload == "dense32" and world > 1:
+        raise SystemExit("dense32 is a single-GPU workload")
 
-    # ---- build this rank's swath directly in HBM -------------------------
+    # ---- the matrix (this rank's swath of it), directly in HBM ----------------------------------------------
+    A = None
+    shard = None
+    if workload == "c5":
+        n = 1 << args.c5_scale
+        rows = cols = n
+        nnz_total = args.c5_edges
+        x_seed = G.SEED_C5 + 2
+        scaling = "strong"
+        desc = (f"C5 R-MAT scale {args.c5_scale}: {n} x {n}, {nnz_total} generated edges (duplicates kept), a,b,c,d = "
+                f".57,.19,.19,.05, seed 0x5EED0005, values/x uniform in [-1,1); one matrix independent of the GPU count")
+        if world == 1:
+            A = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
+        else:
+            shard = MG.rmat_shard(args.c5_scale, nnz_total, rank, world, tdt, device=dev, seed=G.SEED_C5)
+    else:
+        rows = C2_ROWS_PER_GPU * world
+        cols = C2_ROWS_PER_GPU if workload == "c2" else C2_NPR
+        nnz_total = rows * C2_NPR
+        x_seed = G.SEED_C2 + 2
+        scaling = "weak"
+        desc = ((f"C2 uniform CSR: {rows} x {cols}, {C2_NPR} nnz/row, {nnz_total} nnz ({C2_ROWS_PER_GPU * C2_NPR} nnz per GPU), "
+                 f"uniform random sorted columns, values/x in [-1,1)") if workload == "c2" else
+                f"dense {rows} x {C2_NPR} as CSR ({nnz_total} nnz): the streaming variant of C2 (--dense=32 --size=100000000)")
+        if world == 1:
+            A = (G.uniform_csr(rows, cols, C2_NPR, dtype=tdt, device=dev) if workload == "c2"
+                 else G.dense_csr(rows, C2_NPR, dtype=tdt, device=dev, ones=False))
+        else:
+            shard = MG.uniform_shard(rows, cols, C2_NPR, rank, world, tdt, device=dev)
+    x = G.uniform_pm1(x_seed, cols, tdt, dev)
+
+    # ---- the operator ------------------------------------------------------------------------------------------
+    plan = None
+    exchange = None
     if world == 1:
         # the plain drop-in call: no shard wrapper, no collective
-        A = (G.uniform_csr(rows, cols, npr, dtype=tdt, device=dev) if args.workload == "c2"
-             else G.dense_csr(rows, npr, dtype=tdt, device=dev, ones=False))
-        local_rows, local_nnz = rows, nnz_total
-        ws = M.CsrMVWorkspace(rows, nnz_total, tdt, device=dev)
-        y = torch.empty(rows, dtype=tdt, device=dev)
+        local_rows, local_nnz = A.rows, A.nnz
+        ws = M.CsrMVWorkspace(A.rows, A.nnz, tdt, device=dev)
+        y = torch.empty(A.rows, dtype=tdt, device=dev)
 
-        def op(xv):
-            return M.csrmv(A.values, A.row_offsets, A.column_indices, xv, y=y, num_cols=cols, workspace=ws)
-    else:
-        shard = MG.uniform_shard(rows, cols, npr, rank, world, tdt, device=dev)
+        def op():
+            M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=cols, workspace=ws)
+
+        def op_sync():
+            torch.cuda.synchronize()
+    elif backend == "nccl" and not one_device:
+        # the C multi-GPU operator, one part per process; RCCL communicator over the ranks
         local_rows, local_nnz = shard.local_rows, shard.local_nnz
-        op = MG.ShardedCsrMV(shard, group=None)
-    x = G.uniform_pm1(G.SEED_C2 + 2, cols, tdt, dev)
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        plan = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
+                         id128=bytes(idt.cpu().numpy().tobytes()))
+        plan.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
+        plan.x(0).copy_(x)
+        torch.cuda.synchronize()
+        exchange = plan.info()
+
+        def op():
+            plan.csrmv()
+
+        def op_sync():
+            plan.synchronize(); torch.cuda.synchronize()
+    else:
+        local_rows, local_nnz = shard.local_rows, shard.local_nnz
+        sharded = MG.ShardedCsrMV(shard, group=None)
+        exchange = {"exchange": "python twin over " + backend, "carry_bytes_per_step": world * vb}
+
+        def op():
+            sharded(x)
+
+        def op_sync():
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        op_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        op_sync()
 
     for _ in range(args.warmup):
-        op(x)
+        op()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        op(x)
+        op()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -168,9 +263,33 @@ def main():
     # ---- per-kernel durations: the same K steps again with hipEvents on the launch stream
     M.profile_begin(args.steps)
     for _ in range(args.steps):
-        op(x)
-    torch.cuda.synchronize()
+        op()
+    op_sync()
     prof = M.profile_end()
+
+    # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
+    single = None
+    if world > 1 and workload == "c5" and not args.no_single_gpu_leg:
+        if plan is not None:
+            plan.close()
+        plan = None; shard = None; sharded = None
+        torch.cuda.empty_cache()
+        if rank == 0:
+            W = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
+            wws = M.CsrMVWorkspace(W.rows, W.nnz, tdt, device=dev)
+            wy = torch.empty(W.rows, dtype=tdt, device=dev)
+            k = max(5, min(args.steps, 50))
+            for _ in range(3):
+                M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(k):
+                M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
+            torch.cuda.synchronize()
+            sms = (time.perf_counter() - t1) * 1e3 / k
+            single = {"n_gpus": 1, "steps": k, "ms_per_step": round(sms, 5), "value": round(2.0 * nnz_total / (sms * 1e-3) / 1e9, 3),
+                      "unit": "GFLOP/s", "speedup_of_this_job": round(sms / ms_per_step, 3),
+                      "parallel_efficiency": round(sms / ms_per_step / world, 4)}
+            del W, wws, wy
 
     if rank == 0:
         gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
@@ -183,21 +302,20 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("workload") == args.workload and pmc.get("dtype") == dtype_name and world == 1:
+                if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and world == 1:
                     traffic = pmc.get("tile_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
             "metric": "CsrMV GFLOP/s", "value": round(gflops, 3), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": (f"C2 uniform CSR: {rows} x {cols}, {npr} nnz/row, {nnz_total} nnz "
-                                    f"({rows_per_gpu * npr} nnz per GPU), uniform random sorted columns, values/x in [-1,1)")
-                       if args.workload == "c2" else
-                       f"dense {rows} x {npr} as CSR ({nnz_total} nnz): the streaming variant of C2 (--dense=32 --size=100000000)",
+            "config": {"workload": desc,
                        "tile": f"{info['block_threads']}x{info['items_per_thread']}",
-                       "partition": "single GPU" if world == 1 else f"merge-path diagonal split over {world} GPUs + 1 RCCL all-gather of carries"},
+                       "partition": ("single GPU" if world == 1 else
+                                     f"merge-path diagonal split over {world} GPUs (mspmv_mg_partition): "
+                                     f"{local_rows - 1} rows + {local_nnz} nonzeros on rank 0; one exchange of {world} carries per step")},
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": "tile_kernel_vec", "achieved": round(achieved, 2),
@@ -207,8 +325,16 @@ def main():
                                        "fixup": round(prof["fixup_ms"], 5)},
                          "events": f"hipEvents on the launch stream, {prof['calls']} launches"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(A, x)
+        if exchange is not None:
+            out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items()}
+            if isinstance(exchange.get("exchange"), int):
+                out["exchange"]["backend"] = {1: "RCCL ncclAllGather (1 element per rank) below the C ABI", 2: "peer reads"}.get(exchange["exchange"])
+        if single is not None:
+            out["single_gpu_same_workload"] = single
+        if world == 1 and workload == "c2" and not args.no_plan and hasattr(M, "CsrMVPlan"):
+            out["prepared_plan"] = M.plan_bench_record(A, x, y, steps=args.steps, warmup=args.warmup, peak_gbs=HBM_PEAK_GBS)
+        if world == 1 and not args.no_cpu_baseline and A.nnz <= 400_000_000:
+            out["cpu_baseline"] = cpu_baseline(A, x, "same " + workload.upper() + " matrix")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -122,6 +122,39 @@ int mspmv_csrmv_prepared_f64(void *d_temp, size_t *temp_bytes, const double *d_v
                              int32_t nnz, double alpha, double beta,
                              mspmv_stream_t stream, int debug_sync);
 
+/* ---- extension: PREPARED PLAN for a gather-bound matrix multiplied many times (opt-in; the stateless
+ * drop-in calls above never use it).  When x is larger than an XCD's 4 MiB L2, ~70 % of the x gathers miss
+ * and every miss moves a 128-byte line: that, not HBM, bounds mspmv_csrmv_* on such a matrix (BASELINE
+ * config 2).  mspmv_csrmv_plan_build_* makes, ONCE, a band-major copy of the matrix in the caller's
+ * storage: the columns are cut into `bands` equal bands (0 = pick: a multiple of 8 with <= 2 MiB of x per
+ * band; 1 when x fits anyway) and the entries of band b form the b-th block of rows of a stacked CSR
+ * matrix; mspmv_csrmv_plan_apply_* then runs the ordinary merge-path CsrMV over the stacked matrix with
+ * one contiguous tile range per XCD -- so each XCD's L2 only ever holds one band's slice of x and the CSR
+ * stream is read exactly once -- and folds the bands' partial sums in band order:
+ *     y = alpha * A * x + beta * y        (beta == 0: y is never read).
+ * Conventions: caller-owned storage of mspmv_csrmv_plan_size bytes (device memory; the same rows / cols /
+ * nnz / bands must be passed to _size, _build and _apply); nothing is allocated; asynchronous on `stream`;
+ * the original arrays are not needed after _build.  Results are within the CsrMV tolerance and bitwise
+ * reproducible for a given plan.  Needs bands * rows + nnz <= 2^31 - 65537 (hipErrorInvalidValue otherwise:
+ * use the stateless call).  This is the counterpart of what the reference's driver does for its HYB
+ * comparison -- conversion timed once as set-up, SpMV timed separately (gpu_spmv.cu:106-257). ---- */
+int mspmv_csrmv_plan_size(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t bands,
+                          size_t *plan_bytes, int32_t *bands_used);
+int mspmv_csrmv_plan_build_f32(void *d_plan, size_t plan_bytes, const float *d_values,
+                               const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                               int32_t rows, int32_t cols, int32_t nnz, int32_t bands,
+                               mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_plan_build_f64(void *d_plan, size_t plan_bytes, const double *d_values,
+                               const int32_t *d_row_offsets, const int32_t *d_column_indices,
+                               int32_t rows, int32_t cols, int32_t nnz, int32_t bands,
+                               mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_plan_apply_f32(void *d_plan, size_t plan_bytes, const float *d_x, float *d_y,
+                               int32_t rows, int32_t cols, int32_t nnz, int32_t bands,
+                               float alpha, float beta, mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_x, double *d_y,
+                               int32_t rows, int32_t cols, int32_t nnz, int32_t bands,
+                               double alpha, double beta, mspmv_stream_t stream, int debug_sync);
+
 /* ---- introspection (the counterpart of the reference's debug_synchronous
  * launch log, dispatch_spmv_orig.cuh:685-739, as data) ---- */
 typedef struct mspmv_launch_info {
@@ -217,6 +250,61 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries,
                            const int64_t *row_split, int32_t parts,
                            int32_t part, int32_t value_bytes,
                            mspmv_stream_t stream);
+
+/* ---- the multi-GPU operator (mspmv_mg_plan_create / _csrmv / _destroy).  New design; the
+ * reference has a single --device (utils.h:465-474).
+ *
+ * A plan drives the parts ONE PROCESS holds of a matrix cut by mspmv_mg_partition:
+ *   - all of them (local_parts == parts: single-process form; device_ids may repeat, so a 1-GPU box can run
+ *     G parts on one device), or
+ *   - some, typically one (one process per GPU; every process passes the same 128-byte id128 that ONE of
+ *     them obtained from mspmv_mg_unique_id and shipped by whatever means the launcher has).
+ * The caller owns the part's CSR arrays (values, column indices and the local int32 row offsets of
+ * mspmv_mg_local_offsets, all on the part's device) and attaches them with mspmv_mg_plan_set_part, which
+ * also finds the part's tile coordinates once.  The plan owns one stream per part, the replicated x (one
+ * replica per distinct device, mspmv_mg_plan_x -- the caller fills it before the first SpMV), the row-sharded
+ * result (mspmv_mg_plan_y: the part's owned rows, row_split[id+1]-row_split[id] entries, followed by one
+ * scratch entry) and the exchange buffers.
+ *
+ * mspmv_mg_csrmv: y = A*x on every local part + the ONE exchange of the boundary-row carries + the owners'
+ * adds, all asynchronous on the parts' streams (mspmv_mg_synchronize waits).  Exchange backends:
+ *   MSPMV_MG_EXCHANGE_PEER  (single-process form only) events between the parts' streams and one small kernel
+ *                           that reads the carries straight out of the peers' memory over xGMI;
+ *   MSPMV_MG_EXCHANGE_RCCL  one ncclAllGather of a scalar per part (needs distinct devices; librccl is loaded
+ *                           on first use, the library has no link-time dependency on it);
+ *   MSPMV_MG_EXCHANGE_AUTO  PEER when the process holds every part, else RCCL.
+ * mspmv_mg_allgather_rows (square matrices): x <- y on every replica -- PEER: each part
+ * pushes its owned rows into every replica (direct peer writes, unpadded); RCCL: grouped ncclBroadcast.
+ * Results are deterministic (carries are added in part order) and within the CsrMV tolerance.
+ * Returns 0 or a hipError_t; hipErrorNotSupported = librccl could not be loaded, hipErrorUnknown = an
+ * RCCL call failed (message on stderr). ---- */
+typedef struct mspmv_mg_plan mspmv_mg_plan_t;
+#define MSPMV_MG_EXCHANGE_AUTO 0
+#define MSPMV_MG_EXCHANGE_RCCL 1
+#define MSPMV_MG_EXCHANGE_PEER 2
+
+typedef struct mspmv_mg_info {
+    int32_t parts, local_parts, exchange /* backend in effect */, value_bytes, replicas, reserved;
+    int64_t rows, cols;
+    uint64_t carry_bytes_per_step;       /* payload of the carry exchange: parts * value_bytes        */
+    uint64_t allgather_bytes_per_step;   /* payload of y -> x: rows * value_bytes to every OTHER GPU  */
+    uint64_t steps;                      /* mspmv_mg_csrmv calls so far                               */
+} mspmv_mg_info_t;
+
+int mspmv_mg_unique_id(void *id128);
+int mspmv_mg_plan_create(mspmv_mg_plan_t **plan, int32_t parts, int32_t local_parts, const int32_t *part_ids,
+                         const int32_t *device_ids, const int64_t *row_split, const int64_t *nz_split,
+                         int64_t cols, int32_t value_bytes, int32_t exchange, const void *id128);
+int mspmv_mg_plan_set_part(mspmv_mg_plan_t *plan, int32_t local_index, const void *d_values,
+                           const int32_t *d_local_row_offsets, const int32_t *d_column_indices);
+void *mspmv_mg_plan_x(mspmv_mg_plan_t *plan, int32_t local_index);
+void *mspmv_mg_plan_y(mspmv_mg_plan_t *plan, int32_t local_index);
+mspmv_stream_t mspmv_mg_plan_stream(mspmv_mg_plan_t *plan, int32_t local_index);
+int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info);
+int mspmv_mg_csrmv(mspmv_mg_plan_t *plan);
+int mspmv_mg_allgather_rows(mspmv_mg_plan_t *plan);
+int mspmv_mg_synchronize(mspmv_mg_plan_t *plan);
+int mspmv_mg_plan_destroy(mspmv_mg_plan_t *plan);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ import ctypes
 import os
 from typing import Optional, Tuple
 
-__all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "library_path", "load_library", "launch_info",
+__all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "CsrMVPlan", "plan_bench_record", "library_path", "load_library", "launch_info",
            "set_tuning", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
            "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
@@ -108,6 +108,30 @@ def load_library() -> ctypes.CDLL:
                                            ctypes.c_int64, vp]
     lib.mspmv_mg_apply_carries.restype = ctypes.c_int
     lib.mspmv_mg_apply_carries.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    i64, u64 = ctypes.c_int64, ctypes.c_uint64
+    lib.mspmv_csrmv_plan_size.restype = ctypes.c_int
+    lib.mspmv_csrmv_plan_size.argtypes = [i32, i32, i32, i32, i32, sz_p, ctypes.POINTER(i32)]
+    for name, ct in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+        fn = getattr(lib, "mspmv_csrmv_plan_build_" + name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, i32, i32, i32, i32, vp, ctypes.c_int]
+        fn = getattr(lib, "mspmv_csrmv_plan_apply_" + name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [vp, ctypes.c_size_t, vp, vp, i32, i32, i32, i32, ct, ct, vp, ctypes.c_int]
+    lib.mspmv_mg_unique_id.restype = ctypes.c_int
+    lib.mspmv_mg_unique_id.argtypes = [vp]
+    lib.mspmv_mg_plan_create.restype = ctypes.c_int
+    lib.mspmv_mg_plan_create.argtypes = [ctypes.POINTER(vp), i32, i32, vp, vp, vp, vp, i64, i32, i32, vp]
+    lib.mspmv_mg_plan_set_part.restype = ctypes.c_int
+    lib.mspmv_mg_plan_set_part.argtypes = [vp, i32, vp, vp, vp]
+    for name in ("mspmv_mg_plan_x", "mspmv_mg_plan_y", "mspmv_mg_plan_stream"):
+        getattr(lib, name).restype = vp
+        getattr(lib, name).argtypes = [vp, i32]
+    lib.mspmv_mg_plan_info.restype = ctypes.c_int
+    lib.mspmv_mg_plan_info.argtypes = [vp, vp]
+    for name in ("mspmv_mg_csrmv", "mspmv_mg_allgather_rows", "mspmv_mg_synchronize", "mspmv_mg_plan_destroy"):
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = [vp]
     _lib = lib
     return lib
 
@@ -333,6 +357,77 @@ def csrmm(values, row_offsets, column_indices, X, Y=None, alpha: float = 1.0, be
     size = ctypes.c_size_t(temp.numel())
     _check(call(ctypes.c_void_p(temp.data_ptr()), size), "mspmv_csrmm")
     return Y
+
+
+class CsrMVPlan:
+    """The opt-in prepared plan (mspmv_csrmv_plan_*): a band-major copy of the matrix made once, so that every
+    XCD gathers from an L2-sized slice of x.  For a matrix that is multiplied many times and whose x does not
+    fit an XCD's 4 MiB L2; the stateless `csrmv` never uses it.  `plan(x, y)` computes y = alpha*A*x + beta*y."""
+
+    def __init__(self, values, row_offsets, column_indices, num_cols: int, bands: int = 0, stream=None):
+        import torch
+        self.rows, self.cols, self.nnz = row_offsets.numel() - 1, int(num_cols), values.numel()
+        y_probe = torch.empty(0, dtype=values.dtype, device=values.device)
+        _validate(values, row_offsets, column_indices, None, torch.empty(self.rows, dtype=values.dtype, device=values.device)
+                  if self.rows == 0 else y_probe.new_empty(self.rows), self.rows, 0, self.nnz, "CsrMVPlan")
+        self.dtype = values.dtype
+        self.vb = _value_bytes(values)
+        size = ctypes.c_size_t(0); used = ctypes.c_int32(0)
+        _check(load_library().mspmv_csrmv_plan_size(self.rows, self.cols, self.nnz, self.vb, int(bands), ctypes.byref(size),
+                                                    ctypes.byref(used)), "mspmv_csrmv_plan_size")
+        self.bytes, self.bands = int(size.value), int(used.value)
+        self.storage = torch.empty(max(self.bytes, 1), dtype=torch.uint8, device=values.device)
+        fn = load_library().mspmv_csrmv_plan_build_f32 if self.vb == 4 else load_library().mspmv_csrmv_plan_build_f64
+        _check(fn(ctypes.c_void_p(self.storage.data_ptr()), self.bytes, _ptr(values), _ptr(row_offsets), _ptr(column_indices),
+                  self.rows, self.cols, self.nnz, self.bands, _stream_handle(stream), 0), "mspmv_csrmv_plan_build")
+
+    def __call__(self, x, y=None, alpha: float = 1.0, beta: float = 0.0, stream=None, debug_synchronous: bool = False):
+        import torch
+        if y is None:
+            y = torch.empty(self.rows, dtype=self.dtype, device=self.storage.device)
+        if x.dtype != self.dtype or y.dtype != self.dtype or x.device != self.storage.device or y.device != self.storage.device \
+                or not x.is_contiguous() or not y.is_contiguous() or x.dim() != 1 or y.dim() != 1 \
+                or x.numel() < self.cols or y.numel() < self.rows:
+            raise MspmvError("CsrMVPlan: x / y must be contiguous 1-D tensors of the plan's dtype on its device, with at least cols / rows entries")
+        fn = load_library().mspmv_csrmv_plan_apply_f32 if self.vb == 4 else load_library().mspmv_csrmv_plan_apply_f64
+        _check(fn(ctypes.c_void_p(self.storage.data_ptr()), self.bytes, _ptr(x), _ptr(y), self.rows, self.cols, self.nnz, self.bands,
+                  float(alpha), float(beta), _stream_handle(stream), int(bool(debug_synchronous))), "mspmv_csrmv_plan_apply")
+        return y
+
+
+def plan_bench_record(A, x, y_stateless, steps: int = 50, warmup: int = 5, peak_gbs: float = 8000.0) -> dict:
+    """bench.py's `prepared_plan` sub-record: set-up time of the plan, its SpMV time on the same matrix,
+    agreement with the stateless call's y."""
+    import time
+    import torch
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    plan = CsrMVPlan(A.values, A.row_offsets, A.column_indices, A.cols)
+    torch.cuda.synchronize(); setup_ms = (time.perf_counter() - t0) * 1e3
+    y = torch.empty_like(y_stateless)
+    for _ in range(max(warmup, 1)):
+        plan(x, y)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        plan(x, y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    profile_begin(steps)
+    for _ in range(steps):
+        plan(x, y)
+    torch.cuda.synchronize()
+    prof = profile_end()
+    vb = A.values.element_size()
+    b_alg = A.nnz * (vb + 4) + (A.rows + 1) * 4 + A.rows * vb + A.cols * vb
+    diff = float((y.double() - y_stateless.double()).abs().max())
+    scale = float(y_stateless.double().abs().max())
+    return {"api": "mspmv_csrmv_plan_build_* once, then mspmv_csrmv_plan_apply_* per SpMV (opt-in; not the drop-in call)",
+            "bands": plan.bands, "setup_ms": round(setup_ms, 3), "storage_bytes": plan.bytes,
+            "ms_per_step": round(ms, 5), "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
+            "tile_kernel_ms": round(prof["tile_ms"], 5),
+            "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 2), "peak": peak_gbs, "unit": "GB/s",
+                         "frac": round(b_alg / (ms * 1e-3) / 1e9 / peak_gbs, 4),
+                         "note": "algorithmic bytes of the ORIGINAL matrix / whole plan SpMV (tile kernel + fix-up + band fold)"},
+            "max_abs_diff_vs_stateless": diff, "max_abs_y": scale}
 
 
 def launch_info(num_rows: int, num_nonzeros: int, value_bytes: int) -> dict:

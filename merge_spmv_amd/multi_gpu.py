@@ -17,7 +17,9 @@ from typing import Optional
 
 import numpy as np
 
-from . import load_library, _check, CsrMVWorkspace, DeviceSpmv, csrmv, _stream_handle, _value_bytes
+from . import load_library, _check, CsrMVWorkspace, DeviceSpmv, csrmv, _stream_handle, _value_bytes, MspmvError
+
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_PEER = 0, 1, 2
 
 
 def partition(row_offsets_i64: np.ndarray, parts: int):
@@ -42,6 +44,133 @@ def local_offsets(row_offsets_i64: np.ndarray, row_begin: int, row_end: int, nz_
                                                  int(row_end), int(nz_begin), int(nz_end),
                                                  out.ctypes.data_as(ctypes.c_void_p)), "mspmv_mg_local_offsets")
     return out
+
+
+class _MgInfo(ctypes.Structure):
+    _fields_ = [("parts", ctypes.c_int32), ("local_parts", ctypes.c_int32), ("exchange", ctypes.c_int32),
+                ("value_bytes", ctypes.c_int32), ("replicas", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("carry_bytes_per_step", ctypes.c_uint64),
+                ("allgather_bytes_per_step", ctypes.c_uint64), ("steps", ctypes.c_uint64)]
+
+
+class _DeviceArray:
+    """plan-owned device memory seen by torch (torch.as_tensor reads __cuda_array_interface__: no copy)"""
+
+    def __init__(self, ptr: int, count: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def unique_id() -> bytes:
+    """128-byte token (an ncclUniqueId) ONE process makes and every process of a multi-process plan passes."""
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().mspmv_mg_unique_id(buf), "mspmv_mg_unique_id")
+    return buf.raw
+
+
+class MgPlan:
+    """Thin caller of the C multi-GPU operator (include/mspmv.h: mspmv_mg_plan_*): all the per-step work --
+    the parts' CsrMV launches, the one carry exchange (peer reads or one RCCL all-gather) and the owners'
+    adds -- happens below the C ABI in ONE call, `csrmv()`.
+
+    part_ids / device_ids: the parts THIS process drives (all of them, or one per process under
+    torch.distributed.run; then `id128` = unique_id() of one rank, shipped to the others)."""
+
+    def __init__(self, row_split, nz_split, num_cols: int, dtype, part_ids, device_ids, exchange: int = EXCHANGE_AUTO,
+                 id128: Optional[bytes] = None):
+        import torch
+        self.torch = torch
+        self.dtype = dtype
+        self.vb = 4 if dtype == torch.float32 else 8
+        self.row_split = np.ascontiguousarray(row_split, dtype=np.int64)
+        self.nz_split = np.ascontiguousarray(nz_split, dtype=np.int64)
+        self.parts = self.row_split.size - 1
+        self.part_ids = [int(p) for p in part_ids]
+        self.device_ids = [int(d) for d in device_ids]
+        self.num_cols = int(num_cols)
+        ids = np.asarray(self.part_ids, dtype=np.int32); devs = np.asarray(self.device_ids, dtype=np.int32)
+        self._handle = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(id128, 128) if id128 is not None else None
+        _check(load_library().mspmv_mg_plan_create(ctypes.byref(self._handle), self.parts, len(self.part_ids),
+                                                   ids.ctypes.data_as(ctypes.c_void_p), devs.ctypes.data_as(ctypes.c_void_p),
+                                                   self.row_split.ctypes.data_as(ctypes.c_void_p),
+                                                   self.nz_split.ctypes.data_as(ctypes.c_void_p), self.num_cols, self.vb,
+                                                   int(exchange), idbuf), "mspmv_mg_plan_create")
+        self._keep = {}
+
+    def local_rows(self, i: int) -> int:
+        g = self.part_ids[i]
+        return int(self.row_split[g + 1] - self.row_split[g]) + 1
+
+    def owned_rows(self, i: int) -> int:
+        return self.local_rows(i) - 1
+
+    def local_nnz(self, i: int) -> int:
+        g = self.part_ids[i]
+        return int(self.nz_split[g + 1] - self.nz_split[g])
+
+    def set_part(self, i: int, values, local_row_offsets, column_indices):
+        """attach local part i's CSR (tensors on that part's device; kept alive by the plan object)"""
+        torch = self.torch
+        dev = torch.device("cuda", self.device_ids[i])
+        if local_row_offsets.dtype != torch.int32 or local_row_offsets.device != dev or not local_row_offsets.is_contiguous() \
+                or local_row_offsets.numel() != self.local_rows(i) + 1:
+            raise MspmvError("set_part: local_row_offsets must be a contiguous int32 tensor with local_rows + 1 entries on the part's device")
+        n = self.local_nnz(i)
+        if n > 0 and (values.dtype != self.dtype or values.device != dev or not values.is_contiguous() or values.numel() != n or
+                      column_indices.dtype != torch.int32 or column_indices.device != dev or
+                      not column_indices.is_contiguous() or column_indices.numel() != n):
+            raise MspmvError("set_part: values / column_indices must be contiguous tensors of the part's nonzero count on its device")
+        self._keep[i] = (values, local_row_offsets, column_indices)
+        _check(load_library().mspmv_mg_plan_set_part(self._handle, i, ctypes.c_void_p(values.data_ptr() if n else 0),
+                                                     ctypes.c_void_p(local_row_offsets.data_ptr()),
+                                                     ctypes.c_void_p(column_indices.data_ptr() if n else 0)),
+               "mspmv_mg_plan_set_part")
+
+    def _view(self, ptr, count, i):
+        torch = self.torch
+        if count == 0:
+            return torch.empty(0, dtype=self.dtype, device=torch.device("cuda", self.device_ids[i]))
+        t = torch.as_tensor(_DeviceArray(ptr, count, "<f4" if self.vb == 4 else "<f8"), device=torch.device("cuda", self.device_ids[i]))
+        return t
+
+    def x(self, i: int):
+        """the replica of x on local part i's device (num_cols entries), as a tensor aliasing plan memory"""
+        return self._view(load_library().mspmv_mg_plan_x(self._handle, i), self.num_cols, i)
+
+    def y(self, i: int, with_open_row: bool = False):
+        """local part i's owned rows of y (aliasing plan memory)"""
+        n = self.local_rows(i) if with_open_row else self.owned_rows(i)
+        return self._view(load_library().mspmv_mg_plan_y(self._handle, i), n, i)
+
+    def stream(self, i: int) -> int:
+        return int(load_library().mspmv_mg_plan_stream(self._handle, i) or 0)
+
+    def info(self) -> dict:
+        info = _MgInfo()
+        _check(load_library().mspmv_mg_plan_info(self._handle, ctypes.byref(info)), "mspmv_mg_plan_info")
+        return {name: getattr(info, name) for name, _ in _MgInfo._fields_ if name != "reserved"}
+
+    def csrmv(self):
+        _check(load_library().mspmv_mg_csrmv(self._handle), "mspmv_mg_csrmv")
+
+    def allgather_rows(self):
+        _check(load_library().mspmv_mg_allgather_rows(self._handle), "mspmv_mg_allgather_rows")
+
+    def synchronize(self):
+        _check(load_library().mspmv_mg_synchronize(self._handle), "mspmv_mg_synchronize")
+
+    def close(self):
+        if self._handle:
+            load_library().mspmv_mg_plan_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+            self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 @dataclass
@@ -175,3 +304,30 @@ def uniform_shard(rows: int, cols: int, nnz_per_row: int, part: int, parts: int,
     lo = local_offsets(off, r0, r1, int(nz_split[part]), int(nz_split[part + 1]))
     return Shard(part, parts, row_split, nz_split, torch.from_numpy(lo).to(device),
                  full.column_indices[a:b].contiguous(), full.values[a:b].contiguous(), int(cols))
+
+
+def rmat_shard(scale: int, edges: int, part: int, parts: int, dtype, device="cuda", seed: Optional[int] = None,
+               return_global_offsets: bool = False):
+    """Rank `part`'s swath of generators.rmat_csr(scale, edges) (C5: scale 26, 2e9 edges, fp64), built on
+    `device` without materialising the whole matrix: one pass over the edge ids counts the global row
+    lengths (so every rank finds the same partition), a second keeps only the edges of the rows the swath
+    touches (plus the row its right boundary cuts).  The matrix is independent of `parts`."""
+    import torch
+    from . import generators as G
+    seed = G.SEED_C5 if seed is None else seed
+    n = 1 << scale
+    counts = G.rmat_row_counts(scale, edges, device, seed)
+    off_dev = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=off_dev[1:])
+    off = off_dev.cpu().numpy()
+    del counts, off_dev
+    row_split, nz_split = partition(off, parts)
+    r0, r1 = int(row_split[part]), int(row_split[part + 1])
+    r_hi = min(r1 + 1, n)
+    full = G.rmat_csr(scale, edges, dtype=dtype, device=device, seed=seed, row_lo=r0, row_hi=r_hi)
+    a = int(nz_split[part]) - int(off[r0])
+    b = int(nz_split[part + 1]) - int(off[r0])
+    lo = local_offsets(off, r0, r1, int(nz_split[part]), int(nz_split[part + 1]))
+    shard = Shard(part, parts, row_split, nz_split, torch.from_numpy(lo).to(device),
+                  full.column_indices[a:b].contiguous(), full.values[a:b].contiguous(), n)
+    return (shard, off) if return_global_offsets else shard

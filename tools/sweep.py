@@ -37,6 +37,15 @@ def workloads(names):
         elif n == "web":
             A = G.rmat_csr(20, 3_105_536, dtype=torch.float64, seed=G.SEED_C3)
             yield "rmat20_webbase_like_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "dense5d":
+            A = G.dense_csr((1 << 24) // 5, 5, dtype=torch.float64, ones=False)
+            yield "dense5_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "grid2d4096":
+            import numpy as np
+            from oracle import oracle as O
+            c = O.make("grid2d", 4096, dtype=np.float64)
+            A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+            yield "grid2d_4096_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "grid2d":
             import numpy as np
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
