@@ -213,7 +213,7 @@ class DeviceSpmv:
     def CsrMV(d_temp_storage, temp_storage_bytes: int, d_values, d_row_offsets, d_column_indices,
               d_vector_x, d_vector_y, num_rows: int, num_cols: int, num_nonzeros: int,
               stream=None, debug_synchronous: bool = False, alpha: Optional[float] = None,
-              beta: Optional[float] = None) -> Tuple[int, int]:
+              beta: Optional[float] = None, _checked: bool = False) -> Tuple[int, int]:
         """y = A*x.  Returns ``(status, temp_storage_bytes)``.
 
         ``d_temp_storage is None`` -> size query only (no work), exactly like the
@@ -230,8 +230,9 @@ class DeviceSpmv:
         if d_temp_storage is None:
             temp_ptr = ctypes.c_void_p(0)
         else:
-            _validate(d_values, d_row_offsets, d_column_indices, d_vector_x, d_vector_y, int(num_rows), int(num_cols),
-                      int(num_nonzeros), "DeviceSpmv.CsrMV")
+            if not _checked:
+                _validate(d_values, d_row_offsets, d_column_indices, d_vector_x, d_vector_y, int(num_rows), int(num_cols),
+                          int(num_nonzeros), "DeviceSpmv.CsrMV")
             if not d_temp_storage.is_cuda or not d_temp_storage.is_contiguous():
                 raise MspmvError("DeviceSpmv.CsrMV: d_temp_storage must be a contiguous CUDA tensor")
             size = ctypes.c_size_t(min(int(temp_storage_bytes), d_temp_storage.numel() * d_temp_storage.element_size()))
@@ -262,6 +263,7 @@ class CsrMVWorkspace:
         info = launch_info(self.rows, self.nnz, self.value_bytes)
         self.bytes = int(info["temp_bytes"])
         self.buffer = torch.empty(self.bytes, dtype=torch.uint8, device=device)
+        self._checked = None            # the tensors of the last validated csrmv call through this workspace
         self.prepared_for = None        # the row_offsets TENSOR the coordinates in `buffer` belong to
         self.prepared_info = None       # launch_info at prepare time (tile shape / flags / tile count)
 
@@ -301,11 +303,19 @@ def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int
     cols = int(num_cols) if num_cols is not None else x.numel()
     if y is None:
         y = torch.empty(rows, dtype=values.dtype, device=values.device)
-    _validate(values, row_offsets, column_indices, x, y, rows, cols, nnz, "csrmv")
     if workspace is None:
+        _validate(values, row_offsets, column_indices, x, y, rows, cols, nnz, "csrmv")
         workspace = CsrMVWorkspace(rows, nnz, values.dtype, device=values.device)
-    elif workspace.rows != rows or workspace.nnz != nnz or workspace.dtype != values.dtype:
-        raise MspmvError("csrmv: the workspace was sized for another matrix shape or precision")
+    else:
+        if workspace.rows != rows or workspace.nnz != nnz or workspace.dtype != values.dtype:
+            raise MspmvError("csrmv: the workspace was sized for another matrix shape or precision")
+        # repeated calls with the very same tensor objects (a solver loop, a timing loop) are checked once: the
+        # workspace keeps the checked tensors alive, so their identities cannot be recycled
+        checked = workspace._checked
+        if not (checked is not None and checked[0] is values and checked[1] is row_offsets and checked[2] is column_indices
+                and checked[3] is x and checked[4] is y and checked[5] == cols):
+            _validate(values, row_offsets, column_indices, x, y, rows, cols, nnz, "csrmv")
+            workspace._checked = (values, row_offsets, column_indices, x, y, cols)
     if workspace.is_prepared_for(row_offsets, rows, nnz, values.dtype):
         # coordinates already in the workspace (CsrMVWorkspace.prepare): mspmv_csrmv_prepared_*
         vb = _value_bytes(values)
@@ -319,7 +329,7 @@ def csrmv(values, row_offsets, column_indices, x, y=None, num_cols: Optional[int
         return y
     status, _ = DeviceSpmv.CsrMV(workspace.buffer, workspace.bytes, values, row_offsets, column_indices, x, y,
                                  rows, cols, nnz, stream=stream, debug_synchronous=debug_synchronous,
-                                 alpha=alpha, beta=beta)
+                                 alpha=alpha, beta=beta, _checked=True)
     _check(status, "mspmv_csrmv")
     return y
 

@@ -182,7 +182,7 @@ static bool launch_dev_variant(const Layout &L, const Params<V> &p, bool axpby, 
         long long want = (long long) per_cu * device_cus();                                                \
         if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
         const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
-        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, chunk_log2);   \
+        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2);   \
     } while (0)
     if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
     else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
@@ -224,8 +224,9 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         // (small problems always fit the Infinity Cache: ordinary loads)
         const int fchunk_flag = (L.flags >> 24) & 0xf;
         const int fchunk = fchunk_flag == 0 ? FUSED_CHUNK_LOG2 : fchunk_flag == 15 ? 0 : fchunk_flag;
-        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, fchunk);
-        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, fchunk);
+        const size_t xl = (size_t) p.x_lds * sizeof(V);
+        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, fchunk);
+        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, fchunk);
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
     } else {
     // 1. tile boundary coordinates
@@ -265,15 +266,17 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             // run length.  Prepared band-major plans ask for one contiguous tile range per XCD instead.
             const int chunk_flag = (L.flags >> 24) & 0xf;
             const int chunk_log2 = ex.tile_map ? ex.tile_map : chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
-            // CSR streams: ordinary loads while the matrix fits the 256 MB Infinity Cache (it then
-            // stays there between the SpMVs of a solver), non-temporal loads beyond (they keep x in L2)
+            // CSR streams: ordinary loads while the matrix fits the 256 MB Infinity Cache (it then stays there
+            // between the SpMVs of a solver: 214 MB dense5 fp64 0.039 vs 0.053 ms, 208 MB grid2d 0.0438 vs
+            // 0.0447), non-temporal loads beyond (they keep x in L2: C2 -2 %, band5 -7 %, C4 -14 %, dense32 -7 %;
+            // only the 0.7-1.1 GB grids prefer ordinary loads, by 2-5 %; profiles/r02_stream_policy.txt)
             const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
-            const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (200ull << 20));
+            const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (256ull << 20));
             bool launched = false;
 #ifdef MSPMV_DEV
             launched = launch_dev_variant<V, BLOCK, IPT>(L, p, axpby, nt, coords, carries, chunk_log2, stream);
 #endif
-#define MSPMV_LAUNCH(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false>), dim3(grid), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, chunk_log2)
+#define MSPMV_LAUNCH(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2)
             if (!launched) {
                 if (axpby) { if (nt) MSPMV_LAUNCH(true, true); else MSPMV_LAUNCH(true, false); }
                 else if (nt) MSPMV_LAUNCH(false, true);
@@ -371,6 +374,8 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
     Params<V> p;
     p.values = d_values; p.row_end = d_row_offsets + 1; p.cols = d_cols; p.x = d_x; p.y = d_y;
     p.rows = rows; p.nnz = nnz; p.alpha = alpha; p.beta = beta;
+    // a tiny x is gathered from LDS by the vectorised tile kernels (dynamic shared memory of the launch)
+    p.x_lds = (cols > 0 && (size_t) cols * sizeof(V) <= (size_t) X_LDS_MAX_BYTES && !(L.flags & MSPMV_TUNE_NO_XLDS)) ? cols : 0;
     return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, ex);
 }
 template int csrmv_call<float>(void *, size_t *, const float *, const int32_t *, const int32_t *, const float *, float *, int32_t,
@@ -695,7 +700,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    int allowed = MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
+    int allowed = MSPMV_TUNE_NO_XLDS | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
                   MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xf000000;
 #ifdef MSPMV_DEV
     allowed |= MSPMV_DEV_FLAG_BITS;        // development kernels (mspmv_dev.hpp): never in the product library

@@ -59,7 +59,13 @@ struct Params {
     int nnz;
     V alpha;
     V beta;
+    int x_lds;                        // > 0: x has this many entries and the tile kernels gather it from LDS
 };
+
+// A tiny x (the reference's --dense=<cols> inputs: 5 or 32 entries) is copied to LDS once per block and
+// gathered there: the x gather then costs LDS reads instead of 12 vector-memory instructions per thread --
+// as many as the whole CSR stream needs.  Bounded so that residency barely changes.
+constexpr int X_LDS_MAX_BYTES = 4096;
 
 // ---------------------------------------------------------------------------
 // Merge-path diagonal search (reference
@@ -740,10 +746,10 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // and x gathers are issued, tile-relative row ends and products land in LDS (every slot of
 // both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
 // and the block is synchronised.
-template <typename V, int BLOCK, int IPT, bool NT, bool FL>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false>
 __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw, V *s_prod_raw,
-                                           int last_full_nz, int last_full_ro, unsigned *s_flag)
+                                           int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr)
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = threadIdx.x;
@@ -773,7 +779,7 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
-            xv[k][i] = p.x[in ? regs.col[k].get(i) : 0];
+            xv[k][i] = XL ? s_x[in ? regs.col[k].get(i) : 0] : p.x[in ? regs.col[k].get(i) : 0];
         }
     }
     // ---- stage row ends
@@ -818,7 +824,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
         __syncthreads();
         const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
         if (nz_tail && j < c1.y && j >= c0.y)
-            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0) : swz_prod(j - a0)] = ld_stream<NT>(p.values + j) * p.x[ld_stream<NT>(p.cols + j)];
+            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0) : swz_prod(j - a0)] =
+                ld_stream<NT>(p.values + j) * (XL ? s_x[ld_stream<NT>(p.cols + j)] : p.x[ld_stream<NT>(p.cols + j)]);
         const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
         const int r = i - first;
         if (ro_tail && r >= 0 && r < tile_rows) {
@@ -842,10 +849,11 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
 //    least IPT path items past every thread of a full tile.
 // Only whole chunks beyond the needed range are redirected to a cached address (no HBM bytes
 // for data the tile does not use).  This removes ~200 of the ~1100 instructions per wave per tile.
-template <typename V, int BLOCK, int IPT, bool NT, bool FL>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false>
 __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
                                                     const TileRegs<V, BLOCK, IPT> &regs,
-                                                    typename EndType<FL>::type *s_end_raw, V *s_prod_raw, unsigned *s_flag)
+                                                    typename EndType<FL>::type *s_end_raw, V *s_prod_raw, unsigned *s_flag,
+                                                    const V *s_x = nullptr)
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = threadIdx.x;
@@ -871,7 +879,7 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
 #pragma unroll
     for (int k = 0; k < CPT; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[k][i] = p.x[(unsigned) regs.col[k].get(i)];
+        for (int i = 0; i < 4; ++i) xv[k][i] = XL ? s_x[(unsigned) regs.col[k].get(i)] : p.x[(unsigned) regs.col[k].get(i)];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int q = tid + k * BLOCK;
@@ -917,12 +925,27 @@ __device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1,
 template <typename V, int BLOCK, int IPT, bool NT, bool FL>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw,
-                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag)
+                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr)
 {
-    if (tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro))      // block-uniform
+    const bool interior = tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro);      // block-uniform
+    if (s_x != nullptr) {              // block-uniform: x lives in LDS (tiny x only)
+        if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x);
+        else stage_tile_careful<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+    } else if (interior)
         stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag);
     else
         stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
+}
+
+// x -> LDS (dynamic shared memory, p.x_lds entries) at block start; nullptr when the call does not use it.
+// The copy is visible after the block's first barrier.
+template <typename V>
+__device__ __forceinline__ const V *stage_x_in_lds(const Params<V> &p, unsigned char *s_dyn, int block)
+{
+    if (p.x_lds <= 0) return nullptr;
+    V *s_x = reinterpret_cast<V *>(s_dyn);
+    for (int i = threadIdx.x; i < p.x_lds; i += block) s_x[i] = p.x[i];
+    return s_x;
 }
 
 // Block -> tile mapping of the one-tile-per-block launches.  Blocks are dealt round-robin to the 8
@@ -978,8 +1001,10 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
 #endif
 #define MSPMV_TR(i) do { if (TRACE && trace && threadIdx.x == 0 && trace_iter < 16) trace[((size_t) blockIdx.x * 16 + trace_iter) * 8 + (i)] = clock64(); } while (0)
 
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
     const int tid = threadIdx.x;
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
+    const V *const s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
     __syncthreads();
     // XCD_REMAP: blocks are dealt round-robin to the 8 XCDs (block b -> XCD
     // b % 8, observed; only speed depends on it); give each XCD's private L2 a
@@ -1020,7 +1045,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
         MSPMV_TR(0);
         if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MSPMV_TR(1);
-        stage_tile<V, BLOCK, IPT, NT, FL>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
+        stage_tile<V, BLOCK, IPT, NT, FL>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
         MSPMV_TR(2);
         // ---- the next tile's nonzero stream goes in flight, then the LDS phases of this tile
         if (has_next) issue_nonzero_loads<V, BLOCK, IPT, NT>(p, n0, n1, regs);
@@ -1263,9 +1288,11 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     __shared__ V s_wave_val[NW];
     __shared__ Coord s_coord[2];
 
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
     const int tid = threadIdx.x;
     const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
+    const V *const s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
     const long long total = (long long) p.rows + p.nnz;
     {
         const int wave = tid / WAVE;
@@ -1285,7 +1312,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
     TileRegs<V, BLOCK, IPT> regs;
     issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
-    stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
+    stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
     consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
     const Coord c0 = coords[tile];
     const Coord c1 = coords[tile + 1];
     Params<T> q;                                   // the CSR view the shared loaders take
-    q.values = p.values; q.row_end = p.row_end; q.cols = p.cols; q.x = p.x; q.y = p.y; q.rows = p.rows; q.nnz = p.nnz;
+    q.values = p.values; q.row_end = p.row_end; q.cols = p.cols; q.x = p.x; q.y = p.y; q.rows = p.rows; q.nnz = p.nnz; q.x_lds = 0;
     q.alpha = p.alpha; q.beta = p.beta;
     TileRegs<T, BLOCK, IPT> regs;
     issue_nonzero_loads<T, BLOCK, IPT, NT>(q, c0, c1, regs);

@@ -86,6 +86,44 @@ struct DeviceSpmv {
                                                      num_nonzeros, alpha, beta, (mspmv_stream_t) stream,
                                                      debug_synchronous ? 1 : 0);
     }
+
+    // ---- prepared band-major plan (extension, opt-in): build once, multiply many times
+    template <typename ValueT>
+    static hipError_t PlanSize(int num_rows, int num_cols, int num_nonzeros, int bands, size_t &plan_bytes, int &bands_used)
+    {
+        int32_t used = 0;
+        const hipError_t e = (hipError_t) mspmv_csrmv_plan_size(num_rows, num_cols, num_nonzeros, (int) sizeof(ValueT), bands, &plan_bytes, &used);
+        bands_used = used;
+        return e;
+    }
+    static hipError_t PlanBuild(void *d_plan, size_t plan_bytes, const float *d_values, const int *d_row_offsets,
+                                const int *d_column_indices, int num_rows, int num_cols, int num_nonzeros, int bands,
+                                hipStream_t stream = 0, bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_plan_build_f32(d_plan, plan_bytes, d_values, d_row_offsets, d_column_indices, num_rows, num_cols,
+                                                       num_nonzeros, bands, (mspmv_stream_t) stream, debug_synchronous ? 1 : 0);
+    }
+    static hipError_t PlanBuild(void *d_plan, size_t plan_bytes, const double *d_values, const int *d_row_offsets,
+                                const int *d_column_indices, int num_rows, int num_cols, int num_nonzeros, int bands,
+                                hipStream_t stream = 0, bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_plan_build_f64(d_plan, plan_bytes, d_values, d_row_offsets, d_column_indices, num_rows, num_cols,
+                                                       num_nonzeros, bands, (mspmv_stream_t) stream, debug_synchronous ? 1 : 0);
+    }
+    static hipError_t PlanApply(void *d_plan, size_t plan_bytes, const float *d_vector_x, float *d_vector_y, int num_rows, int num_cols,
+                                int num_nonzeros, int bands, float alpha = 1.f, float beta = 0.f, hipStream_t stream = 0,
+                                bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_plan_apply_f32(d_plan, plan_bytes, d_vector_x, d_vector_y, num_rows, num_cols, num_nonzeros, bands,
+                                                       alpha, beta, (mspmv_stream_t) stream, debug_synchronous ? 1 : 0);
+    }
+    static hipError_t PlanApply(void *d_plan, size_t plan_bytes, const double *d_vector_x, double *d_vector_y, int num_rows, int num_cols,
+                                int num_nonzeros, int bands, double alpha = 1.0, double beta = 0.0, hipStream_t stream = 0,
+                                bool debug_synchronous = false)
+    {
+        return (hipError_t) mspmv_csrmv_plan_apply_f64(d_plan, plan_bytes, d_vector_x, d_vector_y, num_rows, num_cols, num_nonzeros, bands,
+                                                       alpha, beta, (mspmv_stream_t) stream, debug_synchronous ? 1 : 0);
+    }
 };
 
 }  // namespace mspmv

@@ -29,6 +29,7 @@ struct RunConfig {
     int device = 0;                        // --device  (utils.h:465-472)
     double peak_gbs = -1;                  // --peak-gbs: overrides the bus-width formula of utils.h:491
     bool cache = false;                    // --cache: keep / reuse <mtx>.<fp32|fp64>.csrbin next to a Matrix Market file
+    bool timing = false;                   // --timing: print the wall-clock seconds of the ingest phases (non-quiet)
 };
 
 inline RunConfig ParseCommon(const CommandLineArgs &args, bool gpu_driver)
@@ -42,6 +43,7 @@ inline RunConfig ParseCommon(const CommandLineArgs &args, bool gpu_driver)
     args.GetCmdLineArgument("i", c.timing_iterations);
     args.GetCmdLineArgument("mtx", c.mtx);
     c.cache = args.CheckCmdLineFlag("cache");
+    c.timing = args.CheckCmdLineFlag("timing");
     args.GetCmdLineArgument("grid2d", c.grid2d);
     args.GetCmdLineArgument("grid3d", c.grid3d);
     args.GetCmdLineArgument("wheel", c.wheel);      // parsed by gpu_spmv.cu:719 only; cpu_spmv.cpp forgot it
@@ -102,7 +104,9 @@ void BuildCsr(const RunConfig &c, CsrMatrix<ValueT> &csr, void (*before_convert)
     if (c.cache && !c.mtx.empty()) {
         bin = c.mtx + (sizeof(ValueT) == 4 ? ".fp32.csrbin" : ".fp64.csrbin");
         struct stat sm, sb;
+        const double t0 = omp_get_wtime();
         if (stat(c.mtx.c_str(), &sm) == 0 && stat(bin.c_str(), &sb) == 0 && sb.st_mtime >= sm.st_mtime && csr.LoadBinary(bin)) {
+            ingest_times().cache_load_s = omp_get_wtime() - t0;
             if (!c.quiet) { printf("Reading binary CSR image... done. "); fflush(stdout); }
             if (csr.num_rows == 1 || csr.num_cols == 1 || csr.num_nonzeros == 1) { if (!c.quiet) printf("Trivial dataset\n"); exit(0); }
             printf("%s, ", c.mtx.c_str()); fflush(stdout);
@@ -113,8 +117,12 @@ void BuildCsr(const RunConfig &c, CsrMatrix<ValueT> &csr, void (*before_convert)
     CooMatrix<ValueT> coo;
     BuildInput(c, coo);
     if (before_convert) before_convert(c, coo.num_nonzeros());
+    double t0 = omp_get_wtime();
     csr.Init(coo);
+    ingest_times().convert_s = omp_get_wtime() - t0;
+    t0 = omp_get_wtime();
     if (!bin.empty() && !csr.SaveBinary(bin) && !c.quiet) fprintf(stderr, "(could not write %s)\n", bin.c_str());
+    if (!bin.empty()) ingest_times().cache_save_s = omp_get_wtime() - t0;
 }
 
 /// Stats line / block, histogram and optional dump (gpu_spmv.cu:503-516).
@@ -122,6 +130,11 @@ template <typename ValueT>
 void ReportMatrix(const RunConfig &c, const CsrMatrix<ValueT> &csr)
 {
     csr.Stats().Display(!c.quiet);
+    if (!c.quiet && c.timing) {
+        const IngestTimes &t = ingest_times();
+        printf("\n\t ingest seconds: read %.3f, parse %.3f, COO->CSR %.3f, cache save %.3f, cache load %.3f (%d threads)\n",
+               t.read_s, t.parse_s, t.convert_s, t.cache_save_s, t.cache_load_s, omp_get_max_threads());
+    }
     if (!c.quiet) {
         printf("\n");
         csr.DisplayHistogram();

@@ -9,7 +9,15 @@
 //
 //   gpu_spmv [--device=<id>] [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32]
 //            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor]
+//            [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] [--mg-exchange=peer|rccl]
 //            --mtx=<file> | --dense=<cols> [--size=<nnz>] | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
+//
+// Extra method lines of this project (non-quiet only; the CSV keeps the reference's columns):
+//   --prepared   the stateless call with the tile coordinates found once (mspmv_csrmv_prepare)
+//   --plan       the prepared band-major plan (mspmv_csrmv_plan_*): set-up = the plan build
+//   --gpus=G     the matrix merge-partitioned over G GPUs of this node through the C multi-GPU operator
+//                (mspmv_mg_plan_*; the reference has a single --device, utils.h:465-474), one line per G;
+//                --mg-one-device runs all parts on --device (a functional run on a 1-GPU box)
 //
 // alpha/beta: the reference parses them but its CsrMV forces 1/0, so any other
 // value makes the reference print FAIL; here they are passed to the
@@ -167,6 +175,95 @@ float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> 
     return ms;
 }
 
+// the prepared band-major plan (extension): set-up = mspmv_csrmv_plan_build_*, then the same protocol
+template <typename V>
+float TestPlan(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
+               const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms, int bands, int &bands_used)
+{
+    size_t bytes = 0;
+    HIP_OK(mspmv::DeviceSpmv::PlanSize<V>(p.rows, p.cols, p.nnz, bands, bytes, bands_used));
+    void *d_plan = nullptr;
+    HIP_OK(hipMalloc(&d_plan, bytes));
+    GpuTimer setup; setup.Start();
+    HIP_OK(mspmv::DeviceSpmv::PlanBuild(d_plan, bytes, p.d_values, p.d_row_offsets, p.d_cols, p.rows, p.cols, p.nnz, bands_used));
+    setup.Stop(); setup_ms = setup.ElapsedMillis();
+    HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));
+    HIP_OK(mspmv::DeviceSpmv::PlanApply(d_plan, bytes, p.d_x, p.d_y, p.rows, p.cols, p.nnz, bands_used, (V) c.alpha, (V) c.beta, 0, !c.quiet));
+    if (!c.quiet) Verify(c, a, x, gold, p.d_y, c.alpha == 1.0f && c.beta == 0.0f);
+    GpuTimer timer; timer.Start();
+    for (int it = 0; it < iterations; ++it)
+        HIP_OK(mspmv::DeviceSpmv::PlanApply(d_plan, bytes, p.d_x, p.d_y, p.rows, p.cols, p.nnz, bands_used, (V) c.alpha, (V) c.beta));
+    timer.Stop();
+    const float ms = timer.ElapsedMillis() / iterations;
+    HIP_OK(hipFree(d_plan));
+    return ms;
+}
+
+// the matrix cut into G swaths of the merge path, one per GPU (or all on one device), through the C multi-GPU
+// operator: y = A*x per step = every part's CsrMV + one carry exchange, below the C ABI.  Timed on the host
+// clock around N back-to-back steps + a plan-wide synchronise (events of one device cannot bracket G streams).
+template <typename V>
+float TestMultiGpu(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &gold, int parts,
+                   bool one_device, int exchange, int iterations, float &setup_ms, int &exchange_used)
+{
+    int ndev = 0; HIP_OK(hipGetDeviceCount(&ndev));
+    if (!one_device && parts > ndev) { printf("\t(skipped: %d GPUs visible)\n", ndev); setup_ms = 0; return -1.f; }
+    CpuTimer setup; setup.Start();
+    std::vector<int64_t> off64((size_t) a.num_rows + 1), row_split((size_t) parts + 1), nz_split((size_t) parts + 1);
+    for (size_t i = 0; i < off64.size(); ++i) off64[i] = a.row_offsets[i];
+    HIP_OK((hipError_t) mspmv_mg_partition(off64.data(), a.num_rows, a.num_nonzeros, parts, row_split.data(), nz_split.data()));
+    std::vector<int32_t> ids((size_t) parts), devs((size_t) parts);
+    for (int g = 0; g < parts; ++g) { ids[g] = g; devs[g] = one_device ? c.device : g; }
+    mspmv_mg_plan_t *plan = nullptr;
+    HIP_OK((hipError_t) mspmv_mg_plan_create(&plan, parts, parts, ids.data(), devs.data(), row_split.data(), nz_split.data(), a.num_cols,
+                                             (int) sizeof(V), exchange, nullptr));
+    std::vector<void *> owned;                       // the parts' CSR arrays (caller-owned, per the plan's contract)
+    for (int g = 0; g < parts; ++g) {
+        HIP_OK(hipSetDevice(devs[g]));
+        const int64_t lr = row_split[g + 1] - row_split[g] + 1, ln = nz_split[g + 1] - nz_split[g];
+        std::vector<int32_t> lo((size_t) lr + 1);
+        HIP_OK((hipError_t) mspmv_mg_local_offsets(off64.data(), a.num_rows, row_split[g], row_split[g + 1], nz_split[g], nz_split[g + 1], lo.data()));
+        void *d_off = nullptr, *d_col = nullptr, *d_val = nullptr;
+        HIP_OK(hipMalloc(&d_off, sizeof(int32_t) * lo.size()));
+        HIP_OK(hipMalloc(&d_col, sizeof(int32_t) * std::max<int64_t>(ln, 1)));
+        HIP_OK(hipMalloc(&d_val, sizeof(V) * std::max<int64_t>(ln, 1)));
+        HIP_OK(hipMemcpy(d_off, lo.data(), sizeof(int32_t) * lo.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_col, a.column_indices.data() + nz_split[g], sizeof(int32_t) * ln, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_val, a.values.data() + nz_split[g], sizeof(V) * ln, hipMemcpyHostToDevice));
+        HIP_OK((hipError_t) mspmv_mg_plan_set_part(plan, g, d_val, (const int32_t *) d_off, (const int32_t *) d_col));
+        HIP_OK(hipMemcpy(mspmv_mg_plan_x(plan, g), x.data(), sizeof(V) * a.num_cols, hipMemcpyHostToDevice));
+        owned.push_back(d_off); owned.push_back(d_col); owned.push_back(d_val);
+    }
+    setup.Stop(); setup_ms = setup.ElapsedMillis();
+    mspmv_mg_info_t info; HIP_OK((hipError_t) mspmv_mg_plan_info(plan, &info)); exchange_used = info.exchange;
+    HIP_OK((hipError_t) mspmv_mg_csrmv(plan));
+    HIP_OK((hipError_t) mspmv_mg_synchronize(plan));
+    if (!c.quiet) {
+        std::vector<V> y((size_t) a.num_rows);
+        for (int g = 0; g < parts; ++g) {
+            HIP_OK(hipSetDevice(devs[g]));
+            HIP_OK(hipMemcpy(y.data() + row_split[g], mspmv_mg_plan_y(plan, g), sizeof(V) * (row_split[g + 1] - row_split[g]), hipMemcpyDeviceToHost));
+        }
+        const int bad = CompareResultsReferenceRule(y.data(), gold.data(), a.num_rows, true);
+        printf("\t%s\n", bad ? "FAIL" : "PASS");
+        if (c.strict) {
+            double worst = 0;
+            const long long v = StrictCheck(a.num_rows, a.row_offsets.data(), a.column_indices.data(), a.values.data(), x.data(), y.data(),
+                                            16 + parts, &worst);
+            printf("\tstrict check: %s (%lld rows outside tolerance, worst ratio %.3g)\n", v ? "FAIL" : "PASS", v, worst);
+        }
+    }
+    CpuTimer timer; timer.Start();
+    for (int it = 0; it < iterations; ++it) HIP_OK((hipError_t) mspmv_mg_csrmv(plan));
+    HIP_OK((hipError_t) mspmv_mg_synchronize(plan));
+    timer.Stop();
+    const float ms = timer.ElapsedMillis() / iterations;
+    HIP_OK((hipError_t) mspmv_mg_plan_destroy(plan));
+    for (size_t i = 0; i < owned.size(); ++i) { HIP_OK(hipSetDevice(devs[i / 3])); HIP_OK(hipFree(owned[i])); }
+    HIP_OK(hipSetDevice(c.device));
+    return ms;
+}
+
 template <typename V> struct Roc;
 template <> struct Roc<float> {
     static constexpr auto analysis = rocsparse_scsrmv_analysis; static constexpr auto csrmv = rocsparse_scsrmv;
@@ -235,9 +332,12 @@ float TestRocsparseHybmv(const RunConfig &c, const CsrMatrix<V> &a, const std::v
     return ms;
 }
 
+struct Extras { bool vendor = true, prepared = false, plan = false, mg_one_device = false; int plan_bands = 0, mg_exchange = MSPMV_MG_EXCHANGE_AUTO; std::vector<int> gpus; };
+
 template <typename V>
-void Run(const RunConfig &c, const Device &dev, bool vendor, bool prepared_too)
+void Run(const RunConfig &c, const Device &dev, const Extras &ex)
 {
+    const bool vendor = ex.vendor, prepared_too = ex.prepared;
     CsrMatrix<V> csr;
     BuildCsr<V>(c, csr, [](const RunConfig &cc, int nnz) {
         const int it = cc.timing_iterations == -1 ? AdaptiveIterations(nnz, 50000ull) : cc.timing_iterations;
@@ -268,6 +368,25 @@ void Run(const RunConfig &c, const Device &dev, bool vendor, bool prepared_too)
         DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
     }
 
+    if (ex.plan && !c.quiet) {                  // extra method line, never in the CSV
+        int used = 0;
+        printf("\n\nMerge-based CsrMV (prepared band-major plan), "); fflush(stdout);
+        avg_ms = TestPlan(c, csr, x, y_in, gold, p, iterations, setup_ms, ex.plan_bands, used);
+        printf("\t%d column band(s)\n", used);
+        DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+        DisplayRoofline((int) sizeof(V), avg_ms, csr.num_rows, csr.num_cols, csr.num_nonzeros, dev.giga_bandwidth);
+    }
+    if (!c.quiet && c.alpha == 1.0f && c.beta == 0.0f)
+        for (int parts : ex.gpus) {
+            int used = 0;
+            printf("\n\nMerge-based CsrMV (%d GPU%s%s), ", parts, parts == 1 ? "" : "s", ex.mg_one_device ? ", all parts on one device" : ""); fflush(stdout);
+            avg_ms = TestMultiGpu(c, csr, x, gold, parts, ex.mg_one_device, ex.mg_exchange, iterations, setup_ms, used);
+            if (avg_ms < 0) continue;
+            printf("\tcarry exchange: %s, %d bytes per step\n", used == MSPMV_MG_EXCHANGE_PEER ? "peer reads" : "RCCL all-gather",
+                   parts * (int) sizeof(V));
+            DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth * parts);
+        }
+
     if (vendor) {
         rocsparse_handle handle;
         ROCSPARSE_OK(rocsparse_create_handle(&handle));
@@ -292,16 +411,31 @@ int main(int argc, char **argv)
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
-               "[--no-strict] [--no-vendor] [--cache] [--prepared]\n"
+               "[--no-strict] [--no-vendor] [--cache] [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
+               "[--mg-exchange=peer|rccl]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;
     }
     const RunConfig c = ParseCommon(args, true);
     const Device dev = DeviceInit(c);
-    const bool vendor = !args.CheckCmdLineFlag("no-vendor");
-    const bool prepared_too = args.CheckCmdLineFlag("prepared");
-    if (c.fp32) Run<float>(c, dev, vendor, prepared_too); else Run<double>(c, dev, vendor, prepared_too);
+    Extras ex;
+    ex.vendor = !args.CheckCmdLineFlag("no-vendor");
+    ex.prepared = args.CheckCmdLineFlag("prepared");
+    ex.plan = args.CheckCmdLineFlag("plan");
+    args.GetCmdLineArgument("plan", ex.plan_bands);
+    ex.mg_one_device = args.CheckCmdLineFlag("mg-one-device");
+    std::string gpus, exchange;
+    args.GetCmdLineArgument("gpus", gpus);
+    args.GetCmdLineArgument("mg-exchange", exchange);
+    if (exchange == "peer") ex.mg_exchange = MSPMV_MG_EXCHANGE_PEER; else if (exchange == "rccl") ex.mg_exchange = MSPMV_MG_EXCHANGE_RCCL;
+    for (size_t i = 0; i < gpus.size();) {
+        size_t j = gpus.find(',', i); if (j == std::string::npos) j = gpus.size();
+        const int g = atoi(gpus.substr(i, j - i).c_str());
+        if (g >= 1 && g <= MSPMV_MG_MAX_PARTS) ex.gpus.push_back(g);
+        i = j + 1;
+    }
+    if (c.fp32) Run<float>(c, dev, ex); else Run<double>(c, dev, ex);
     HIP_OK(hipDeviceSynchronize());
     printf("\n");
     return 0;

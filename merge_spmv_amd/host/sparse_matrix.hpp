@@ -32,6 +32,10 @@
 
 namespace mspmv_host {
 
+/// Wall-clock seconds of the last ingest, by phase (drivers print them with --timing).
+struct IngestTimes { double read_s = 0, parse_s = 0, convert_s = 0, cache_save_s = 0, cache_load_s = 0; };
+inline IngestTimes &ingest_times() { static IngestTimes t; return t; }
+
 /// Row-length statistics (reference GraphStats, sparse_matrix.h:59-107).
 struct GraphStats {
     int num_rows = 0, num_cols = 0, num_nonzeros = 0;
@@ -148,6 +152,7 @@ struct CooMatrix {
     void InitMarket(const std::string &filename, ValueT default_value = 1.0, bool verbose = false, bool serial = false)
     {
         if (verbose) { printf("Reading... "); fflush(stdout); }
+        const double t_begin = omp_get_wtime();
         std::string buf;
         {
             std::ifstream ifs(filename.c_str(), std::ifstream::in | std::ifstream::binary);
@@ -159,6 +164,8 @@ struct CooMatrix {
             if (size > 0) ifs.read(&buf[0], size);
         }
         if (verbose) { printf("Parsing... "); fflush(stdout); }
+        const double t_read = omp_get_wtime();
+        ingest_times().read_s = t_read - t_begin;
         // ---- lines: only newline-terminated ones count; a line of >= 1024 characters ends the file
         const size_t n = buf.size();
         std::vector<size_t> starts;                        // start offset of every terminated line
@@ -278,6 +285,7 @@ struct CooMatrix {
                 val[at + 1] = (ValueT) q.v * (ValueT) (q.skew ? -1 : 1);
             }
         }
+        ingest_times().parse_s = omp_get_wtime() - t_read;
         if (verbose) { printf("done. "); fflush(stdout); }
     }
 };

@@ -612,3 +612,29 @@ def test_nan_and_inf_stay_in_their_rows(M, prec, flags):
             touched[r] = True
             assert not np.isfinite(y_bad[r]), r
     assert np.array_equal(y_bad[~touched], y_clean[~touched])          # bit for bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("cols", [1, 5, 32, 511, 512, 1024, 1025])
+def test_tiny_x_is_gathered_from_lds(M, prec, cols):
+    """x of at most 4 KB (the reference's --dense=<cols> inputs) is copied to LDS once per block and gathered
+    there; the result must be BITWISE what the global-memory gather gives (MSPMV_TUNE_NO_XLDS = 0x80000), on the
+    small-problem kernel, the large-problem kernel and with alpha/beta, incl. ragged array tails."""
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(cols)
+    for rows, hi in ((3001, 9), (50003, 40)):
+        csr = random_csr(rng, rows, cols, rng.integers(0, hi, rows), dtype)
+        x = rng.uniform(-1, 1, cols).astype(dtype)
+        got = {}
+        for flags in (0, 0x80000, 16, 16 | 0x80000):
+            try:
+                M.set_tuning(vb, 0, 0, flags)
+                y, ws = run_gpu(M, csr, x)
+                y2, _ = run_gpu(M, csr, x, alpha=1.5, beta=0.0)
+            finally:
+                M.set_tuning(vb)
+            check_strict(M, csr, x, y)
+            got[flags] = (y, y2)
+        assert np.array_equal(got[0][0], got[0x80000][0]) and np.array_equal(got[0][1], got[0x80000][1])
+        assert np.array_equal(got[16][0], got[16 | 0x80000][0]) and np.array_equal(got[16][1], got[16 | 0x80000][1])

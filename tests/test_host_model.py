@@ -301,3 +301,42 @@ def test_binary_csr_cache_of_the_drivers(tmp_path):
         f.write("% touched\n")
     os.utime(mtx, None)
     assert "Reading binary CSR image" not in run("--cache")
+
+
+def test_eval_csrmv_sweep_and_ingest_timing(tmp_path):
+    """tools/eval_csrmv.sh = the reference's eval_csrmv.sh:8-17 for these drivers: its header, then one `--quiet` CSV
+    line per Matrix Market file; --timing prints the ingest phases (non-quiet only, so the CSV is untouched)."""
+    import subprocess
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools/eval_csrmv.sh"), os.path.join(ROOT, "tests/golden/mtx"), "cpu_spmv", "--i=1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == ("file, num_rows, num_cols, num_nonzeros, row_length_mean, row_length_std_dev, row_length_variation, "
+                        "row_length_skewness, method_name, setup_ms, avg_spmv_ms, gflops, effective_GBs")
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "tests/golden/mtx")) if f.endswith(".mtx"))
+    body = [l for l in lines[1:] if l.strip()]
+    assert len(body) >= 4 and all(".mtx, " in l and "Merge CsrMV, " in l for l in body) and len(body) <= len(files)
+    exe = os.path.join(ROOT, "merge_spmv_amd", "cpu_spmv")
+    src = os.path.join(ROOT, "tests/golden/mtx/giant_row.mtx")
+    r = subprocess.run([exe, "--mtx=" + src, "--i=1", "--timing"], capture_output=True, text=True, timeout=120)
+    assert "ingest seconds: read " in r.stdout and "COO->CSR" in r.stdout
+    q = subprocess.run([exe, "--mtx=" + src, "--i=1", "--timing", "--quiet"], capture_output=True, text=True, timeout=120)
+    assert "ingest seconds" not in q.stdout
+
+
+def test_pattern_mtx_writer_round_trips(H, tmp_path):
+    """mspmv_host_write_pattern_mtx (the corpus-scale ingest tool's writer) -> InitMarket gives back the entries,
+    mirrored for a symmetric banner"""
+    rng = np.random.default_rng(8)
+    n = 5000
+    r = rng.integers(0, 300, n).astype(np.int32); c = rng.integers(0, 300, n).astype(np.int32)
+    H.mspmv_host_write_pattern_mtx.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_int]
+    for sym in (0, 1):
+        path = str(tmp_path / f"w{sym}.mtx")
+        assert H.mspmv_host_write_pattern_mtx(path.encode(), 300, 300, n, r.ctypes.data, c.ctypes.data, sym) == 0
+        got = _host_market(H, "mtx", path, False)
+        from oracle import oracle as O
+        want = O.csr_from_coo(*O.coo_market(path))
+        assert got[0] == "ok" and got[4] == want.row_offsets.tolist() and got[5] == want.column_indices.tolist()
+        assert got[3] == n + (int((r != c).sum()) if sym else 0)

@@ -16,8 +16,8 @@ gpu = pytest.mark.gpu
 def test_plan_size_query_conventions():
     lib = M.load_library()
     size = ctypes.c_size_t(0); bands = ctypes.c_int32(0)
-    # automatic band count: 1 while x fits an XCD's L2, then multiples of 8 with <= 2 MiB of x per band
-    for cols, vb, want in ((1000, 4, 1), (700_000, 4, 1), (3_125_000, 4, 8), (3_125_000, 8, 16), (16_000_000, 4, 32),
+    # automatic band count: 1 while x fits an XCD's L2, then the fewest multiple of 8 with <= 3.25 MiB of x per band
+    for cols, vb, want in ((1000, 4, 1), (700_000, 4, 1), (3_125_000, 4, 8), (3_125_000, 8, 8), (16_000_000, 4, 24),
                            (200_000_000, 8, 64)):
         assert lib.mspmv_csrmv_plan_size(1000, cols, 5000, vb, 0, ctypes.byref(size), ctypes.byref(bands)) == 0
         assert bands.value == want, (cols, vb, bands.value)

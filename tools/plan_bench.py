@@ -23,7 +23,10 @@ for label, A, x in sweep.workloads(names):
     vb = A.values.element_size()
     balg = A.nnz * (vb + 4) + (A.rows + 1) * 4 + A.rows * vb + A.cols * vb
     ws = M.CsrMVWorkspace(A.rows, A.nnz, A.values.dtype); y0 = torch.empty(A.rows, dtype=A.values.dtype, device="cuda")
-    base = t(lambda: M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y0, num_cols=A.cols, workspace=ws))
+    M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y0, num_cols=A.cols, workspace=ws)
+    # PLAN_SKIP_BASE=1 (profiling runs): only one stateless call, so the kernel statistics are the plan's
+    base = float("nan") if os.environ.get("PLAN_SKIP_BASE") == "1" else \
+        t(lambda: M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y0, num_cols=A.cols, workspace=ws))
     print(f"== {label}: rows {A.rows} nnz {A.nnz} x {A.cols * vb / 1e6:.1f} MB | stateless {base:.4f} ms = {balg / base / 1e6:.0f} GB/s B_alg", flush=True)
     for bands in band_sets:
         try:
