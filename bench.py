@@ -100,7 +100,7 @@ def cpu_baseline(A, x, label, budget_s=12.0, max_iters=40):
             "kernel": "merge_spmv_amd/host/merge_csrmv.hpp (product OpenMP merge-path CsrMV; -O3 -march=x86-64-v3 -ffp-contract=off)",
             "sample": f"{label} ({nnz} nnz), {iters.value} SpMVs after 4 warm-ups, {avg.value:.2f} ms each",
             "threads": threads, "hardware_threads": int(H.mspmv_host_hardware_threads()), "cpu_quota": quota, "cpuset": cpuset,
-            "binding": (f"one thread per physical core of socket 0 ({packages.value} socket(s) visible)" if pinned.value
+            "binding": (f"one thread per physical core of socket 0, spread evenly over its cores ({packages.value} socket(s) visible)" if pinned.value
                         else "unbound (socket 0 has fewer allowed cores than threads, or affinity calls are refused)"),
             "first_touch": "every thread first-touches the swath of the arrays it streams",
             "effective_GBs": round(effective_bytes(A.rows, nnz, val.dtype.itemsize) / dt / 1e9, 2)}
@@ -179,7 +179,7 @@ def main():
         if world == 1:
             A = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
         else:
-            shard = MG.rmat_shard(args.c5_scale, nnz_total, rank, world, tdt, device=dev, seed=G.SEED_C5)
+            shard = MG.rmat_shard(args.c5_scale, nnz_total, rank, world, tdt, device=dev, seed=G.SEED_C5, use_dist=True)
     else:
         rows = C2_ROWS_PER_GPU * world
         cols = C2_ROWS_PER_GPU if workload == "c2" else C2_NPR

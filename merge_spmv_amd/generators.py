@@ -152,12 +152,13 @@ def rmat_edges(scale: int, edge_begin: int, edge_end: int, device, seed: int,
     return row, col
 
 
-def rmat_row_counts(scale: int, edges: int, device, seed: int = SEED_C5, chunk: int = 1 << 25) -> torch.Tensor:
-    """int64 [2^scale]: how many of the R-MAT edges [0, edges) fall in each row (one hashing pass, nothing kept)."""
+def rmat_row_counts(scale: int, edges: int, device, seed: int = SEED_C5, chunk: int = 1 << 25, edge_begin: int = 0) -> torch.Tensor:
+    """int64 [2^scale]: how many of the R-MAT edges [edge_begin, edge_begin + edges) fall in each row (one hashing pass,
+    nothing kept)."""
     n = 1 << scale
     counts = torch.zeros(n, dtype=torch.int64, device=device)
-    for e0 in range(0, edges, chunk):
-        r, _ = rmat_edges(scale, e0, min(e0 + chunk, edges), device, seed)
+    for e0 in range(edge_begin, edge_begin + edges, chunk):
+        r, _ = rmat_edges(scale, e0, min(e0 + chunk, edge_begin + edges), device, seed)
         counts += torch.bincount(r, minlength=n)
     return counts
 

@@ -4,7 +4,7 @@
 // code with the oracle.
 //
 //   cpu_spmv [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32] [--threads=<n>]
-//            [--alpha=<a>] [--beta=<b>]
+//            [--alpha=<a>] [--beta=<b>] [--pin] [--timing] [--cache]
 //            --mtx=<file> | --dense=<cols> | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
 //
 // Differences from the reference, all deliberate:
@@ -15,7 +15,10 @@
 //    CsrMV") where the reference calls MKL (cpu_spmv.cpp:417-491);
 //  * besides the reference's vacuous PASS/FAIL rule, a strict per-row tolerance
 //    check is printed (--no-strict to skip);
-//  * --wheel is honoured (the reference never parses it, cpu_spmv.cpp:721-732).
+//  * --wheel is honoured (the reference never parses it, cpu_spmv.cpp:721-732);
+//  * --pin adds a "Merge CsrMV (socket 0, first touch)" line: the same kernel timed on private copies of the arrays
+//    first-touched by the threads that stream them, one thread per physical core of socket 0 (BASELINE config 1:
+//    "single socket"; the reference relies on numactl / KMP_AFFINITY outside the program for that).
 #include <omp.h>
 
 #include <cstring>
@@ -23,6 +26,7 @@
 
 #include "driver_common.hpp"
 #include "merge_csrmv.hpp"
+#include "cpu_bench.hpp"
 
 using namespace mspmv_host;
 
@@ -65,7 +69,7 @@ float TimeMethod(const RunConfig &c, const CsrMatrix<V> &a, const V *x, const V 
 }
 
 template <typename V>
-void Run(const RunConfig &c)
+void Run(const RunConfig &c, bool pin)
 {
     CsrMatrix<V> csr;
     BuildCsr(c, csr);
@@ -100,6 +104,19 @@ void Run(const RunConfig &c)
     });
     DisplayPerf(c.quiet, (int) sizeof(V), 0.0, avg, csr.num_rows, csr.num_nonzeros, -1);
     if (!c.quiet) DisplayRoofline((int) sizeof(V), avg, csr.num_rows, csr.num_cols, csr.num_nonzeros, -1);
+    if (pin && !c.quiet) {                    // extra method line, never in the CSV (its columns are the reference's)
+        printf("\n\nMerge CsrMV (socket 0, first touch), "); fflush(stdout);
+        double avg_ms = 0; int done = 0, pinned = 0, packages = 0;
+        const int st = BenchMerge<V>(threads, 1, csr.num_rows, csr.num_cols, csr.num_nonzeros, csr.row_offsets.data(),
+                                     csr.column_indices.data(), csr.values.data(), x.data(), 1e9, iterations, &avg_ms, &done, &pinned,
+                                     &packages, y.data());
+        if (st != 0) { printf("\tskipped (allocation failed)\n"); return; }
+        printf("\t%d threads, %s (%d socket(s) visible)\n", threads,
+               pinned ? "one per physical core of socket 0, spread evenly over its cores" : "NOT bound (socket 0 has fewer allowed cores, or affinity refused)", packages);
+        const int bad = CompareResultsReferenceRule(y.data(), gold.data(), csr.num_rows, true);
+        printf("\t%s\n", bad ? "FAIL" : "PASS");
+        DisplayPerf(c.quiet, (int) sizeof(V), 0.0, avg_ms, csr.num_rows, csr.num_nonzeros, -1);
+    }
 }
 
 }  // namespace
@@ -109,14 +126,15 @@ int main(int argc, char **argv)
     CommandLineArgs args(argc, argv);
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--quiet] [--v] [--v2] [--threads=<OMP threads>] [--i=<timing iterations>] [--fp32] "
-               "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--no-strict] [--cache]\n"
+               "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--no-strict] [--cache] [--pin] [--timing]\n"
                "\t--mtx=<matrix market file>\n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;
     }
     const RunConfig c = ParseCommon(args, false);
     omp_set_num_threads(c.threads > 0 ? c.threads : UsableCpus());     // also sizes the matrix-building regions
-    if (c.fp32) Run<float>(c); else Run<double>(c);
+    const bool pin = args.CheckCmdLineFlag("pin");
+    if (c.fp32) Run<float>(c, pin); else Run<double>(c, pin);
     printf("\n");
     return 0;
 }

@@ -307,16 +307,27 @@ def uniform_shard(rows: int, cols: int, nnz_per_row: int, part: int, parts: int,
 
 
 def rmat_shard(scale: int, edges: int, part: int, parts: int, dtype, device="cuda", seed: Optional[int] = None,
-               return_global_offsets: bool = False):
+               return_global_offsets: bool = False, dist_group=None, use_dist: bool = False):
     """Rank `part`'s swath of generators.rmat_csr(scale, edges) (C5: scale 26, 2e9 edges, fp64), built on
     `device` without materialising the whole matrix: one pass over the edge ids counts the global row
     lengths (so every rank finds the same partition), a second keeps only the edges of the rows the swath
-    touches (plus the row its right boundary cuts).  The matrix is independent of `parts`."""
+    touches (plus the row its right boundary cuts).  The matrix is independent of `parts`.
+    use_dist: the counting pass is split over the ranks of torch.distributed (each hashes 1/parts of the
+    edge ids) and summed with one all-reduce -- set-up work, not part of any timed region."""
     import torch
     from . import generators as G
     seed = G.SEED_C5 if seed is None else seed
     n = 1 << scale
-    counts = G.rmat_row_counts(scale, edges, device, seed)
+    if use_dist and parts > 1:
+        import torch.distributed as dist
+        e0 = edges * part // parts; e1 = edges * (part + 1) // parts
+        counts = G.rmat_row_counts(scale, e1 - e0, device, seed, edge_begin=e0)
+        if dist.get_backend(dist_group) == "gloo":
+            c = counts.cpu(); dist.all_reduce(c, group=dist_group); counts = c.to(device)
+        else:
+            dist.all_reduce(counts, group=dist_group)
+    else:
+        counts = G.rmat_row_counts(scale, edges, device, seed)
     off_dev = torch.zeros(n + 1, dtype=torch.int64, device=device)
     torch.cumsum(counts, 0, out=off_dev[1:])
     off = off_dev.cpu().numpy()
