@@ -323,7 +323,18 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
         plan->local.push_back(q);
     }
     // exchange backend
-    if (exchange == MSPMV_MG_EXCHANGE_AUTO) exchange = plan->whole ? MSPMV_MG_EXCHANGE_PEER : MSPMV_MG_EXCHANGE_RCCL;
+    if (exchange == MSPMV_MG_EXCHANGE_AUTO) {
+        exchange = plan->whole ? MSPMV_MG_EXCHANGE_PEER : MSPMV_MG_EXCHANGE_RCCL;
+        // peer reads need every pair of distinct devices to map each other's memory (true on an xGMI node); else RCCL
+        if (exchange == MSPMV_MG_EXCHANGE_PEER && distinct_devices)
+            for (int i = 0; i < local_parts && exchange == MSPMV_MG_EXCHANGE_PEER; ++i)
+                for (int j = 0; j < local_parts; ++j) {
+                    int can = 1;
+                    if (device_ids[i] != device_ids[j] && (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) != hipSuccess || !can)) {
+                        (void) hipGetLastError(); exchange = MSPMV_MG_EXCHANGE_RCCL; break;
+                    }
+                }
+    }
     if (exchange == MSPMV_MG_EXCHANGE_PEER && local_parts != parts) return fail(kErrInvalid);       // peers live in this process
     if (exchange == MSPMV_MG_EXCHANGE_RCCL && !distinct_devices) return fail(kErrInvalid);  // one RCCL rank per device
     if (exchange == MSPMV_MG_EXCHANGE_RCCL && !plan->whole && !id128) return fail(kErrInvalid);

@@ -352,17 +352,63 @@ struct CsrMatrix {
         num_rows = coo.num_rows; num_cols = coo.num_cols; num_nonzeros = coo.num_nonzeros();
         const size_t n = (size_t) num_nonzeros;
         row_offsets.assign((size_t) num_rows + 1, 0);
+        const int T = std::max(1, omp_get_max_threads());
+        // ---- row histogram, all threads (relaxed atomic increments: collisions are rare), indices validated on the way
+        //      (the reference never checks: a row or column outside the matrix becomes an out-of-bounds access)
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
         for (size_t k = 0; k < n; ++k) {
-            if (coo.row[k] < 0 || coo.row[k] >= num_rows) throw MarketError("row index out of range");
-            // (the reference never checks: a column outside [0, num_cols) becomes an out-of-bounds gather of x)
-            if ((unsigned) coo.col[k] >= (unsigned) num_cols) throw MarketError("col index out of range");
-            ++row_offsets[(size_t) coo.row[k] + 1];
+            const int r = coo.row[k];
+            if (r < 0 || r >= num_rows) { bad |= 1; continue; }
+            if ((unsigned) coo.col[k] >= (unsigned) num_cols) bad |= 2;
+#pragma omp atomic
+            ++row_offsets[(size_t) r + 1];
         }
+        if (bad & 1) throw MarketError("row index out of range");
+        if (bad & 2) throw MarketError("col index out of range");
         for (int r = 0; r < num_rows; ++r) row_offsets[(size_t) r + 1] += row_offsets[r];
-        // stable scatter by row (keeps emission order inside a row)
-        std::vector<int> cursor(row_offsets.begin(), row_offsets.end() - 1);
+        // ---- stable scatter by row (keeps emission order inside a row), two levels so that every thread works:
+        //      the rows are cut into T blocks of about equal nonzero count; entry chunk c counts its entries per
+        //      block, a prefix over (block, chunk) gives every chunk its stable slot range inside every block, the
+        //      chunks scatter their entry ids there, and finally each block runs the classic cursor scatter on its own.
         std::vector<int> perm(n);
-        for (size_t k = 0; k < n; ++k) perm[(size_t) cursor[coo.row[k]]++] = (int) k;
+        {
+            std::vector<int> block_first_row((size_t) T + 1, num_rows);
+            block_first_row[0] = 0;
+            for (int b = 1; b < T; ++b) {
+                const int target = (int) ((long long) n * b / T);
+                block_first_row[(size_t) b] = (int) (std::lower_bound(row_offsets.begin(), row_offsets.end() - 1, target) - row_offsets.begin());
+                if (block_first_row[(size_t) b] < block_first_row[(size_t) b - 1]) block_first_row[(size_t) b] = block_first_row[(size_t) b - 1];
+            }
+            auto block_of = [&](int r) { return (int) (std::upper_bound(block_first_row.begin() + 1, block_first_row.begin() + T, r) - (block_first_row.begin() + 1)); };
+            std::vector<size_t> cnt((size_t) T * T, 0);                 // [chunk][block]
+            std::vector<int> tmp(n);
+#pragma omp parallel for schedule(static, 1)
+            for (int c = 0; c < T; ++c) {
+                const size_t lo = n * (size_t) c / T, hi = n * (size_t) (c + 1) / T;
+                size_t *mine = &cnt[(size_t) c * T];
+                for (size_t k = lo; k < hi; ++k) ++mine[block_of(coo.row[k])];
+            }
+            for (int b = 0; b < T; ++b) {
+                size_t at = (size_t) row_offsets[(size_t) block_first_row[(size_t) b]];
+                for (int cc = 0; cc < T; ++cc) { const size_t v = cnt[(size_t) cc * T + b]; cnt[(size_t) cc * T + b] = at; at += v; }
+            }
+#pragma omp parallel for schedule(static, 1)
+            for (int c = 0; c < T; ++c) {
+                const size_t lo = n * (size_t) c / T, hi = n * (size_t) (c + 1) / T;
+                size_t *mine = &cnt[(size_t) c * T];
+                for (size_t k = lo; k < hi; ++k) tmp[mine[block_of(coo.row[k])]++] = (int) k;
+            }
+            // block b: cursor scatter of its (already block-local, still emission-ordered) entry ids
+#pragma omp parallel for schedule(static, 1)
+            for (int blk = 0; blk < T; ++blk) {
+                const int r0 = block_first_row[(size_t) blk], r1 = block_first_row[(size_t) blk + 1];
+                if (r1 <= r0) continue;
+                std::vector<int> cursor(row_offsets.begin() + r0, row_offsets.begin() + r1);
+                const size_t a = (size_t) row_offsets[(size_t) r0], e = (size_t) row_offsets[(size_t) r1];
+                for (size_t i = a; i < e; ++i) { const int k = tmp[i]; perm[(size_t) cursor[(size_t) (coo.row[(size_t) k] - r0)]++] = k; }
+            }
+        }
         // stable sort by column inside each row, rows in parallel
         column_indices.resize(n); values.resize(n);
 #pragma omp parallel for schedule(dynamic, 1024)

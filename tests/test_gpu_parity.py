@@ -530,6 +530,24 @@ def test_gpu_driver_quiet_csv_and_matrix_market_input(M):
     assert "\tPASS" in out and "FAIL" not in out
 
 
+def test_gpu_driver_plan_and_multi_gpu_method_lines(M):
+    """extra method lines of this project (non-quiet only): --plan = the prepared band-major plan with its set-up in the
+    `setup ms` column; --gpus=G = the matrix merge-partitioned over G parts through the C multi-GPU operator, here with
+    all parts on one device, peer exchange and the RCCL backend (one rank); --timing prints the ingest phases"""
+    out = _gpu_spmv("--grid2d=400", "--fp32", "--i=10", "--no-vendor", "--plan=8", "--gpus=1,3", "--mg-one-device")
+    assert "Merge-based CsrMV (prepared band-major plan), " in out and "\t8 column band(s)" in out
+    assert "Merge-based CsrMV (1 GPU, all parts on one device), " in out and "Merge-based CsrMV (3 GPUs, all parts on one device), " in out
+    assert "carry exchange: peer reads, 12 bytes per step" in out
+    assert out.count("\tPASS") == 4 and "FAIL" not in out and out.count("strict check: PASS") == 4
+    out = _gpu_spmv("--wheel=20000", "--i=5", "--no-vendor", "--gpus=1", "--mg-exchange=rccl")
+    assert "carry exchange: RCCL all-gather, 8 bytes per step" in out and out.count("\tPASS") == 2 and "FAIL" not in out
+    out = _gpu_spmv("--mtx=" + os.path.join(ROOT, "tests/golden/mtx/symmetric.mtx"), "--i=2", "--no-vendor", "--timing")
+    assert "ingest seconds: read " in out
+    # the CSV keeps the reference's columns whatever extras are asked for
+    line = _gpu_spmv("--quiet", "--grid2d=100", "--i=3", "--plan", "--gpus=2", "--mg-one-device", "--timing").strip()
+    assert "plan" not in line and "GPU" not in line and "ingest" not in line and line.count("Merge-based CsrMV") == 1
+
+
 def _guarded(t, fill, guard=64):
     """t inside a larger buffer whose surroundings hold `fill`; returns (view, whole buffer)"""
     buf = torch.full((t.numel() + 2 * guard,), fill, dtype=t.dtype, device="cuda")
@@ -638,3 +656,38 @@ def test_tiny_x_is_gathered_from_lds(M, prec, cols):
             got[flags] = (y, y2)
         assert np.array_equal(got[0][0], got[0x80000][0]) and np.array_equal(got[0][1], got[0x80000][1])
         assert np.array_equal(got[16][0], got[16 | 0x80000][0]) and np.array_equal(got[16][1], got[16 | 0x80000][1])
+
+
+@pytest.mark.gpu
+def test_config3_through_the_matrix_market_path(M, tmp_path):
+    """BASELINE config 3 through the REAL ingest path (tools/c3_ingest.py does this at com-Orkut size: 117 M lines, see
+    profiles/r02_c3_ingest.txt): a power-law graph written as a `coordinate pattern symmetric` Matrix Market file,
+    `gpu_spmv --mtx=... --cache` run twice (parse + mirror + COO->CSR + image, then the image alone), PASS + strict PASS
+    both times, and the CSR the driver built equals the generator's symmetrised CSR array for array."""
+    import ctypes
+    from merge_spmv_amd import generators as G
+    scale, edges = 18, 3_000_000
+    n = 1 << scale
+    r, c = G.rmat_edges(scale, 0, edges, "cuda", G.SEED_C3)
+    off_diag = r != c
+    rr = torch.cat([r, c[off_diag]]); cc = torch.cat([c, r[off_diag]])
+    order = torch.sort(rr * n + cc, stable=True).indices
+    exp_cols = cc[order].to(torch.int32).cpu().numpy()
+    exp_off = np.zeros(n + 1, np.int64); np.cumsum(torch.bincount(rr, minlength=n).cpu().numpy(), out=exp_off[1:])
+    H = ctypes.CDLL(os.path.join(ROOT, "merge_spmv_amd", "libmspmv_host.so"))
+    H.mspmv_host_write_pattern_mtx.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_int]
+    rh = r.to(torch.int32).cpu().numpy(); ch = c.to(torch.int32).cpu().numpy()
+    path = str(tmp_path / "c3.mtx")
+    assert H.mspmv_host_write_pattern_mtx(path.encode(), n, n, edges, rh.ctypes.data, ch.ctypes.data, 1) == 0
+    first = _gpu_spmv("--mtx=" + path, "--cache", "--timing", "--i=5", "--no-vendor")
+    second = _gpu_spmv("--mtx=" + path, "--cache", "--timing", "--i=5", "--no-vendor")
+    for out in (first, second):
+        assert "\tPASS" in out and "FAIL" not in out and "strict check: PASS" in out and f"num_nonzeros: {exp_cols.size}" in out
+    assert "Reading binary CSR image" in second and "Reading binary CSR image" not in first
+    with open(path + ".fp64.csrbin", "rb") as f:
+        head = f.read(28)
+        rows, cols, nnz = np.frombuffer(head[16:28], np.int32)
+        off = np.fromfile(f, np.int32, rows + 1); col = np.fromfile(f, np.int32, nnz)
+    assert (rows, cols, nnz) == (n, n, exp_cols.size)
+    assert np.array_equal(off, exp_off.astype(np.int32)) and np.array_equal(col, exp_cols)
