@@ -194,7 +194,9 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_NO_XLDS    0x80000 /* never gather a tiny x (<= 4 KB) from LDS */
 #define MSPMV_TUNE_ATOMIC_FIX 2   /* single-launch atomicAdd fix-up (non-deterministic) */
 #define MSPMV_TUNE_NO_VEC     4   /* force the dword-per-lane kernel with the reference's per-thread path walk (the path taken for unaligned arrays) */
-#define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by per-boundary wave search instead of the one-pass scatter */
+#define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by a 64-ary wave search per boundary */
+#define MSPMV_TUNE_SCATTER_COORDS 0x10000000 /* ... always by one coalesced pass over all row offsets (the default below 10 M rows) */
+#define MSPMV_TUNE_INTERP_COORDS  0x20000000 /* ... always by one thread per boundary, interpolation search (the default from 10 M rows up) */
 #define MSPMV_TUNE_NO_FUSED   16  /* never use the single-launch small-problem kernel */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
 #define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -22,12 +23,20 @@
 namespace mspmv {
 
 constexpr int SEARCH_BLOCK = 256;
+constexpr int INTERP_MIN_ROWS = 10000000;       // coordinate pass: interpolation search from here up, scatter pass below
 constexpr int FUSED_CHUNK_LOG2 = 0;      // XCD-chunked mapping (see the tile_kernel_vec dispatch): no measurable effect below 2048 tiles
 constexpr int MM_CHUNK_LOG2 = 6;         // ... 0-3 % on the SpMM tiles
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
-constexpr int FUSED_MAX_TILES = 2048;            // up to here: tiles search their own coordinates (one launch less)
+constexpr int FUSED_MAX_TILES_DEFAULT = 2048;    // up to here: tiles search their own coordinates (one launch less)
+// (MSPMV_FUSED_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
+static int fused_max_tiles()
+{
+    static const int v = [] { const char *e = getenv("MSPMV_FUSED_MAX_TILES"); const int n = e ? atoi(e) : 0; return n > 0 ? n : FUSED_MAX_TILES_DEFAULT; }();
+    return v;
+}
+#define FUSED_MAX_TILES (fused_max_tiles())
 
 static_assert(TILE_MAP_CONTIGUOUS_CODE == TILE_MAP_CONTIGUOUS, "mapping code shared with the kernels");
 
@@ -238,6 +247,13 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         hipLaunchKernelGGL((search_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows,
                            p.nnz, tile_items, L.num_tiles, coords);
         MSPMV_CHECK(after_launch(stream, debug_sync, "search_kernel", grid, SEARCH_BLOCK));
+    } else if ((L.flags & MSPMV_TUNE_INTERP_COORDS) || (!(L.flags & MSPMV_TUNE_SCATTER_COORDS) && p.rows >= INTERP_MIN_ROWS)) {
+        // from 10 M rows up: one thread per boundary, interpolation search (latency-bound: <= 17 us whatever the row
+        // count, 2-8 us on regular matrices) instead of reading all of row_offsets (20-23 us at 16.8 M rows)
+        const unsigned grid = (unsigned) ((L.num_tiles + 1 + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
+        hipLaunchKernelGGL((coords_interp_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows, p.nnz,
+                           tile_items, L.num_tiles, coords);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "coords_interp_kernel", grid, SEARCH_BLOCK));
     } else {
         const long long threads = ((long long) p.rows + 1 + 3) / 4;       // 4 row indices per thread
         const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
@@ -700,7 +716,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    int allowed = MSPMV_TUNE_NO_XLDS | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
+    int allowed = MSPMV_TUNE_SCATTER_COORDS | MSPMV_TUNE_INTERP_COORDS | MSPMV_TUNE_NO_XLDS | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
                   MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xf000000;
 #ifdef MSPMV_DEV
     allowed |= MSPMV_DEV_FLAG_BITS;        // development kernels (mspmv_dev.hpp): never in the product library

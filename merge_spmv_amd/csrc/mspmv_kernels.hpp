@@ -100,6 +100,58 @@ __device__ __forceinline__ Coord wave_merge_path_search(int diagonal, const int 
     return c;
 }
 
+// The same search as the self-searching tiles of small problems do it: round 1 probes 64 FIXED samples
+// (k + 1) * rows / 64 -- the same addresses for every block, so they come from L2 --, round 2 probes 64 CONSECUTIVE
+// rows around the point linear interpolation inside that bracket predicts (two cache lines); on a matrix whose row
+// lengths vary smoothly that finishes it: two dependent loads instead of four, ~1.5 us less before a block's first
+// nonzero is requested.  Whatever is left of the bracket goes through 64-ary rounds.  Exact; all lanes return the
+// same coordinate.  M(p) = row_end[p] + p + 1 (strictly increasing), M(rows) = +inf; the point of diagonal d is
+// (p, d - p) for the first p with M(p) > d.
+__device__ __forceinline__ Coord wave_merge_path_search_interp(int diagonal, const int *__restrict__ row_end, int rows, int nnz)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int inf = rows + nnz + 1;                              // < 2^31
+    auto m_of = [&](int p) { return p < rows ? row_end[p] + p + 1 : inf; };
+    const int pk = (int) ((long long) (lane + 1) * rows / WAVE);  // lane 63: rows
+    const int mk = m_of(pk);
+    unsigned long long mask = __ballot(mk > diagonal);            // monotone; lane 63 is always set
+    int f = __ffsll((long long) mask) - 1;
+    int b = __shfl(pk, f, WAVE);
+    const int m_hi = __shfl(mk, f, WAVE);
+    const int p_lo = f == 0 ? -1 : __shfl(pk, f - 1, WAVE);
+    const int m_lo = f == 0 ? 0 : __shfl(mk, f - 1, WAVE);
+    int a = p_lo + 1;                                             // M(p) <= diagonal for p < a;  M(b) > diagonal
+    if (a < b) {
+        const long long g = p_lo + 1 + (long long) ((double) (diagonal - m_lo) * (double) (b - p_lo - 1) / (double) (m_hi - m_lo));
+        int w0 = (int) g - WAVE / 2;
+        const int w_max = b - (WAVE - 1) > a ? b - (WAVE - 1) : a;
+        w0 = w0 < a ? a : w0 > w_max ? w_max : w0;               // window [w0, w0 + 63], inside [a, b] where possible
+        const int p = w0 + lane;
+        const bool pred = p >= b ? true : m_of(p) > diagonal;
+        mask = __ballot(pred);
+        f = __ffsll((long long) mask) - 1;
+        if (mask == 0ull) a = w0 + WAVE;                          // the answer lies beyond the window
+        else if (f == 0 && w0 > a) b = w0;                        // ... at or before its first row
+        else a = b = w0 + f;                                      // found
+        while (a < b) {                                           // 64-ary rounds over [a, b), M(b) > diagonal
+            const int n = b - a;
+            const int step = (n + WAVE - 1) / WAVE;
+            const int chunk_lo = a + lane * step;
+            int q = chunk_lo + step; q = (q < b ? q : b) - 1;
+            bool pr = false;
+            if (chunk_lo < b) pr = m_of(q) > diagonal;
+            const unsigned long long mm = __ballot(pr);
+            if (mm == 0ull) { a = b; break; }
+            const int ff = __ffsll((long long) mm) - 1;
+            const int na = a + ff * step;
+            int nb = na + step; nb = (nb < b ? nb : b) - 1;
+            a = na; b = nb;
+        }
+    }
+    Coord c; c.x = b < rows ? b : rows; c.y = diagonal - b;
+    return c;
+}
+
 // ref: DeviceSpmvSearchKernel, dispatch_spmv_orig.cuh:104-143 (there: one
 // thread per boundary, binary search).  coords has num_tiles+1 entries.
 template <int BLOCK>
@@ -186,6 +238,61 @@ __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__rest
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The same coordinates WITHOUT reading every row offset: one THREAD per tile boundary, interpolation search.
+// With M(p) = row_end[p] + p + 1 (the merge position just past row-end p; strictly increasing) and
+// M(rows) = +inf, the point of diagonal d is (p, d - p) for the first p in [0, rows] with M(p) > d (for
+// p > d or p < d - nnz the predicate holds / fails by itself, so the search bounds of Appendix B.2 are implied).
+//   1. every block loads the same K + 1 samples M(k * rows / K) into LDS (L2 hits after the first block);
+//   2. a thread finds its bracket among them (10 LDS steps) and runs up to four secant steps -- evaluate M at the
+//      linearly interpolated point, shrink the bracket -- then a short walk; on a matrix whose row lengths vary
+//      smoothly (grids, bands, dense blocks, uniform random rows) that ends within a row or two of the first guess;
+//   3. otherwise (a giant row, a power-law neighbourhood) an exact binary search over what is left of the bracket.
+// Always exact -- the result is bit for bit the scatter pass's.  The kernel is latency-bound: its time is that of
+// its slowest thread, ~2-8 us on regular matrices and <= 17 us (a full binary search of a bracket) on any matrix,
+// whatever the row count, where the scatter pass reads all of row_offsets: 8 us at 3 M rows, 12 at 8 M, 20-23 at
+// 16.8 M.  The dispatcher therefore uses it from 10 M rows up (measured: band5 19.1 -> 7.5 us, C4 22.7 -> 11.5,
+// grid2d-4096 20.3 -> 16.5; below that size the scatter pass is at least as fast on irregular matrices).
+// ---------------------------------------------------------------------------
+constexpr int INTERP_SAMPLES = 1024;
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void coords_interp_kernel(const int *__restrict__ row_end, int rows, int nnz, int tile_items,
+                                                              int num_tiles, Coord *__restrict__ coords)
+{
+    static_assert(INTERP_SAMPLES % BLOCK == 0, "whole rounds of sample loads");
+    __shared__ long long s_m[INTERP_SAMPLES + 1];
+    const long long total = (long long) rows + nnz;
+    auto sample_pos = [&](int k) { return (int) ((long long) k * rows / INTERP_SAMPLES); };
+    auto m_of = [&](int p) { return p < rows ? (long long) row_end[p] + p + 1 : total + 1; };
+    for (int k = threadIdx.x; k < INTERP_SAMPLES; k += BLOCK) s_m[k] = m_of(sample_pos(k));
+    if (threadIdx.x == 0) s_m[INTERP_SAMPLES] = total + 1;          // M(rows) = +inf
+    __syncthreads();
+    const int boundary = blockIdx.x * BLOCK + threadIdx.x;
+    if (boundary > num_tiles) return;
+    long long d = (long long) boundary * tile_items; d = d < total ? d : total;
+    // bracket: first sample k with M(p_k) > d  (k = INTERP_SAMPLES always qualifies)
+    int klo = 0, khi = INTERP_SAMPLES;
+    while (klo < khi) { const int mid = (klo + khi) >> 1; if (s_m[mid] > d) khi = mid; else klo = mid + 1; }
+    int b = sample_pos(klo);                                       // M(b) = m_hi > d
+    long long m_hi = s_m[klo];
+    int p_lo = klo == 0 ? -1 : sample_pos(klo - 1);                // M(p_lo) = m_lo <= d   (p_lo = -1: nothing below)
+    long long m_lo = klo == 0 ? 0 : s_m[klo - 1];
+    // secant steps: evaluate M at the interpolated point, keep the half that holds the answer
+    for (int it = 0; it < 4 && b - p_lo > 1; ++it) {
+        long long g = p_lo + 1 + (long long) ((double) (d - m_lo) * (double) (b - p_lo - 1) / (double) (m_hi - m_lo));
+        const int p = (int) (g <= p_lo ? p_lo + 1 : g >= b ? b - 1 : g);
+        const long long mp = m_of(p);
+        if (mp > d) { b = p; m_hi = mp; } else { p_lo = p; m_lo = mp; }
+    }
+    // short walk from both ends, then an exact binary search over what is left (nothing, on a smooth matrix)
+    int a = p_lo + 1;                                              // M(p) <= d for p < a;  M(b) > d
+    for (int step = 0; step < 2 && a < b; ++step) { if (m_of(a) > d) b = a; else ++a; }
+    for (int step = 0; step < 2 && a < b; ++step) { if (m_of(b - 1) > d) --b; else a = b; }
+    while (a < b) { const int mid = (int) (((long long) a + b) >> 1); if (m_of(mid) > d) b = mid; else a = mid + 1; }
+    Coord c; c.x = b < rows ? b : rows; c.y = (int) (d - b);
+    coords[boundary] = c;
 }
 
 // ---------------------------------------------------------------------------
@@ -1298,7 +1405,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
         const int wave = tid / WAVE;
         if (wave < 2) {
             const long long d = (long long) (tile + wave) * TILE;
-            const Coord c = wave_merge_path_search((int) (d < total ? d : total), p.row_end, p.rows, p.nnz);
+            const Coord c = wave_merge_path_search_interp((int) (d < total ? d : total), p.row_end, p.rows, p.nnz);
             if ((tid & (WAVE - 1)) == 0) s_coord[wave] = c;
         }
     }

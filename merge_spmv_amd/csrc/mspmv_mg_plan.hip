@@ -109,17 +109,15 @@ __global__ void mg_take_carries_kernel(V *__restrict__ y_first, const V *const *
     *y_first = acc;
 }
 
-// Push `count` owned rows into `ndst` replicas of x (dst[d] already offset to this part's row range);
-// 16-byte accesses where the three addresses allow it.
+// Push `count` owned rows into every replica of x (dst[d] already offset to this part's row range).  blockIdx.y is
+// the replica: the writes to the different peers are in flight together, one xGMI link each (the links are
+// point-to-point, so a part's push to seven peers uses seven links at once), while y is read from local HBM / L2.
 template <typename V>
-__global__ __launch_bounds__(256) void mg_push_rows_kernel(const V *__restrict__ y, V *const *__restrict__ dst, int ndst,
-                                                           long long count)
+__global__ __launch_bounds__(256) void mg_push_rows_kernel(const V *__restrict__ y, V *const *__restrict__ dst, long long count)
 {
     const long long stride = (long long) gridDim.x * blockDim.x;
-    for (int d = 0; d < ndst; ++d) {
-        V *__restrict__ out = dst[d];
-        for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = y[i];
-    }
+    V *__restrict__ out = dst[blockIdx.y];
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = y[i];
 }
 
 struct Part {
@@ -239,9 +237,9 @@ int run_allgather(mspmv_mg_plan *plan)
         MG_HIP(hipSetDevice(q.device));
         for (Part &o : plan->local) if (&o != &q && o.done_valid) MG_HIP(hipStreamWaitEvent(q.stream, o.done, 0));
         if (q.owned > 0) {
-            const unsigned grid = (unsigned) std::min<long long>((q.owned + 255) / 256, 4096);
-            hipLaunchKernelGGL((mg_push_rows_kernel<V>), dim3(grid), dim3(256), 0, q.stream, static_cast<const V *>(q.y),
-                               reinterpret_cast<V *const *>(q.push_table), (int) plan->replicas.size(), q.owned);
+            const unsigned grid = (unsigned) std::min<long long>((q.owned + 255) / 256, 1024);
+            hipLaunchKernelGGL((mg_push_rows_kernel<V>), dim3(grid, (unsigned) plan->replicas.size()), dim3(256), 0, q.stream,
+                               static_cast<const V *>(q.y), reinterpret_cast<V *const *>(q.push_table), q.owned);
             MG_HIP(hipGetLastError());
         }
         MG_HIP(hipEventRecord(q.pushed, q.stream)); q.pushed_valid = true;

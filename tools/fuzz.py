@@ -2,13 +2,16 @@
 """tools/fuzz.py [seconds] -- randomized differential test of the C ABI on the GPU: random CSR shapes
 (row-length families, empty rows, giant rows), precisions, array alignments (views at element offsets
 0..3: the unaligned ones take the scalar fallback), tuning flags, alpha/beta, SpMM widths and leading
-dimensions; results compared with an fp64 segment-sum on the GPU under the strict per-row bound."""
+dimensions, the prepared band-major plan (random band counts, sorted and unsorted rows, alpha/beta) and the C multi-GPU
+operator (1..8 parts on this device, peer exchange); results compared with an fp64 segment-sum on the GPU under the strict
+per-row bound."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import merge_spmv_amd as M
+from merge_spmv_amd import multi_gpu as MG
 
-FLAGS = [0, 0, 0, 2, 4, 8, 16, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0xE000010]
+FLAGS = [0, 0, 0, 2, 4, 8, 16, 16, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0xE000010, 0x20000010, 0x20000000]
 SHAPES = {4: [(256, 7), (256, 5), (256, 9), (256, 11), (128, 7), (512, 7), (256, 15)],
           8: [(256, 5), (256, 3), (256, 7), (256, 9), (128, 5), (512, 5), (256, 11)]}
 
@@ -68,8 +71,51 @@ def main():
         cfac = 2.0 * (torch.ceil(torch.log2(lens_t + 1)) + 16 + 8)
         try:
             M.set_tuning(vb, shape[0], shape[1], flags)
-            mode = rng.integers(0, 3)
-            if mode < 2:                               # CsrMV / axpby (+ prepared)
+            mode = rng.integers(0, 5)
+            if mode == 3:                              # prepared band-major plan (mspmv_csrmv_plan_*)
+                x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+                colp = col
+                if rng.random() < 0.5 and nnz:         # the reference's CSR has sorted rows: the order-preserving scatter path
+                    rowid = torch.repeat_interleave(torch.arange(rows, device="cuda"), lens_i)
+                    colp = col[torch.sort(rowid * cols + col.long(), stable=True).indices].contiguous()
+                bands = int(rng.choice([0, 1, 2, 3, 8, 16, 24, 64]))
+                if bands * rows + nnz > 2**31 - 65537: bands = 1
+                alpha, beta = (1.0, 0.0) if rng.random() < 0.5 else (float(rng.uniform(-2, 2)), float(rng.choice([0.0, 0.5, -1.0])))
+                y0 = (torch.rand(rows, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+                y = y0.clone()
+                plan = M.CsrMVPlan(val, offs, colp, cols, bands=bands)
+                plan(x, y, alpha=alpha, beta=beta)
+                prod = val.double() * x.double()[colp.long()]
+                g = segsum(prod); s = segsum(prod.abs())
+                want = alpha * g + beta * y0.double()
+                cf = cfac + 2.0 * plan.bands
+                tol = cf * eps * (abs(alpha) * s + abs(beta) * y0.double().abs()) + 4 * eps * want.abs()
+                err = (y.double() - want).abs()
+                bad = err > tol
+                if alpha == 1.0 and beta == 0.0: bad |= (lens_t == 0) & (y != 0)
+                ratio = float((err / (tol + 1e-300)).max()) if rows else 0.0
+            elif mode == 4:                            # the C multi-GPU operator, all parts on this device (peer exchange)
+                parts = int(rng.choice([1, 2, 3, 5, 8]))
+                x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+                row_split, nz_split = MG.partition(off, parts)
+                plan = MG.MgPlan(row_split, nz_split, cols, tdt, list(range(parts)), [0] * parts)
+                try:
+                    for gpart in range(parts):
+                        lo = MG.local_offsets(off, row_split[gpart], row_split[gpart + 1], nz_split[gpart], nz_split[gpart + 1])
+                        a, b = int(nz_split[gpart]), int(nz_split[gpart + 1])
+                        plan.set_part(gpart, val[a:b].clone(), torch.from_numpy(lo).cuda(), col[a:b].clone())
+                    plan.x(0).copy_(x); torch.cuda.synchronize()
+                    plan.csrmv(); plan.synchronize()
+                    y = torch.cat([plan.y(gpart) for gpart in range(parts)]) if rows else torch.empty(0, dtype=tdt, device="cuda")
+                finally:
+                    plan.close()
+                prod = val.double() * x.double()[col.long()]
+                g = segsum(prod); s = segsum(prod.abs())
+                tol = (cfac + 2.0 * parts) * eps * s
+                err = (y.double() - g).abs()
+                bad = (err > tol) | ((lens_t == 0) & (y != 0))
+                ratio = float((err / (tol + 1e-300)).max()) if rows else 0.0
+            elif mode < 2:                               # CsrMV / axpby (+ prepared)
                 x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
                 alpha, beta = (1.0, 0.0) if mode == 0 else (float(rng.uniform(-2, 2)), float(rng.choice([0.0, 0.5, -1.0])))
                 y0 = (torch.rand(rows, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
