@@ -291,6 +291,15 @@ def main():
                       "parallel_efficiency": round(sms / ms_per_step / world, 4)}
             del W, wws, wy
 
+    # anything native code left in C stdio buffers (RCCL prints a version banner at communicator creation) goes out on
+    # EVERY rank before rank 0 prints the result, so that the JSON line is the last line of the job's stdout
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
         gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
         info = M.launch_info(local_rows, local_nnz, vb)
