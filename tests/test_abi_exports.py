@@ -133,3 +133,18 @@ def test_extension_entry_points_follow_the_same_conventions():
         small = ctypes.c_size_t(16)
         assert fn(ctypes.c_void_p(256), ctypes.byref(small), None, None, None, None, 4, None, 4, 1000, 1000, 50000, 4, 1.0, 0.0, None, 0) == 1
     assert lib.mspmv_csrmv_prepared_f32(None, ctypes.byref(size), None, None, None, None, None, 10, 10, 10, 1.0, 0.0, None, 0) == 1   # needs a prepared buffer
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/mspmv.h (and the development header) must compile as C99 with no HIP or C++ in sight: that is what a cgo /
+    JNI / ctypes-generator binding of the boundary consumes."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "include/mspmv.h"\n#include "include/mspmv_dev.h"\n'
+                   "int use(void) { size_t b = 0; int32_t n = 0; mspmv_mg_info_t info; mspmv_launch_info_t li;\n"
+                   "  int st = mspmv_csrmv_f64(0, &b, 0, 0, 0, 0, 0, 10, 10, 10, 0, 0);\n"
+                   "  st |= mspmv_csrmv_plan_size(10, 10, 10, 4, 0, &b, &n); st |= mspmv_mg_plan_info(0, &info);\n"
+                   "  st |= mspmv_get_launch_info(10, 10, 4, &li); return st; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "hdr.o"), "-I", ROOT],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

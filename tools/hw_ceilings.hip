@@ -247,3 +247,31 @@ extern "C" int ub7_splits(const void* off, const void* col, void* splits, int ro
     hipLaunchKernelGGL(k_splits, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t) s, (const int*) off, (const int*) col, (int*) splits, rows, nb, band_width);
     return (int) hipGetLastError();
 }
+
+// ===== scalar-load gather probe =====
+// The vector L1 (TCP) asks L2 for whole 128-byte lines; the scalar data cache works on 64-byte lines.  Does a gather issued
+// as 64 scalar loads per wave (v_readlane -> s_load_dword, address made wave-uniform) move fewer bytes per miss, and how
+// fast can a CU issue it?  Same index stream as k_gather_policy.
+__global__ __launch_bounds__(256) void k_gather_scalar(const float* __restrict__ x, unsigned mask, int iters, float* out)
+{
+    unsigned h = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h = h * 1664525u + 1013904223u;
+            const int idx = (int) ((h >> 7) & mask);
+#pragma unroll
+            for (int l = 0; l < 64; ++l) {
+                const int s = __builtin_amdgcn_readlane(idx, l);
+                acc += x[s];                                   // uniform address: s_load_dword
+            }
+        }
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+extern "C" int ub_gather_scalar(const void* x, unsigned mask, int iters, void* out, int blocks, void* s)
+{
+    hipLaunchKernelGGL(k_gather_scalar, dim3(blocks), dim3(256), 0, (hipStream_t) s, (const float*) x, mask, iters, (float*) out);
+    return (int) hipGetLastError();
+}

@@ -7,6 +7,7 @@ box (kernels: tools/hw_ceilings.hip).  Output is committed under profiles/ (r02_
   policy    100 M random 4-byte gathers over 1 MiB / 16 MiB / 1 GiB tables with every sc0/sc1/nt combination
             (the L2-resident, Infinity-Cache-resident and DRAM random-line rates)
   pattern   cycles per wave gather instruction by address pattern (texture-address unit)
+  scalar    the same gather issued as scalar loads (v_readlane + s_load_dword): 64-byte scalar-cache lines vs 128-byte TCP lines
   banded    column-banded traversal of the C2 matrix WITHOUT re-laying it out (what a stateless call could do): the probe
             that motivated the prepared plan
 """
@@ -117,7 +118,22 @@ def banded():
     print(f"prepared band-major plan ({plan.bands} bands, matrix re-laid out once): {t_p:.4f} ms  (max diff vs merge {float((yp.double() - yref.double()).abs().max()):.2e})")
 
 
-PROBES = {"stream": stream, "shapes": shapes, "policy": policy, "pattern": pattern, "banded": banded}
+def scalar():
+    """gather issued as scalar loads (64 per wave instruction slot): bytes per miss and issue rate vs the vector gather"""
+    lib.ub5.argtypes = [vp, ctypes.c_uint, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.ub_gather_scalar.argtypes = [vp, ctypes.c_uint, ctypes.c_int, vp, ctypes.c_int, vp]
+    out = torch.zeros(4, device="cuda"); s = vp(torch.cuda.current_stream().cuda_stream)
+    x = torch.empty(1 << 28, device="cuda").uniform_()
+    blocks, iters = 8192, 6
+    total = blocks * 256 * iters * 8
+    for xbytes in (64 << 10, 1 << 20, 4 << 20, 16 << 20, 128 << 20, 1 << 30):
+        mask = xbytes // 4 - 1
+        tv = timeit(lambda: lib.ub5(vp(x.data_ptr()), mask, iters, vp(out.data_ptr()), blocks, 0, s), 5)
+        ts = timeit(lambda: lib.ub_gather_scalar(vp(x.data_ptr()), mask, iters, vp(out.data_ptr()), blocks, s), 5)
+        print(f"table {xbytes / 2**20:8.2f} MiB: vector gather {tv:.4f} ms = {total / tv / 1e6:7.1f} G/s | scalar-load gather {ts:.4f} ms = {total / ts / 1e6:7.1f} G/s", flush=True)
+
+
+PROBES = {"scalar": scalar, "stream": stream, "shapes": shapes, "policy": policy, "pattern": pattern, "banded": banded}
 if __name__ == "__main__":
     for name in sys.argv[1:] or list(PROBES):
         print(f"## {name}", flush=True)
