@@ -126,8 +126,8 @@ int mspmv_csrmv_prepared_f64(void *d_temp, size_t *temp_bytes, const double *d_v
  * drop-in calls above never use it).  When x is larger than an XCD's 4 MiB L2, ~70 % of the x gathers miss
  * and every miss moves a 128-byte line: that, not HBM, bounds mspmv_csrmv_* on such a matrix (BASELINE
  * config 2).  mspmv_csrmv_plan_build_* makes, ONCE, a band-major copy of the matrix in the caller's
- * storage: the columns are cut into `bands` equal bands (0 = pick: the fewest multiple of 8 with <= 3.25 MiB of x
- * per band; 1 when x fits anyway) and the entries of band b form the b-th block of rows of a stacked CSR
+ * storage: the columns are cut into `bands` equal bands (0 = pick: the fewest of 2, 4, 8, 16, ... with <= 3.25 MiB
+ * of x per band; 1 when x fits anyway) and the entries of band b form the b-th block of rows of a stacked CSR
  * matrix; mspmv_csrmv_plan_apply_* then runs the ordinary merge-path CsrMV over the stacked matrix with
  * one contiguous tile range per XCD -- so each XCD's L2 only ever holds one band's slice of x and the CSR
  * stream is read exactly once -- and folds the bands' partial sums in band order:

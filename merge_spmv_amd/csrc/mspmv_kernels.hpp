@@ -6,18 +6,22 @@
 // SURVEY.md Appendix B.
 //
 // Device passes per SpMV, all on the caller's stream (mspmv_api.hip picks):
-//   1. coords_scatter_kernel : tile boundaries of the merge path in ONE coalesced pass over
-//                      row_offsets (row end r sits at path position r + row_end[r]); or
-//                      search_kernel: one WAVE per boundary, 64-ary search (option)
-//                      -> coords[tile]                       (ref: DeviceSpmvSearchKernel)
-//   2. tile_kernel_vec : one 256-thread block per merge tile (XCD-chunked tile order),
-//                      16-byte streaming of (col, val) and row offsets, gather of x, products
+//   1. tile boundaries of the merge path -> coords[tile]            (ref: DeviceSpmvSearchKernel)
+//        coords_scatter_kernel : ONE coalesced pass over row_offsets (row end r sits at path position
+//                      r + row_end[r]); the default below 10 M rows;
+//        coords_interp_kernel  : one THREAD per boundary -- bracket in an LDS table of 1025 samples, secant steps,
+//                      exact binary search of what is left; latency-bound, the default from 10 M rows up;
+//        search_kernel : one WAVE per boundary, 64-ary search (option)
+//   2. tile_kernel_vec : one 256-thread block per merge tile (XCD-chunked tile order, or one contiguous tile
+//                      range per XCD for the prepared band-major plan), 16-byte streaming of (col, val) and row
+//                      offsets, gather of x (from a per-block LDS copy when x is <= 4 KB), products
 //                      and 16-bit tile-relative row ends staged in LDS, one bit per row start;
 //                      segmented running sums over 12 consecutive products per thread + one
 //                      block-wide DPP segmented scan (consume_tile_flags), y stored per row from
 //                      registers, one (row, partial) carry per tile  (ref: DeviceSpmvKernel)
 //      tile_kernel_fused : the same for <= 2048 tiles, each block searching its own two
-//                      coordinates (no pass 1);
+//                      coordinates (no pass 1): 64 fixed samples, 64 consecutive rows at the interpolated point,
+//                      64-ary rounds on the rest;
 //      tile_kernel     : dword-per-lane fallback for unaligned arrays, with the reference's
 //                      per-thread search + path walk (consume_tile_lds)
 //   3. fixup_onepass_kernel : deterministic reduce-by-key over the per-tile carries in one
@@ -25,6 +29,7 @@
 //                      no decoupled look-back, no spin-waits, no atomics: bitwise reproducible
 //                      (ref: DeviceSegmentFixupKernel).  fixup_kernel / fixup_atomic_kernel:
 //                      multi-level and atomic options.
+// Development variants of tile_kernel_vec (persistent grid, ablations, cycle stamps) compile only with -DMSPMV_DEV.
 // mspmv_spmm.hpp builds the SpMM kernels on the same pieces.
 #pragma once
 #include <hip/hip_runtime.h>

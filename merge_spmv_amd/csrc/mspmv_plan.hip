@@ -8,7 +8,7 @@
 // the same matrix many times can.  The reference does the same thing for its HYB comparison: conversion
 // timed once as "setup", SpMV timed separately (gpu_spmv.cu:106-257).
 //
-// What.  The columns are cut into B equal bands (B a multiple of the 8 XCDs, the fewest whose
+// What.  The columns are cut into B equal bands (the fewest -- 2, 4, then multiples of the 8 XCDs -- whose
 // slices of x stay <= 3.25 MiB); the matrix is re-laid out as the STACKED matrix A' = [A_0; A_1; ...; A_{B-1}]
 // (A_b = the entries of A whose column lies in band b; B*rows rows, the same nnz, absolute column indices),
 // which is an ordinary CSR matrix.  y' = A' x is computed by the UNCHANGED merge-path CsrMV (csrmv_call)
@@ -51,15 +51,18 @@ struct PlanLayout {
 // bands: 0 = automatic.  A band's slice of x must sit in an XCD's 4 MiB L2 beside the (non-temporal) streams
 // that pass through it; every extra band costs `rows` stacked rows and partial sums.  Measured on C2
 // (profiles/r02_plan.txt): fp32, 12.5 MB of x: 8 bands (1.6 MB slices) 0.527 ms, 16: 0.574, 32: 0.729;
-// fp64, 25 MB: 8 bands (3.1 MB slices) 0.670 ms, 16 (1.6 MB): 0.734.  So: the fewest bands, in multiples of the
-// 8 XCDs, whose slices stay <= 3.25 MiB; 1 when x fits anyway.
+// 4 bands (3.1 MB slices, two XCDs per band) 0.511; fp64, 25 MB: 8 bands (3.1 MB slices) 0.667 ms, 16 (1.6 MB): 0.734,
+// 4 (6.25 MB): 0.850.  So: the fewest bands -- 2, 4, then multiples of the 8 XCDs -- whose slices stay <= 3.25 MiB;
+// 1 when x fits anyway.  (With one contiguous tile range per XCD any band count lines up with the XCDs.)
 int pick_bands(long long cols, int value_bytes, int bands)
 {
     if (bands > 0) return bands;
     const long long xbytes = cols * value_bytes;
     if (xbytes <= (3ll << 20)) return 1;
+    const long long limit = 13ll << 18;                  // 3.25 MiB
+    for (int b : {2, 4}) if ((xbytes + b - 1) / b <= limit) return b;
     int b = 8;
-    while (b < 64 && (xbytes + b - 1) / b > (13ll << 18)) b += 8;
+    while (b < 64 && (xbytes + b - 1) / b > limit) b += 8;
     return b;
 }
 

@@ -16,14 +16,14 @@ gpu = pytest.mark.gpu
 def test_plan_size_query_conventions():
     lib = M.load_library()
     size = ctypes.c_size_t(0); bands = ctypes.c_int32(0)
-    # automatic band count: 1 while x fits an XCD's L2, then the fewest multiple of 8 with <= 3.25 MiB of x per band
-    for cols, vb, want in ((1000, 4, 1), (700_000, 4, 1), (3_125_000, 4, 8), (3_125_000, 8, 8), (16_000_000, 4, 24),
+    # automatic band count: 1 while x fits an XCD's L2, then the fewest of 2, 4, 8, 16, ... with <= 3.25 MiB of x per band
+    for cols, vb, want in ((1000, 4, 1), (700_000, 4, 1), (1_500_000, 4, 2), (3_125_000, 4, 4), (3_125_000, 8, 8), (16_000_000, 4, 24),
                            (200_000_000, 8, 64)):
         assert lib.mspmv_csrmv_plan_size(1000, cols, 5000, vb, 0, ctypes.byref(size), ctypes.byref(bands)) == 0
         assert bands.value == want, (cols, vb, bands.value)
     assert lib.mspmv_csrmv_plan_size(3_125_000, 3_125_000, 100_000_000, 4, 0, ctypes.byref(size), ctypes.byref(bands)) == 0
     # a second copy of the matrix + stacked offsets + partial sums + the CsrMV temp of the stacked problem
-    assert 800_000_000 + 2 * 4 * 8 * 3_125_000 <= size.value <= 1_100_000_000
+    assert bands.value == 4 and 800_000_000 + 2 * 4 * 4 * 3_125_000 <= size.value <= 1_000_000_000
     assert lib.mspmv_csrmv_plan_size(1000, 1000, 5000, 4, 8, ctypes.byref(size), None) == 0
     assert lib.mspmv_csrmv_plan_size(1000, 1000, 5000, 2, 8, ctypes.byref(size), None) == 1
     assert lib.mspmv_csrmv_plan_size(1000, 1000, 5000, 4, 65, ctypes.byref(size), None) == 1
