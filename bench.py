@@ -146,7 +146,11 @@ def main():
     M.load_library()
     dist = None
     backend = os.environ.get("MSPMV_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # MSPMV_BENCH_FORCE_MG=1 with ONE rank (torch.distributed.run --nproc-per-node 1): take the N > 1 code path anyway --
+    # process group, shipped RCCL id, the C operator's multi-process form with its all-gather in the timed loop, the
+    # single-GPU leg -- so that everything but "more than one rank" is exercised on a one-GPU box
+    mg = world > 1 or os.environ.get("MSPMV_BENCH_FORCE_MG") == "1"
+    if mg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -154,7 +158,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    workload = args.workload or ("c2" if world == 1 else "c5")
+    workload = args.workload or ("c5" if mg else "c2")
     dtype_name = args.dtype or WORKLOADS[workload]
     if args.tune:
         shape, _, fl = args.tune.partition(":")
@@ -162,7 +166,7 @@ def main():
         M.set_tuning(4 if dtype_name == "f32" else 8, int(b or 0), int(i or 0), int(fl or "0", 0))
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
-    if workload == "dense32" and world > 1:
+    if workload == "dense32" and mg:
         raise SystemExit("dense32 is a single-GPU workload")
 
     # ---- the matrix (this rank's swath of it), directly in HBM ----------------------------------------------
@@ -176,7 +180,7 @@ def main():
         scaling = "strong"
         desc = (f"C5 R-MAT scale {args.c5_scale}: {n} x {n}, {nnz_total} generated edges (duplicates kept), a,b,c,d = "
                 f".57,.19,.19,.05, seed 0x5EED0005, values/x uniform in [-1,1); one matrix independent of the GPU count")
-        if world == 1:
+        if not mg:
             A = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
         else:
             shard = MG.rmat_shard(args.c5_scale, nnz_total, rank, world, tdt, device=dev, seed=G.SEED_C5, use_dist=True)
@@ -189,7 +193,7 @@ def main():
         desc = ((f"C2 uniform CSR: {rows} x {cols}, {C2_NPR} nnz/row, {nnz_total} nnz ({C2_ROWS_PER_GPU * C2_NPR} nnz per GPU), "
                  f"uniform random sorted columns, values/x in [-1,1)") if workload == "c2" else
                 f"dense {rows} x {C2_NPR} as CSR ({nnz_total} nnz): the streaming variant of C2 (--dense=32 --size=100000000)")
-        if world == 1:
+        if not mg:
             A = (G.uniform_csr(rows, cols, C2_NPR, dtype=tdt, device=dev) if workload == "c2"
                  else G.dense_csr(rows, C2_NPR, dtype=tdt, device=dev, ones=False))
         else:
@@ -199,7 +203,7 @@ def main():
     # ---- the operator ------------------------------------------------------------------------------------------
     plan = None
     exchange = None
-    if world == 1:
+    if not mg:
         # the plain drop-in call: no shard wrapper, no collective
         local_rows, local_nnz = A.rows, A.nnz
         ws = M.CsrMVWorkspace(A.rows, A.nnz, tdt, device=dev)
@@ -269,7 +273,7 @@ def main():
 
     # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
     single = None
-    if world > 1 and workload == "c5" and not args.no_single_gpu_leg:
+    if mg and workload == "c5" and not args.no_single_gpu_leg:
         if plan is not None:
             plan.close()
         plan = None; shard = None; sharded = None
@@ -311,7 +315,7 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and world == 1:
+                if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and not mg:
                     traffic = pmc.get("tile_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -322,7 +326,7 @@ def main():
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": desc,
                        "tile": f"{info['block_threads']}x{info['items_per_thread']}",
-                       "partition": ("single GPU" if world == 1 else
+                       "partition": ("single GPU" if not mg else
                                      f"merge-path diagonal split over {world} GPUs (mspmv_mg_partition): "
                                      f"{local_rows - 1} rows + {local_nnz} nonzeros on rank 0; one exchange of {world} carries per step")},
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
@@ -335,14 +339,14 @@ def main():
                          "events": f"hipEvents on the launch stream, {prof['calls']} launches"},
         }
         if exchange is not None:
-            out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items()}
+            out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
             if isinstance(exchange.get("exchange"), int):
                 out["exchange"]["backend"] = {1: "RCCL ncclAllGather (1 element per rank) below the C ABI", 2: "peer reads"}.get(exchange["exchange"])
         if single is not None:
             out["single_gpu_same_workload"] = single
-        if world == 1 and workload == "c2" and not args.no_plan and hasattr(M, "CsrMVPlan"):
+        if not mg and workload == "c2" and not args.no_plan and hasattr(M, "CsrMVPlan"):
             out["prepared_plan"] = M.plan_bench_record(A, x, y, steps=args.steps, warmup=args.warmup, peak_gbs=HBM_PEAK_GBS)
-        if world == 1 and not args.no_cpu_baseline and A.nnz <= 400_000_000:
+        if not mg and not args.no_cpu_baseline and A.nnz <= 400_000_000:
             out["cpu_baseline"] = cpu_baseline(A, x, "same " + workload.upper() + " matrix")
         print(json.dumps(out), flush=True)
     if dist is not None:

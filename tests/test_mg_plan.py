@@ -256,3 +256,34 @@ def test_c5_full_size_eight_parts_every_row():
     ok, worst_whole = O.strict_check(whole, y_whole, gold[:n], sabs[:n], items_per_thread=16)
     assert ok, worst_whole
     print(f"\nC5 scale {scale}, {edges} edges, {parts} parts: worst |error|/bound = {worst:.3g} (8 parts), {worst_whole:.3g} (one GPU)")
+
+
+def _run_bench(env_extra, nproc, *args, timeout=600):
+    import json, subprocess, sys, socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ); env.update(env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), lines[-3:]          # the JSON line is the LAST line of stdout
+    return json.loads(lines[-1])
+
+
+@gpu
+def test_bench_multi_rank_path_on_one_device():
+    """bench.py --gpus N (N > 1 runs BASELINE config 5, one R-MAT matrix cut N ways) end to end on this one-GPU box, at a
+    reduced scale: (a) 2 ranks sharing the device, carries over gloo through the Python twin; (b) ONE rank forced through
+    the N > 1 code path: nccl process group, shipped RCCL id, the C operator's multi-process form with its
+    ncclAllGather inside the timed loop, the same-job single-GPU leg."""
+    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000")
+    out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo"}, 2, *small)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f64" and out["value"] > 0
+    assert "C5 R-MAT scale 18" in out["config"]["workload"] and "merge-path diagonal split over 2 GPUs" in out["config"]["partition"]
+    assert out["single_gpu_same_workload"]["n_gpus"] == 1 and out["single_gpu_same_workload"]["value"] > 0
+    out = _run_bench({"MSPMV_BENCH_FORCE_MG": "1"}, 1, *small)
+    assert out["n_gpus"] == 1 and "C5 R-MAT scale 18" in out["config"]["workload"]
+    assert out["exchange"]["exchange"] == MG.EXCHANGE_RCCL and out["exchange"]["carry_bytes_per_step"] == 8
+    assert out["roofline"]["kernel_ms"]["tile"] > 0 and out["single_gpu_same_workload"]["ms_per_step"] > 0
