@@ -693,3 +693,63 @@ def test_config3_through_the_matrix_market_path(M, tmp_path):
         off = np.fromfile(f, np.int32, rows + 1); col = np.fromfile(f, np.int32, nnz)
     assert (rows, cols, nnz) == (n, n, exp_cols.size)
     assert np.array_equal(off, exp_off.astype(np.int32)) and np.array_equal(col, exp_cols)
+
+
+@pytest.mark.gpu
+def test_calls_are_capturable_in_a_hip_graph(M):
+    """A stateless call is two or three kernel launches and nothing else (no allocation, no synchronisation, no runtime
+    query), and so is a plan SpMV: both can be captured into a hipGraph on the caller's stream and replayed with new x."""
+    rng = np.random.default_rng(3)
+    csr = random_csr(rng, 200000, 50000, rng.integers(0, 12, 200000), np.float32)
+    val, off, col = dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices)
+    x = torch.zeros(csr.cols, dtype=torch.float32, device="cuda")
+    y = torch.zeros(csr.rows, dtype=torch.float32, device="cuda"); yp = torch.zeros_like(y)
+    ws = M.CsrMVWorkspace(csr.rows, csr.nnz, torch.float32)
+    plan = M.CsrMVPlan(val, off, col, csr.cols, bands=8)
+    M.csrmv(val, off, col, x, y=y, num_cols=csr.cols, workspace=ws); plan(x, yp)          # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        M.csrmv(val, off, col, x, y=y, num_cols=csr.cols, workspace=ws)
+        plan(x, yp)
+    for seed in (1, 2):
+        xh = np.random.default_rng(seed).uniform(-1, 1, csr.cols).astype(np.float32)
+        x.copy_(torch.from_numpy(xh))
+        g.replay(); torch.cuda.synchronize()
+        check_strict(M, csr, xh, y.cpu().numpy())
+        gold, s = O.spmv_gold_acc64(csr, xh)
+        ok, worst = O.strict_check(csr, yp.cpu().numpy(), gold, s, items_per_thread=24)
+        assert ok, worst
+
+
+@pytest.mark.gpu
+def test_concurrent_host_threads_on_their_own_streams(M):
+    """The library keeps no per-call state: host threads calling it concurrently, each with its own temp storage and
+    stream, get bitwise the results of serial calls (ctypes releases the GIL for the duration of a call)."""
+    import threading
+    rng = np.random.default_rng(9)
+    jobs = []
+    for i in range(4):
+        dtype = np.float32 if i % 2 == 0 else np.float64
+        csr = random_csr(rng, 30000 + 7000 * i, 20000, rng.integers(0, 30, 30000 + 7000 * i), dtype)
+        xh = rng.uniform(-1, 1, csr.cols).astype(dtype)
+        t = (dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(xh))
+        tdt = torch.float32 if dtype == np.float32 else torch.float64
+        serial = M.csrmv(*t, num_cols=csr.cols).clone()
+        jobs.append((csr, t, tdt, serial))
+    torch.cuda.synchronize()
+    results = [None] * len(jobs)
+    def work(i):
+        csr, t, tdt, _ = jobs[i]
+        stream = torch.cuda.Stream()
+        ws = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)
+        y = torch.empty(csr.rows, dtype=tdt, device="cuda")
+        for _ in range(50):
+            M.csrmv(*t, y=y, num_cols=csr.cols, workspace=ws, stream=stream)
+        stream.synchronize()
+        results[i] = y
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    for (csr, t, tdt, serial), y in zip(jobs, results):
+        assert y is not None and torch.equal(y, serial)
