@@ -209,16 +209,26 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(const int *__restrict
     }
 }
 
-// y[r] = alpha * (y'[r] + y'[rows + r] + ...) + beta * y[r], bands added in order
-template <typename V>
+// y[r] = alpha * (y'[r] + y'[rows + r] + ...) + beta * y[r], bands added in order.  VEC: a thread folds one 16-byte unit
+// of rows per band (rows a multiple of the unit and y 16-byte aligned, so every band's row block is aligned too).
+template <typename V, bool VEC>
 __global__ __launch_bounds__(256) void plan_combine_kernel(const V *__restrict__ ypart, V *__restrict__ y, int rows, int bands, V alpha,
                                                            V beta)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+    constexpr int W = VEC ? 16 / (int) sizeof(V) : 1;
+    typedef V vec_t __attribute__((ext_vector_type(W)));
+    const long long r = ((long long) blockIdx.x * 256 + threadIdx.x) * W;
     if (r >= rows) return;
-    V s = ypart[r];
-    for (int b = 1; b < bands; ++b) s += __builtin_nontemporal_load(ypart + (size_t) b * rows + r);
-    y[r] = beta == (V) 0 ? alpha * s : alpha * s + beta * y[r];
+    if constexpr (VEC) {
+        vec_t s = *reinterpret_cast<const vec_t *>(ypart + r);
+        for (int b = 1; b < bands; ++b) s += __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(ypart + (size_t) b * rows + r));
+        vec_t *out = reinterpret_cast<vec_t *>(y + r);
+        *out = beta == (V) 0 ? alpha * s : alpha * s + beta * *out;
+    } else {
+        V s = ypart[r];
+        for (int b = 1; b < bands; ++b) s += __builtin_nontemporal_load(ypart + (size_t) b * rows + r);
+        y[r] = beta == (V) 0 ? alpha * s : alpha * s + beta * y[r];
+    }
 }
 
 #define PL_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int) e_; } while (0)
@@ -298,8 +308,12 @@ int plan_apply(void *d_plan, size_t plan_bytes, const V *d_x, V *d_y, int32_t ro
                                  reinterpret_cast<const int *>(base + L.offsets_off), reinterpret_cast<const int *>(base + L.cols_off),
                                  d_x, ypart, (int32_t) L.srows, cols, nnz, (V) 1, (V) 0, false, stream, debug_sync, ex);
     if (st != 0) return st;
-    const unsigned grid = (unsigned) ((rows + 255) / 256);
-    hipLaunchKernelGGL((plan_combine_kernel<V>), dim3(grid), dim3(256), 0, stream, ypart, d_y, rows, L.bands, alpha, beta);
+    constexpr int W = 16 / (int) sizeof(V);
+    const bool vec = rows % W == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0;
+    const long long units = vec ? rows / W : rows;
+    const unsigned grid = (unsigned) ((units + 255) / 256);
+    if (vec) hipLaunchKernelGGL((plan_combine_kernel<V, true>), dim3(grid), dim3(256), 0, stream, ypart, d_y, rows, L.bands, alpha, beta);
+    else hipLaunchKernelGGL((plan_combine_kernel<V, false>), dim3(grid), dim3(256), 0, stream, ypart, d_y, rows, L.bands, alpha, beta);
     return launched(stream, debug_sync, "plan_combine_kernel", grid);
 }
 
