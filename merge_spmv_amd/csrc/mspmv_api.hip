@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <random>
 #include <vector>
 
 #include "../../include/mspmv.h"
@@ -23,13 +24,15 @@
 namespace mspmv {
 
 constexpr int SEARCH_BLOCK = 256;
+constexpr int SINGLE_LAUNCH_MAX_TILES = 2048;   // (a forced shape / MSPMV_FUSED_MAX_TILES may put more tiles on the self-searching kernel)
 constexpr int INTERP_MIN_ROWS = 10000000;       // coordinate pass: interpolation search from here up, scatter pass below
 constexpr int FUSED_CHUNK_LOG2 = 0;      // XCD-chunked mapping (see the tile_kernel_vec dispatch): no measurable effect below 2048 tiles
 constexpr int MM_CHUNK_LOG2 = 6;         // ... 0-3 % on the SpMM tiles
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
-constexpr int FUSED_MAX_TILES_DEFAULT = 2048;    // up to here: tiles search their own coordinates (one launch less)
+constexpr int FUSED_MAX_TILES_DEFAULT = 1280;    // up to here: tiles search their own coordinates and add the carries themselves
+                                                 // (beyond, the self-searching kernel + fix-up is slower than the three-pass pipeline)
 // (MSPMV_FUSED_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
 static int fused_max_tiles()
 {
@@ -48,12 +51,14 @@ static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128,
 struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}; };
 static Tuning g_tune[2];  // [0] = 4-byte values, [1] = 8-byte values
 
-// Default shape.  Problems of up to FUSED_MAX_TILES tiles take the smallest compiled tile that
-// keeps them within that count (more, smaller tiles = more blocks in flight on a small matrix)
-// and run tile_kernel_fused + one fix-up launch.  Everything larger uses 256x11 for both
-// precisions: measured on MI355X (tools/sweep.py, profiles/r01_sweep_vs_rocsparse.txt) it is
-// the fastest or within 1 % of the fastest compiled shape on every workload tried, and fewer
-// tiles also shorten the coordinate pass and the fix-up.
+// Default shape (measured on MI355X; profiles/r02_small_problem_shapes.txt, r01_sweep_vs_rocsparse.txt):
+//  * a problem that fits ONE compiled tile takes it: one launch, no carries;
+//  * a problem that some compiled tile cuts into at most FUSED_MAX_TILES (1280) tiles runs tile_kernel_fused in ONE
+//    launch (the tiles search their own coordinates and add the carries themselves): the smallest tile that keeps it
+//    within 896 tiles (more, smaller tiles = more CUs busy on a small matrix), else the largest tile;
+//  * everything larger runs the three-pass pipeline (coordinates, tiles, fix-up): 256x11 -- the fastest or within 1 % of
+//    the fastest shape on every large workload tried -- except fp64 problems of up to 24 M path items, where 256x7
+//    (7 resident blocks per CU instead of 5) is 2-4 % faster.
 static Shape pick_shape(int value_bytes, long long items, int &flags)
 {
     Tuning &t = g_tune[value_bytes == 8];
@@ -61,13 +66,15 @@ static Shape pick_shape(int value_bytes, long long items, int &flags)
     if (t.block.load() > 0) return Shape{t.block.load(), t.ipt.load()};
     static const int ipts32[] = {7, 9, 11, 15}, ipts64[] = {5, 7, 9, 11};
     const int *ipts = value_bytes == 8 ? ipts64 : ipts32;
+    auto tiles = [&](int ipt) { return (items + 256LL * ipt - 1) / (256LL * ipt); };
     if (!(flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED))) {
-        // a problem that fits ONE compiled tile needs no carry fix-up: one launch (~7 us) instead of two (~13 us)
         for (int i = 0; i < 4; ++i)
             if (items <= 256LL * ipts[i]) return Shape{256, ipts[i]};
         for (int i = 0; i < 4; ++i)
-            if ((items + 256LL * ipts[i] - 1) / (256LL * ipts[i]) <= FUSED_MAX_TILES) return Shape{256, ipts[i]};
+            if (tiles(ipts[i]) <= 896) return Shape{256, ipts[i]};
+        if (tiles(ipts[3]) <= FUSED_MAX_TILES) return Shape{256, ipts[3]};
     }
+    if (value_bytes == 8 && items <= 24000000LL) return Shape{256, 7};
     return Shape{256, 11};
 }
 
@@ -77,7 +84,8 @@ struct Layout {
     bool fused;            // small: tile_kernel_fused (needs aligned arrays, decided again at launch)
     int fix_n[3];          // pairs entering fix-up level i (fix_n[0] == num_tiles)
     int fix_levels;
-    uint64_t coords_off, carries_off, fix_off[2], total;
+    uint64_t coords_off, carries_off, fix_off[2], pub_off, total;
+    bool single_launch;    // fused AND the carries are added by the tiles themselves (no fix-up launch)
 };
 
 static Layout make_layout(int rows, int nnz, int value_bytes)
@@ -92,6 +100,12 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     L.coords_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(Coord));
     L.carries_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * pair);
     L.fused = !(L.flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED)) && L.num_tiles <= FUSED_MAX_TILES;
+    // small problems: the tiles publish their carries and add them themselves (2 x 8 bytes per tile); no fix-up launch
+    // (up to the tile count at which every block of the heaviest kernel is resident at once; measured: 4-975 tiles
+    // 2.2-3.2 us faster than two launches, 1405 tiles 1.2 us faster, 1912 tiles equal to 1 us slower)
+    L.single_launch = L.fused && L.num_tiles > 1 && L.num_tiles <= SINGLE_LAUNCH_MAX_TILES &&
+                      !(L.flags & (MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX));
+    if (L.fused) { L.pub_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * 16); }
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
@@ -146,6 +160,20 @@ static inline void prof_mark(hipStream_t stream, int slot, int which)
 }
 
 #define MSPMV_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+// per-call tag of the published carries (LookBack, mspmv_kernels.hpp): a counter from a random start through a
+// 64-bit mixer, so that neither a previous call nor whatever another process left in recycled memory can look current
+static unsigned long long next_call_tag()
+{
+    static std::atomic<unsigned long long> counter{[] {
+        std::random_device rd;
+        return ((unsigned long long) rd() << 32) ^ (unsigned long long) rd() ^ (unsigned long long) (uintptr_t) &rd;
+    }()};
+    unsigned long long z = counter.fetch_add(0x9E3779B97F4A7C15ull, std::memory_order_relaxed) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 
 static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *name, unsigned grid, unsigned block)
 {
@@ -234,8 +262,17 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const int fchunk_flag = (L.flags >> 24) & 0xf;
         const int fchunk = fchunk_flag == 0 ? FUSED_CHUNK_LOG2 : fchunk_flag == 15 ? 0 : fchunk_flag;
         const size_t xl = (size_t) p.x_lds * sizeof(V);
-        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, fchunk);
-        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, fchunk);
+        LookBack lb; lb.rec = nullptr; lb.tag_a = lb.tag_b = 0;
+        int map = fchunk;
+        if (L.single_launch) {
+            const unsigned long long tag = next_call_tag();
+            lb.rec = reinterpret_cast<unsigned long long *>(base + L.pub_off);
+            lb.tag_a = (unsigned) (tag >> 32) | 1u;                 // never 0: a cleared record is never valid
+            lb.tag_b = (unsigned) tag & 0x7fffffffu;
+            map = 0;                                                // blocks take tiles in block order: a tile waits on a lower-numbered block only
+        }
+        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, map, lb);
+        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, map, lb);
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
     } else {
     // 1. tile boundary coordinates
@@ -306,9 +343,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         MSPMV_CHECK(after_launch(stream, debug_sync, vec ? "tile_kernel_vec" : "tile_kernel", grid, BLOCK));
     }
     }
-    // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair)
+    // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair; nor when the self-searching
+    //    tiles of a small problem have added the carries themselves)
     prof_mark(stream, slot, 2);
-    if (L.num_tiles > 1) {
+    if (L.num_tiles > 1 && !(fused && L.single_launch)) {
         if (L.flags & MSPMV_TUNE_ATOMIC_FIX) {
             const unsigned grid = (unsigned) ((L.num_tiles + FIX_BLOCK - 1) / FIX_BLOCK);
             hipLaunchKernelGGL((fixup_atomic_kernel<V, FIX_BLOCK>), dim3(grid), dim3(FIX_BLOCK), 0, stream, carries,
@@ -677,7 +715,7 @@ int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_
     info->tile_items = L.shape.block * L.shape.ipt;
     info->num_tiles = L.num_tiles;
     info->fixup_chunk = FIX_CHUNK;
-    info->fixup_levels = L.fix_levels;
+    info->fixup_levels = L.single_launch ? 0 : L.fix_levels;     // (fix-up launches; 0: the tiles add the carries themselves)
     info->flags = L.flags;
     info->temp_bytes = L.total;
     info->coords_offset = L.coords_off;
@@ -716,7 +754,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
-    int allowed = MSPMV_TUNE_SCATTER_COORDS | MSPMV_TUNE_INTERP_COORDS | MSPMV_TUNE_NO_XLDS | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
+    int allowed = MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_SCATTER_COORDS | MSPMV_TUNE_INTERP_COORDS | MSPMV_TUNE_NO_XLDS | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
                   MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xf000000;
 #ifdef MSPMV_DEV
     allowed |= MSPMV_DEV_FLAG_BITS;        // development kernels (mspmv_dev.hpp): never in the product library

@@ -565,6 +565,114 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 }
 
 // ---------------------------------------------------------------------------
+// Carries without a second launch (small problems: tile_kernel_fused).  The per-tile carries are LOCAL partial sums --
+// no tile needs another tile's result to compute its own -- so the fix-up "y[row] += carries of the tiles before the one in
+// which the row ends" can be done by that tile itself: every tile PUBLISHES its carry as soon as its scan is done, and a
+// tile with row ends walks back over its predecessors' records -- tile t-1, t-2, ... up to and including the first one
+// that has a row end of its own (the tile in which the row began) -- adds what it finds to its first row, and clears
+// the records it consumed.  There is no chain of waits (a waiting tile waits for ONE other block to run, and that block
+// waits for nobody), blocks take tiles in block order on this path, and workgroups are dispatched in order: the
+// awaited block is running or done.  The reference's fp64 fix-up relies on the same property (decoupled look-back,
+// agent_segment_fixup.cuh:262-341 with single_pass_scan_operators.cuh); unlike it, nothing here spins on a chain.
+// A record is two 64-bit words, each carrying half of a per-call tag beside its payload, written and read with
+// relaxed agent-scope atomics (visible across the XCDs' L2s without a cache flush): a word is valid when its tag
+// matches, so no ordering between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits,
+// and consumers clear what they read (each record has exactly one consumer), which also makes a captured call
+// replayable with the same tags.  Polling is bounded (~seconds); running out poisons the row with NaN instead of hanging.
+// Summation order is fixed (nearest predecessor first, then a fixed wave tree): bitwise reproducible.
+// ---------------------------------------------------------------------------
+struct LookBack {
+    unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
+    unsigned tag_a, tag_b;        // tag_b uses 31 bits
+};
+template <typename V> struct LbBits;
+template <> struct LbBits<float> {
+    static __device__ __forceinline__ void split(float v, unsigned &p0, unsigned &p1) { p0 = __builtin_bit_cast(unsigned, v); p1 = 0u; }
+    static __device__ __forceinline__ float join(unsigned p0, unsigned) { return __builtin_bit_cast(float, p0); }
+};
+template <> struct LbBits<double> {
+    static __device__ __forceinline__ void split(double v, unsigned &p0, unsigned &p1)
+    { const unsigned long long b = __builtin_bit_cast(unsigned long long, v); p0 = (unsigned) (b >> 32); p1 = (unsigned) b; }
+    static __device__ __forceinline__ double join(unsigned p0, unsigned p1)
+    { return __builtin_bit_cast(double, ((unsigned long long) p0 << 32) | p1); }
+};
+template <typename V>
+__device__ __forceinline__ void lb_publish(const LookBack &lb, int tile, V value, bool has_row_end)
+{
+    unsigned p0, p1; LbBits<V>::split(value, p0, p1);
+    const unsigned long long w0 = ((unsigned long long) lb.tag_a << 32) | p0;
+    const unsigned long long w1 = ((unsigned long long) ((lb.tag_b << 1) | (has_row_end ? 1u : 0u)) << 32) | p1;
+    __hip_atomic_store(&lb.rec[2 * (size_t) tile], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&lb.rec[2 * (size_t) tile + 1], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one look at the record of tile s: valid (both words carry this call's tag)?  value and has-row-end flag if so
+template <typename V>
+__device__ __forceinline__ bool lb_peek(const LookBack &lb, int s, V &value, bool &has_row_end)
+{
+    const unsigned long long w0 = __hip_atomic_load(&lb.rec[2 * (size_t) s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(&lb.rec[2 * (size_t) s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = (unsigned) (w0 >> 32) == lb.tag_a && ((unsigned) (w1 >> 32) >> 1) == lb.tag_b;
+    has_row_end = ok && ((unsigned) (w1 >> 32) & 1u) != 0u;
+    value = ok ? LbBits<V>::join((unsigned) w0, (unsigned) w1) : (V) 0;
+    return ok;
+}
+__device__ __forceinline__ void lb_clear(const LookBack &lb, int s)
+{
+    __hip_atomic_store(&lb.rec[2 * (size_t) s], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&lb.rec[2 * (size_t) s + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int LB_MAX_POLLS = 1 << 21;       // x ~1 us: seconds; running out poisons the row with NaN instead of hanging
+// Sum of the carries that belong to the first row of `tile` (tile > 0): the records of tiles tile-1, tile-2, ... up to and
+// including the first one that has a row end of its own (or tile 0).  Called by ALL lanes of one wave; wave-uniform
+// result.  Records are taken in FIXED windows (tile-1 alone, then 64 at a time) and only once everything needed of a
+// window is there, so the association order does not depend on timing.  Records beyond the walk's end belong to other
+// rows' walks and are neither waited for nor touched.
+template <typename V>
+__device__ __forceinline__ V lb_lookback(const LookBack &lb, int tile)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    int polls = 0;
+    // common case (rows shorter than a tile): only the tile just before contributes
+    V v0 = 0; bool end0 = false; bool ok0 = true;
+    if (lane == 0) {
+        ok0 = false;
+        while (!ok0 && polls < LB_MAX_POLLS) { ok0 = lb_peek<V>(lb, tile - 1, v0, end0); if (!ok0) { ++polls; __builtin_amdgcn_s_sleep(2); } }
+        if (ok0) lb_clear(lb, tile - 1);
+    }
+    polls = __shfl(polls, 0, WAVE);
+    if (!__shfl((int) ok0, 0, WAVE)) return (V) __builtin_nan("");
+    v0 = __shfl(v0, 0, WAVE);
+    if (__shfl((int) end0, 0, WAVE) || tile - 1 == 0) return v0;
+    // a row spanning several tiles: 64 predecessors per window, nearest first
+    V total = v0;
+    for (int base = tile - 2;; base -= WAVE) {
+        const int s = base - lane;
+        V v = 0; int f = -1, k = 0;
+        for (;;) {
+            bool e = false, ok = true;
+            v = 0;
+            if (s >= 0) ok = lb_peek<V>(lb, s, v, e);
+            const unsigned long long valid = __ballot(ok);
+            k = valid == ~0ull ? WAVE : __ffsll((long long) ~valid) - 1;                       // length of the valid prefix
+            const unsigned long long in_prefix = k == WAVE ? ~0ull : ((1ull << k) - 1ull);
+            const unsigned long long stop = __ballot(ok && s >= 0 && (e || s == 0)) & in_prefix;
+            f = stop ? __ffsll((long long) stop) - 1 : -1;
+            if (f >= 0 || k == WAVE) break;                                                    // the walk ends here, or the whole window is there
+            if (++polls >= LB_MAX_POLLS) return (V) __builtin_nan("");
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const int take = f >= 0 ? f + 1 : WAVE;                                                // lanes [0, take) are consumed
+        if (lane < take && s >= 0) lb_clear(lb, s);
+        V part = (lane < take && s >= 0) ? v : (V) 0;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
+        total += part;
+        if (f >= 0) break;
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------------------
 // In-tile reduction of the production kernels: head flags + segmented scan.
 //
 // The reference walks the tile's merge path thread by thread (a binary search per
@@ -666,7 +774,8 @@ template <typename V, int BLOCK, int IPT, bool AXPBY>
 __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
                                                    const end16_t *s_end, V *s_prod_raw, unsigned *s_flag,
                                                    int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
-                                                   int pshift, unsigned long long *tr = nullptr)
+                                                   int pshift, unsigned long long *tr = nullptr, const LookBack *lb = nullptr,
+                                                   int tile = 0, int num_tiles = 0)
 {
     constexpr int CPT = IPT / 4 + 1;
     constexpr int NPT = CPT * 4;                  // staged products per thread
@@ -705,6 +814,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
             for (int k = 0; k < NPT; ++k) v = (tile_nnz > 0 && k == last % NPT) ? s[k] : v;
             Carry<V> c; c.key = c0.x; c.value = v;
             *carry_out = c;
+            if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, v, false);     // (nobody reads the last tile's carry)
         }
         return;
     }
@@ -714,21 +824,28 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
     if (tr && tid == 0) tr[7] = clock64();
     if (tid < FLAG_WORDS) s_flag[tid] = 0u;       // clean for the next tile's staging (after the loop's barrier)
 
+    // ---- the row left open at the tile end (ref: agent_spmv_orig.cuh:906-913): the carry.  Written -- and, on the
+    //      single-launch path, published for the tile in which that row ends -- BEFORE the row phase, as early as it exists
+    if (tid == BLOCK - 1) {
+        const int e_last = tile_rows > 0 ? s_end[tile_rows - 1] : 0;
+        Carry<V> c; c.key = c0.x + tile_rows;
+        c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
+        *carry_out = c;
+        if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, c.value, true);
+    }
+    // single-launch path: what the earlier tiles hold of this tile's first row (wave 0 walks back; thread 0 stores row 0)
+    V first_row_carry = 0;
+    if (lb && tile > 0 && tid < WAVE) first_row_carry = lb_lookback<V>(*lb, tile);
+
     // ---- row phase
     V *__restrict__ y = p.y + c0.x;
     for (int r = tid; r < tile_rows; r += BLOCK) {
         const int e = s_end[r];
         const int e0 = r > 0 ? s_end[r - 1] : 0;
-        const V sum = e > e0 ? s_prod_raw[prod_slot<V, CPT>(pshift + e - 1)] : (V) 0;
+        V sum = e > e0 ? s_prod_raw[prod_slot<V, CPT>(pshift + e - 1)] : (V) 0;
+        if (r == 0) sum += first_row_carry;
         if (AXPBY) y[r] = p.alpha * sum + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
         else y[r] = sum;
-    }
-    if (tid == BLOCK - 1) {
-        // the row left open at the tile end (ref: agent_spmv_orig.cuh:906-913)
-        const int e_last = tile_rows > 0 ? s_end[tile_rows - 1] : 0;
-        Carry<V> c; c.key = c0.x + tile_rows;
-        c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
-        *carry_out = c;
     }
 }
 
@@ -1386,7 +1503,8 @@ __global__ __launch_bounds__(BLOCK) void fixup_onepass_kernel(const Carry<V> *__
 // ---------------------------------------------------------------------------
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>())) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
-                                                           Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2)
+                                                           Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2,
+                                                           LookBack lb)
 {
     constexpr int TILE = BLOCK * IPT;
     constexpr int NW = BLOCK / WAVE;
@@ -1428,7 +1546,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
     consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                             s_wave_key, s_wave_val, carries + tile, pshift);
+                                             s_wave_key, s_wave_val, carries + tile, pshift, nullptr, lb.rec ? &lb : nullptr, tile, num_tiles);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

@@ -65,13 +65,21 @@ def test_tuning_rejects_unknown_shapes():
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 9
     M.set_tuning(4)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
-    # default shapes: small -> 256x7 / 256x5, a little larger -> the smallest shape with <= 2048 tiles,
-    # large -> 256x11
-    assert M.launch_info(1_000_000, 3_500_000, 4)["items_per_thread"] == 9      # 4.5M items / 2304 = 1954 tiles
-    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 1     # one-launch fix-up whatever the carry count
-    M.set_tuning(4, 0, 0, 128)                                                     # the chunked multi-level variant
-    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2     # 1954 carries / 512 per block -> 2 launches
+    # default shapes: one tile when the problem fits one; the smallest tile that keeps a small problem within 896 tiles,
+    # else the largest if that keeps it within 1280 (both: ONE launch, the tiles add the carries themselves);
+    # beyond: the three-pass pipeline with 256x11 (fp64 up to 24 M path items: 256x7)
+    assert M.launch_info(300_000, 1_000_000, 4)["items_per_thread"] == 7         # 1.3M items / 1792 = 726 tiles
+    assert M.launch_info(1_000_000, 3_500_000, 4)["items_per_thread"] == 15      # 4.5M items / 3840 = 1172 tiles
+    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 0           # no fix-up launch
+    M.set_tuning(4, 0, 0, 0x40000000)                                            # ... unless asked for: one launch of the one-pass kernel
+    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 1
+    M.set_tuning(4, 0, 0, 128)                                                   # the chunked multi-level variant
+    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2           # 1172 carries / 512 per block -> 2 launches
     M.set_tuning(4)
+    assert M.launch_info(1_000_000, 5_000_000, 4)["items_per_thread"] == 11      # 6M items: 1563 tiles even at 256x15 -> three passes
+    assert M.launch_info(1_000_000, 5_000_000, 4)["fixup_levels"] == 1
+    assert M.launch_info(1_000_000, 5_000_000, 8)["items_per_thread"] == 7       # fp64 mid-size: 256x7
+    assert M.launch_info(4_000_000, 30_000_000, 8)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 4)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 11
     with pytest.raises(M.MspmvError):

@@ -136,10 +136,11 @@ SHAPES = {
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("path", ["single_launch", "multi_launch", "interp_coords", "contiguous_map", "reference_walk"])
+@pytest.mark.parametrize("path", ["single_launch", "two_launch", "multi_launch", "interp_coords", "contiguous_map", "reference_walk"])
 def test_random_and_degenerate_shapes(M, shape, prec, path):
     """Every dispatch path on the same inputs: small problems take tile_kernel_fused (own coordinate
-    search); MSPMV_TUNE_NO_FUSED forces the large-problem pipeline (coordinate pass + tile_kernel_vec,
+    search, and the tiles add the carries themselves: ONE launch; "two_launch" = the same kernel followed by the fix-up
+    launch); MSPMV_TUNE_NO_FUSED forces the large-problem pipeline (coordinate pass + tile_kernel_vec,
     one tile per block + fix-up launches; coordinates by the one-pass scatter over all row offsets, or with
     "interp_coords" by the per-boundary interpolation search that large matrices use); "contiguous_map" = the same with runs of 2^14 tiles per XCD (the
     mapping family the prepared plan uses); "reference_walk" = the dword-per-lane kernel with the reference's
@@ -150,7 +151,7 @@ def test_random_and_degenerate_shapes(M, shape, prec, path):
     csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
     x = rng.uniform(-1, 1, size=cols).astype(dtype)
     try:
-        M.set_tuning(vb, 0, 0, {"single_launch": 0, "multi_launch": 16, "interp_coords": 0x20000010, "contiguous_map": 0xE000010, "reference_walk": 4 | 16}[path])
+        M.set_tuning(vb, 0, 0, {"single_launch": 0, "two_launch": 0x40000000, "multi_launch": 16, "interp_coords": 0x20000010, "contiguous_map": 0xE000010, "reference_walk": 4 | 16}[path])
         y, ws = run_gpu(M, csr, x)
         assert not np.isnan(y).any(), "a row was never written"
         check_strict(M, csr, x, y)
@@ -203,7 +204,7 @@ def test_all_ones_giant_row_is_exact(M):
 # kernel with the reference's in-tile walk, +8 binary-search coordinate pass, 32/64 forced stream policy,
 # 128 = multi-level fix-up (default: one launch); bits 24-27 = block->tile mapping (0xF: round-robin, 3: runs of 8);
 # 0x20000000 = coordinates by the per-boundary interpolation search (the default from 10 M rows up; scatter pass below)
-@pytest.mark.parametrize("flags", [0, 2, 4, 16, 18, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0x20000010])
+@pytest.mark.parametrize("flags", [0, 2, 4, 16, 18, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0x20000010, 0x40000000])
 def test_every_compiled_tile_shape(M, vb, block, ipt, flags):
     dtype = np.float32 if vb == 4 else np.float64
     rng = np.random.default_rng(block * 100 + ipt)

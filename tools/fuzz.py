@@ -11,7 +11,7 @@ import numpy as np, torch
 import merge_spmv_amd as M
 from merge_spmv_amd import multi_gpu as MG
 
-FLAGS = [0, 0, 0, 2, 4, 8, 16, 16, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0xE000010, 0x20000010, 0x20000000]
+FLAGS = [0, 0, 0, 2, 4, 8, 16, 16, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0xE000010, 0x20000010, 0x20000000, 0x40000000, 0x40000000]
 SHAPES = {4: [(256, 7), (256, 5), (256, 9), (256, 11), (128, 7), (512, 7), (256, 15)],
           8: [(256, 5), (256, 3), (256, 7), (256, 9), (128, 5), (512, 5), (256, 11)]}
 
