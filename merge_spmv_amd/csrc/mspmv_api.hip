@@ -4,7 +4,7 @@
 // (cub/device/dispatch/dispatch_spmv_orig.cuh:544-752) -- without that
 // dispatcher's per-call device-attribute / occupancy queries and texture
 // bind/unbind (all inside the reference's timed loop): grid shapes here are
-// pure arithmetic on (rows, nnz), so a call is two or three kernel launches
+// pure arithmetic on (rows, nnz), so a call is one to three kernel launches
 // and nothing else.  Also here: the prepared-call and SpMM entry points.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -268,7 +268,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             const unsigned long long tag = next_call_tag();
             lb.rec = reinterpret_cast<unsigned long long *>(base + L.pub_off);
             lb.tag_a = (unsigned) (tag >> 32) | 1u;                 // never 0: a cleared record is never valid
-            lb.tag_b = (unsigned) tag & 0x7fffffffu;
+            lb.tag_b = (unsigned) tag;
             map = 0;                                                // blocks take tiles in block order: a tile waits on a lower-numbered block only
         }
         if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, map, lb);

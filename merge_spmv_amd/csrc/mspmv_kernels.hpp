@@ -567,23 +567,25 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 // ---------------------------------------------------------------------------
 // Carries without a second launch (small problems: tile_kernel_fused).  The per-tile carries are LOCAL partial sums --
 // no tile needs another tile's result to compute its own -- so the fix-up "y[row] += carries of the tiles before the one in
-// which the row ends" can be done by that tile itself: every tile PUBLISHES its carry as soon as its scan is done, and a
-// tile with row ends walks back over its predecessors' records -- tile t-1, t-2, ... up to and including the first one
-// that has a row end of its own (the tile in which the row began) -- adds what it finds to its first row, and clears
-// the records it consumed.  There is no chain of waits (a waiting tile waits for ONE other block to run, and that block
-// waits for nobody), blocks take tiles in block order on this path, and workgroups are dispatched in order: the
-// awaited block is running or done.  The reference's fp64 fix-up relies on the same property (decoupled look-back,
-// agent_segment_fixup.cuh:262-341 with single_pass_scan_operators.cuh); unlike it, nothing here spins on a chain.
+// which the row ends" can be done by that tile itself.  Every tile PUBLISHES its carry as soon as its scan is done.  A
+// tile with row ends knows exactly which earlier tiles hold pieces of its first row r = c0.x: the row's first nonzero is
+// path item r + row_offsets[r], i.e. it lies in tile (r + row_offsets[r]) / TILE, so the pieces are the carries of tiles
+// [that tile, this tile) -- none when the row starts in this tile, one for rows shorter than a tile, many for a giant
+// row.  The tile takes exactly those records (one lane each: up to 64 by wave 0 alone while the other waves run the row
+// phase, longer lists by the whole block), adds them to its first row in a fixed order and clears them.  There is no
+// chain of waits (a waiting tile waits for blocks that wait for nobody before publishing), blocks take tiles in block
+// order on this path, and workgroups are dispatched in order: an awaited block is running or done.  The reference's
+// fp64 fix-up relies on the same property (decoupled look-back, agent_segment_fixup.cuh:262-341 with
+// single_pass_scan_operators.cuh); unlike it, nothing here spins on a chain.
 // A record is two 64-bit words, each carrying half of a per-call tag beside its payload, written and read with
 // relaxed agent-scope atomics (visible across the XCDs' L2s without a cache flush): a word is valid when its tag
 // matches, so no ordering between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits,
-// and consumers clear what they read (each record has exactly one consumer), which also makes a captured call
+// and consumers clear what they read (each record has at most one consumer), which also makes a captured call
 // replayable with the same tags.  Polling is bounded (~seconds); running out poisons the row with NaN instead of hanging.
-// Summation order is fixed (nearest predecessor first, then a fixed wave tree): bitwise reproducible.
 // ---------------------------------------------------------------------------
 struct LookBack {
     unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
-    unsigned tag_a, tag_b;        // tag_b uses 31 bits
+    unsigned tag_a, tag_b;        // tag_a is never 0 (a cleared word is never valid)
 };
 template <typename V> struct LbBits;
 template <> struct LbBits<float> {
@@ -597,78 +599,57 @@ template <> struct LbBits<double> {
     { return __builtin_bit_cast(double, ((unsigned long long) p0 << 32) | p1); }
 };
 template <typename V>
-__device__ __forceinline__ void lb_publish(const LookBack &lb, int tile, V value, bool has_row_end)
+__device__ __forceinline__ void lb_publish(const LookBack &lb, int tile, V value)
 {
     unsigned p0, p1; LbBits<V>::split(value, p0, p1);
-    const unsigned long long w0 = ((unsigned long long) lb.tag_a << 32) | p0;
-    const unsigned long long w1 = ((unsigned long long) ((lb.tag_b << 1) | (has_row_end ? 1u : 0u)) << 32) | p1;
-    __hip_atomic_store(&lb.rec[2 * (size_t) tile], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&lb.rec[2 * (size_t) tile + 1], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one look at the record of tile s: valid (both words carry this call's tag)?  value and has-row-end flag if so
-template <typename V>
-__device__ __forceinline__ bool lb_peek(const LookBack &lb, int s, V &value, bool &has_row_end)
-{
-    const unsigned long long w0 = __hip_atomic_load(&lb.rec[2 * (size_t) s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w1 = __hip_atomic_load(&lb.rec[2 * (size_t) s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool ok = (unsigned) (w0 >> 32) == lb.tag_a && ((unsigned) (w1 >> 32) >> 1) == lb.tag_b;
-    has_row_end = ok && ((unsigned) (w1 >> 32) & 1u) != 0u;
-    value = ok ? LbBits<V>::join((unsigned) w0, (unsigned) w1) : (V) 0;
-    return ok;
-}
-__device__ __forceinline__ void lb_clear(const LookBack &lb, int s)
-{
-    __hip_atomic_store(&lb.rec[2 * (size_t) s], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&lb.rec[2 * (size_t) s + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&lb.rec[2 * (size_t) tile], ((unsigned long long) lb.tag_a << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&lb.rec[2 * (size_t) tile + 1], ((unsigned long long) lb.tag_b << 32) | p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr int LB_MAX_POLLS = 1 << 21;       // x ~1 us: seconds; running out poisons the row with NaN instead of hanging
-// Sum of the carries that belong to the first row of `tile` (tile > 0): the records of tiles tile-1, tile-2, ... up to and
-// including the first one that has a row end of its own (or tile 0).  Called by ALL lanes of one wave; wave-uniform
-// result.  Records are taken in FIXED windows (tile-1 alone, then 64 at a time) and only once everything needed of a
-// window is there, so the association order does not depend on timing.  Records beyond the walk's end belong to other
-// rows' walks and are neither waited for nor touched.
+// the carry tile s published: waits (bounded) until both words carry this call's tag, then clears the record
 template <typename V>
-__device__ __forceinline__ V lb_lookback(const LookBack &lb, int tile)
+__device__ __forceinline__ V lb_take(const LookBack &lb, int s)
+{
+    for (int polls = 0; polls < LB_MAX_POLLS; ++polls) {
+        const unsigned long long w0 = __hip_atomic_load(&lb.rec[2 * (size_t) s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w1 = __hip_atomic_load(&lb.rec[2 * (size_t) s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned) (w0 >> 32) == lb.tag_a && (unsigned) (w1 >> 32) == lb.tag_b) {
+            __hip_atomic_store(&lb.rec[2 * (size_t) s], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&lb.rec[2 * (size_t) s + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return LbBits<V>::join((unsigned) w0, (unsigned) w1);
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return (V) __builtin_nan("");           // never seen in practice: loud, not a hang
+}
+// Sum of the carries of tiles [tile - count, tile) -- the pieces of this tile's first row held by earlier tiles --
+// taken by the lanes of ONE wave (count <= 64), nearest tile on lane 0; fixed butterfly order; wave-uniform result.
+template <typename V>
+__device__ __forceinline__ V lb_take_wave(const LookBack &lb, int tile, int count)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    int polls = 0;
-    // common case (rows shorter than a tile): only the tile just before contributes
-    V v0 = 0; bool end0 = false; bool ok0 = true;
-    if (lane == 0) {
-        ok0 = false;
-        while (!ok0 && polls < LB_MAX_POLLS) { ok0 = lb_peek<V>(lb, tile - 1, v0, end0); if (!ok0) { ++polls; __builtin_amdgcn_s_sleep(2); } }
-        if (ok0) lb_clear(lb, tile - 1);
-    }
-    polls = __shfl(polls, 0, WAVE);
-    if (!__shfl((int) ok0, 0, WAVE)) return (V) __builtin_nan("");
-    v0 = __shfl(v0, 0, WAVE);
-    if (__shfl((int) end0, 0, WAVE) || tile - 1 == 0) return v0;
-    // a row spanning several tiles: 64 predecessors per window, nearest first
-    V total = v0;
-    for (int base = tile - 2;; base -= WAVE) {
-        const int s = base - lane;
-        V v = 0; int f = -1, k = 0;
-        for (;;) {
-            bool e = false, ok = true;
-            v = 0;
-            if (s >= 0) ok = lb_peek<V>(lb, s, v, e);
-            const unsigned long long valid = __ballot(ok);
-            k = valid == ~0ull ? WAVE : __ffsll((long long) ~valid) - 1;                       // length of the valid prefix
-            const unsigned long long in_prefix = k == WAVE ? ~0ull : ((1ull << k) - 1ull);
-            const unsigned long long stop = __ballot(ok && s >= 0 && (e || s == 0)) & in_prefix;
-            f = stop ? __ffsll((long long) stop) - 1 : -1;
-            if (f >= 0 || k == WAVE) break;                                                    // the walk ends here, or the whole window is there
-            if (++polls >= LB_MAX_POLLS) return (V) __builtin_nan("");
-            __builtin_amdgcn_s_sleep(2);
-        }
-        const int take = f >= 0 ? f + 1 : WAVE;                                                // lanes [0, take) are consumed
-        if (lane < take && s >= 0) lb_clear(lb, s);
-        V part = (lane < take && s >= 0) ? v : (V) 0;
+    V part = lane < count ? lb_take<V>(lb, tile - 1 - lane) : (V) 0;
+    if (count > 1) {
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
-        total += part;
-        if (f >= 0) break;
-    }
+    } else part = __shfl(part, 0, WAVE);
+    return part;
+}
+// The same for a long list (a row spanning more than 64 tiles), by the whole block: thread j takes tiles tile-1-j,
+// tile-1-j-BLOCK, ... in that order; wave butterflies; the wave partials in wave order.  Block-uniform call (it has a
+// barrier); the result is valid on thread 0.
+template <typename V, int BLOCK>
+__device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int count, V *s_wave_val)
+{
+    V part = 0;
+    for (int i = threadIdx.x; i < count; i += BLOCK) part += lb_take<V>(lb, tile - 1 - i);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_wave_val[threadIdx.x / WAVE] = part;
+    __syncthreads();
+    V total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / WAVE; ++w) total += s_wave_val[w];
     return total;
 }
 
@@ -775,7 +756,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
                                                    const end16_t *s_end, V *s_prod_raw, unsigned *s_flag,
                                                    int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
                                                    int pshift, unsigned long long *tr = nullptr, const LookBack *lb = nullptr,
-                                                   int tile = 0, int num_tiles = 0)
+                                                   int tile = 0, int num_tiles = 0, int first_row_tile = 0)
 {
     constexpr int CPT = IPT / 4 + 1;
     constexpr int NPT = CPT * 4;                  // staged products per thread
@@ -814,7 +795,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
             for (int k = 0; k < NPT; ++k) v = (tile_nnz > 0 && k == last % NPT) ? s[k] : v;
             Carry<V> c; c.key = c0.x; c.value = v;
             *carry_out = c;
-            if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, v, false);     // (nobody reads the last tile's carry)
+            if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, v);            // (nobody reads the last tile's carry)
         }
         return;
     }
@@ -831,11 +812,16 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         Carry<V> c; c.key = c0.x + tile_rows;
         c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
         *carry_out = c;
-        if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, c.value, true);
+        if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, c.value);
     }
-    // single-launch path: what the earlier tiles hold of this tile's first row (wave 0 walks back; thread 0 stores row 0)
+    // single-launch path: the pieces of this tile's first row held by tiles [first_row_tile, tile) (thread 0 stores row 0).
+    // Up to 64 of them: wave 0 alone, while the other waves go on with the row phase; more: the whole block.
     V first_row_carry = 0;
-    if (lb && tile > 0 && tid < WAVE) first_row_carry = lb_lookback<V>(*lb, tile);
+    if (lb) {
+        const int pieces = tile - first_row_tile;            // block-uniform
+        if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK>(*lb, tile, pieces, s_wave_val);
+        else if (pieces > 0 && tid < WAVE) first_row_carry = lb_take_wave<V>(*lb, tile, pieces);
+    }
 
     // ---- row phase
     V *__restrict__ y = p.y + c0.x;
@@ -1545,8 +1531,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
+    // the tile holding the first nonzero of this tile's first row r = c0.x: path item r + row_offsets[r]
+    int first_row_tile = tile;
+    if (lb.rec && c1.x > c0.x) first_row_tile = (int) (((long long) c0.x + (c0.x > 0 ? p.row_end[c0.x - 1] : 0)) / TILE);
     consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                             s_wave_key, s_wave_val, carries + tile, pshift, nullptr, lb.rec ? &lb : nullptr, tile, num_tiles);
+                                             s_wave_key, s_wave_val, carries + tile, pshift, nullptr, lb.rec ? &lb : nullptr, tile, num_tiles,
+                                             first_row_tile < tile ? first_row_tile : tile);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,
