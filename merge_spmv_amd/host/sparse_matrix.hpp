@@ -170,23 +170,33 @@ struct CooMatrix {
         const size_t n = buf.size();
         std::vector<size_t> starts;                        // start offset of every terminated line
         {
-            std::vector<size_t> newlines;
-            const int nthreads = serial ? 1 : omp_get_max_threads();
-            std::vector<std::vector<size_t>> local((size_t) nthreads);
-#pragma omp parallel num_threads(nthreads)
-            {
-                const int t = omp_get_thread_num();
-                const size_t lo = n * (size_t) t / nthreads, hi = n * (size_t) (t + 1) / nthreads;
-                for (size_t i = lo; i < hi; ++i) if (buf[i] == '\n') local[(size_t) t].push_back(i);
+            // newline positions, found by all threads (chunk c of the file -> local[c]), then laid out in file order
+            const int chunks = serial ? 1 : std::max(1, omp_get_max_threads());
+            std::vector<std::vector<size_t>> local((size_t) chunks);
+#pragma omp parallel for schedule(static, 1) if (!serial)
+            for (int c = 0; c < chunks; ++c) {
+                const size_t lo = n * (size_t) c / chunks, hi = n * (size_t) (c + 1) / chunks;
+                std::vector<size_t> &v = local[(size_t) c];
+                for (size_t i = lo; i < hi; ++i) if (buf[i] == '\n') v.push_back(i);
             }
-            for (auto &v : local) newlines.insert(newlines.end(), v.begin(), v.end());
-            starts.reserve(newlines.size());
-            size_t begin = 0;
-            for (size_t nl : newlines) {
-                if (nl - begin >= 1024) break;             // getline(line, 1024) fails here: parsing stops
-                starts.push_back(begin);
-                buf[nl] = '\0';                            // every kept line is now a C string
-                begin = nl + 1;
+            std::vector<size_t> base((size_t) chunks + 1, 0);
+            for (int c = 0; c < chunks; ++c) base[(size_t) c + 1] = base[(size_t) c] + local[(size_t) c].size();
+            const size_t lines = base[(size_t) chunks];
+            std::vector<size_t> newlines(lines);
+#pragma omp parallel for schedule(static, 1) if (!serial)
+            for (int c = 0; c < chunks; ++c) std::copy(local[(size_t) c].begin(), local[(size_t) c].end(), newlines.begin() + (std::ptrdiff_t) base[(size_t) c]);
+            // getline(line, 1024) fails on the first line of >= 1024 characters: parsing stops there
+            size_t kept = lines;
+#pragma omp parallel for schedule(static) reduction(min : kept) if (!serial)
+            for (size_t k = 0; k < lines; ++k) {
+                const size_t begin = k == 0 ? 0 : newlines[k - 1] + 1;
+                if (newlines[k] - begin >= 1024 && k < kept) kept = k;
+            }
+            starts.resize(kept);
+#pragma omp parallel for schedule(static) if (!serial)
+            for (size_t k = 0; k < kept; ++k) {
+                starts[k] = k == 0 ? 0 : newlines[k - 1] + 1;
+                buf[newlines[k]] = '\0';                   // every kept line is now a C string
             }
         }
         // ---- header (serial): comments / banner until the size line
@@ -253,22 +263,54 @@ struct CooMatrix {
                 parsed[k] = parse_line(line, a, s, w);
             }
         }
-        // ---- sequential semantics: entry counter before each line, first failure in file order
+        // ---- sequential semantics: entry counter before each line, first failure in file order.  Coordinate files: the
+        //      entries a line yields are known from the parse alone, so the counter is a prefix sum computed chunk-wise by
+        //      all threads, and every chunk reports its first failure; array files (position from the counter, symmetric
+        //      mirroring decided by the position) go through the loop as one chunk.
         std::vector<long long> before(m + 1, 0);
-        for (size_t k = 0; k < m; ++k) {
-            Parsed &q = parsed[k];
-            if (q.array && q.kind == 1) {                  // array: position comes from the entry counter (:316-324)
-                const long long cur = before[k];
-                q.c = num_rows ? (int) (cur / num_rows) : 0;
-                q.r = (int) (cur - (long long) num_rows * q.c);
-                if (q.symmetric && q.r != q.c) q.kind = 2;
+        {
+            bool any_array = false;
+#pragma omp parallel for schedule(static) reduction(|| : any_array) if (!serial)
+            for (size_t k = 0; k < m; ++k) any_array = any_array || (parsed[k].array && parsed[k].kind == 1);
+            const int chunks = (serial || any_array) ? 1 : std::max(1, omp_get_max_threads());
+            std::vector<long long> chunk_sum((size_t) chunks + 1, 0);
+            if (chunks > 1) {
+#pragma omp parallel for schedule(static, 1)
+                for (int c = 0; c < chunks; ++c) {
+                    long long sum = 0;
+                    for (size_t k = m * (size_t) c / chunks; k < m * (size_t) (c + 1) / chunks; ++k) sum += parsed[k].kind > 0 ? parsed[k].kind : 0;
+                    chunk_sum[(size_t) c + 1] = sum;
+                }
+                for (int c = 0; c < chunks; ++c) chunk_sum[(size_t) c + 1] += chunk_sum[(size_t) c];
             }
-            if (q.kind != 0 && before[k] >= declared)
-                throw MarketError("Error parsing MARKET matrix: encountered more than " + std::to_string(declared) + " num_nonzeros");
-            if (q.kind == -1) throw MarketError("Error parsing MARKET matrix: badly formed row at edge " + std::to_string(before[k]));
-            if (q.kind == -2) throw MarketError("Error parsing MARKET matrix: badly formed col at edge " + std::to_string(before[k]));
-            if (q.kind == -3) throw MarketError("Error parsing MARKET matrix: badly formed current_nz: '" + std::string(&buf[starts[li + k]]) + "'");
-            before[k + 1] = before[k] + (q.kind > 0 ? q.kind : 0);
+            std::vector<size_t> first_bad((size_t) chunks, m);          // index of each chunk's first failing line (m: none)
+#pragma omp parallel for schedule(static, 1) if (chunks > 1)
+            for (int c = 0; c < chunks; ++c) {
+                long long cur = chunk_sum[(size_t) c];
+                const size_t lo = m * (size_t) c / chunks, hi = m * (size_t) (c + 1) / chunks;
+                for (size_t k = lo; k < hi; ++k) {
+                    Parsed &q = parsed[k];
+                    before[k] = cur;
+                    if (q.array && q.kind == 1) {              // array: position comes from the entry counter (:316-324)
+                        q.c = num_rows ? (int) (cur / num_rows) : 0;
+                        q.r = (int) (cur - (long long) num_rows * q.c);
+                        if (q.symmetric && q.r != q.c) q.kind = 2;
+                    }
+                    if ((q.kind != 0 && cur >= declared) || q.kind < 0) { first_bad[(size_t) c] = k; break; }
+                    cur += q.kind > 0 ? q.kind : 0;
+                }
+                if (first_bad[(size_t) c] == m && hi == m) before[m] = cur;
+            }
+            size_t bad = m;
+            for (int c = 0; c < chunks; ++c) if (first_bad[(size_t) c] < bad) { bad = first_bad[(size_t) c]; break; }
+            if (bad < m) {
+                const Parsed &q = parsed[bad];
+                if (q.kind != 0 && before[bad] >= declared)
+                    throw MarketError("Error parsing MARKET matrix: encountered more than " + std::to_string(declared) + " num_nonzeros");
+                if (q.kind == -1) throw MarketError("Error parsing MARKET matrix: badly formed row at edge " + std::to_string(before[bad]));
+                if (q.kind == -2) throw MarketError("Error parsing MARKET matrix: badly formed col at edge " + std::to_string(before[bad]));
+                throw MarketError("Error parsing MARKET matrix: badly formed current_nz: '" + std::string(&buf[starts[li + bad]]) + "'");
+            }
         }
         // ---- fill
         const size_t total = (size_t) before[m];
