@@ -570,8 +570,8 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 // which the row ends" can be done by that tile itself.  Every tile PUBLISHES its carry as soon as its scan is done.  A
 // tile with row ends knows exactly which earlier tiles hold pieces of its first row r = c0.x: the row's first nonzero is
 // path item r + row_offsets[r], i.e. it lies in tile (r + row_offsets[r]) / TILE, so the pieces are the carries of tiles
-// [that tile, this tile) -- none when the row starts in this tile, one for rows shorter than a tile, many for a giant
-// row.  The tile takes exactly those records (one lane each: up to 64 by wave 0 alone while the other waves run the row
+// [that tile, this tile) -- one for rows shorter than a tile (an empty one when the row starts on the tile boundary), many
+// for a giant row.  The tile takes exactly those records (one lane each: up to 64 by wave 0 alone while the other waves run the row
 // phase, longer lists by the whole block), adds them to its first row in a fixed order and clears them.  There is no
 // chain of waits (a waiting tile waits for blocks that wait for nobody before publishing), blocks take tiles in block
 // order on this path, and workgroups are dispatched in order: an awaited block is running or done.  The reference's
@@ -580,8 +580,8 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 // A record is two 64-bit words, each carrying half of a per-call tag beside its payload, written and read with
 // relaxed agent-scope atomics (visible across the XCDs' L2s without a cache flush): a word is valid when its tag
 // matches, so no ordering between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits,
-// and consumers clear what they read (each record has at most one consumer), which also makes a captured call
-// replayable with the same tags.  Polling is bounded (~seconds); running out poisons the row with NaN instead of hanging.
+// and consumers clear what they read -- every record has exactly one consumer, so none outlives the call, which also
+// makes a captured call replayable with the same tags, even after the matrix changed.  Polling is bounded (~seconds); running out poisons the row with NaN instead of hanging.
 // ---------------------------------------------------------------------------
 struct LookBack {
     unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
@@ -1531,9 +1531,15 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>()
     stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
-    // the tile holding the first nonzero of this tile's first row r = c0.x: path item r + row_offsets[r]
+    // the tile holding the first nonzero of this tile's first row r = c0.x: path item r + row_offsets[r].  When the row
+    // starts exactly on a tile boundary the tile before that boundary holds an EMPTY piece of it (carry 0): it is taken
+    // too, so that every published record has exactly one consumer and none outlives the call.
     int first_row_tile = tile;
-    if (lb.rec && c1.x > c0.x) first_row_tile = (int) (((long long) c0.x + (c0.x > 0 ? p.row_end[c0.x - 1] : 0)) / TILE);
+    if (lb.rec && c1.x > c0.x) {
+        const long long d_start = (long long) c0.x + (c0.x > 0 ? p.row_end[c0.x - 1] : 0);
+        first_row_tile = (int) (d_start / TILE);
+        if (d_start % TILE == 0 && first_row_tile > 0) --first_row_tile;
+    }
     consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
                                              s_wave_key, s_wave_val, carries + tile, pshift, nullptr, lb.rec ? &lb : nullptr, tile, num_tiles,
                                              first_row_tile < tile ? first_row_tile : tile);
