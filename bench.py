@@ -8,7 +8,9 @@ A "step" is one y = A*x through the C ABI (include/mspmv.h); inputs are resident
 
 N = 1 (default workload "c2"): BASELINE.json config 2, the configuration the metric is quoted on for one
 GPU -- fp32, 3 125 000 x 3 125 000, exactly 32 nnz/row = 100 000 000 nnz, uniform random sorted columns
- -- through the stateless drop-in call mspmv_csrmv_f32.  The same line carries a
+ -- through the stateless drop-in call mspmv_csrmv_f32 (which, on a matrix like this one, lets the
+tile kernel run its column-band passes: `column_band_passes` in the roofline record says whether and how many;
+DESIGN.md 4).  The same line carries a
 `prepared_plan` sub-record: the opt-in band-major plan (mspmv_csrmv_plan_*; set-up reported separately,
 like the reference reports the HYB conversion, gpu_spmv.cu:106-257) on the same matrix.
 
@@ -338,6 +340,17 @@ def main():
                                        "fixup": round(prof["fixup_ms"], 5)},
                          "events": f"hipEvents on the launch stream, {prof['calls']} launches"},
         }
+        if not mg:
+            # column-band passes of the stateless call: offered by the sizes, accepted (or not) by the device-side windows
+            offered = M.band_passes(local_rows, cols, local_nnz, vb)
+            rec = {"offered_by_policy": offered, "passes_run": 0, "windows_spread_of_64": None}
+            if offered > 1:
+                spread = int(M.debug_band_windows(ws, local_rows, local_nnz, vb).sum())
+                rec["windows_spread_of_64"] = spread
+                rec["passes_run"] = offered if spread >= 56 else 0
+                rec["note"] = ("the tile kernel streamed the CSR arrays `passes_run` times, each pass gathering one column band of x "
+                               "(the slice stays in every XCD's L2); algorithmic bytes count the arrays once")
+            out["roofline"]["column_band_passes"] = rec
         if exchange is not None:
             out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
             if isinstance(exchange.get("exchange"), int):

@@ -207,6 +207,25 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
 
+/* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of
+ * 7-36 MiB (fp32; 10-28 MiB fp64) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
+ * pass multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 7-29 %
+ * faster.  The call stays stateless and asynchronous: a 64-block kernel samples 64 windows of 2048
+ * consecutive column indices, and the ordinary tile kernel and the band kernel both read its verdicts and
+ * return at once when the other is to run.  Results stay within the strict bound and are bitwise reproducible
+ * (fixed pass order); rounding differs from the single-pass result in the last bits.
+ *   passes = 0  automatic (default): by the sizes of the call (csrc/mspmv_api.hip: band_passes_for) and the verdicts
+ *   passes < 0  never
+ *   passes >= 2 always that many passes, on any call that takes the large-problem 256x11 tile (tests, tuning). */
+int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
+/* *passes = how many passes a call of these sizes is offered under the current setting (0: none; the aligned,
+ * vectorised path is assumed); with the automatic setting the device-side verdicts still have the last word. */
+int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes);
+/* The 64 window verdicts (1 = columns look uniformly spread) the last automatic call left in d_temp -> HOST
+ * array of 64 int32 (synchronises `stream`); at least 56 ones select the band passes. */
+int mspmv_debug_band_windows(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes,
+                             int32_t *h_verdicts, mspmv_stream_t stream);
+
 /* Opt-in per-kernel timing with hipEvents recorded on the caller's stream
  * around each of the three passes (the counterpart of the reference's
  * GpuTimer, utils.h:624-658, at kernel granularity).  While active, every

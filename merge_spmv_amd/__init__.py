@@ -101,6 +101,12 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_profile_begin.argtypes = [i32]
     lib.mspmv_profile_end.restype = ctypes.c_int
     lib.mspmv_profile_end.argtypes = [ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(ctypes.c_float)] * 3
+    lib.mspmv_set_band_passes.restype = ctypes.c_int
+    lib.mspmv_set_band_passes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.mspmv_get_band_passes.restype = ctypes.c_int
+    lib.mspmv_get_band_passes.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
+    lib.mspmv_debug_band_windows.restype = ctypes.c_int
+    lib.mspmv_debug_band_windows.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     lib.mspmv_mg_partition.restype = ctypes.c_int
     lib.mspmv_mg_partition.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, i32, vp, vp]
     lib.mspmv_mg_local_offsets.restype = ctypes.c_int
@@ -463,6 +469,28 @@ def profile_end() -> dict:
     ms = [ctypes.c_float() for _ in range(3)]
     _check(load_library().mspmv_profile_end(ctypes.byref(calls), *[ctypes.byref(m) for m in ms]), "mspmv_profile_end")
     return {"calls": calls.value, "search_ms": ms[0].value, "tile_ms": ms[1].value, "fixup_ms": ms[2].value}
+
+
+def set_band_passes(value_bytes: int, passes: int = 0) -> None:
+    """Column-band passes (mspmv_set_band_passes): 0 automatic, < 0 never, >= 2 always that many."""
+    _check(load_library().mspmv_set_band_passes(int(value_bytes), int(passes)), "mspmv_set_band_passes")
+
+
+def band_passes(rows: int, cols: int, nnz: int, value_bytes: int) -> int:
+    """Passes a call of these sizes is offered (0: none); automatic setting: subject to the device-side verdicts."""
+    n = ctypes.c_int32(0)
+    _check(load_library().mspmv_get_band_passes(int(rows), int(cols), int(nnz), int(value_bytes), ctypes.byref(n)), "mspmv_get_band_passes")
+    return n.value
+
+
+def debug_band_windows(workspace, rows: int, nnz: int, value_bytes: int):
+    """The 64 window verdicts the last automatic large-problem call left in the workspace (numpy int32[64])."""
+    import numpy as np
+    out = np.zeros(64, np.int32)
+    tmp = workspace.buffer if hasattr(workspace, "buffer") else workspace
+    _check(load_library().mspmv_debug_band_windows(ctypes.c_void_p(tmp.data_ptr()), int(rows), int(nnz), int(value_bytes),
+                                                   out.ctypes.data_as(ctypes.c_void_p), None), "mspmv_debug_band_windows")
+    return out
 
 
 def debug_read_tiles(workspace_buffer, num_rows: int, num_nonzeros: int, value_bytes: int, stream=None):

@@ -31,6 +31,7 @@ constexpr int MM_CHUNK_LOG2 = 6;         // ... 0-3 % on the SpMM tiles
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
+constexpr int DEV_FLAG_MASK = 1 | 0xff00 | 0x70000 | 0xf00000;   // selectors of the -DMSPMV_DEV kernel variants
 constexpr int FUSED_MAX_TILES_DEFAULT = 1280;    // up to here: tiles search their own coordinates and add the carries themselves
                                                  // (beyond, the self-searching kernel + fix-up is slower than the three-pass pipeline)
 // (MSPMV_FUSED_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
@@ -48,7 +49,7 @@ struct Shape { int block, ipt; };
 static const Shape kShapesF32[] = {{256, 7}, {256, 5}, {256, 9}, {256, 11}, {128, 7}, {512, 7}, {256, 15}};
 static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128, 5}, {512, 5}, {256, 11}};
 
-struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}; };
+struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}, band_passes{0}; };   // band_passes: mspmv_set_band_passes
 static Tuning g_tune[2];  // [0] = 4-byte values, [1] = 8-byte values
 
 // Default shape (measured on MI355X; profiles/r02_small_problem_shapes.txt, r01_sweep_vs_rocsparse.txt):
@@ -84,7 +85,7 @@ struct Layout {
     bool fused;            // small: tile_kernel_fused (needs aligned arrays, decided again at launch)
     int fix_n[3];          // pairs entering fix-up level i (fix_n[0] == num_tiles)
     int fix_levels;
-    uint64_t coords_off, carries_off, fix_off[2], pub_off, total;
+    uint64_t coords_off, carries_off, fix_off[2], pub_off, band_off, band_next_off, total;
     bool single_launch;    // fused AND the carries are added by the tiles themselves (no fix-up launch)
 };
 
@@ -106,6 +107,11 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     L.single_launch = L.fused && L.num_tiles > 1 && L.num_tiles <= SINGLE_LAUNCH_MAX_TILES &&
                       !(L.flags & (MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX));
     if (L.fused) { L.pub_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * 16); }
+    else {
+        // column-band passes: the window verdicts, 8 claim counters, and one int per tile (the chain of tiles each block ran)
+        L.band_off = off; off = align256(off + uint64_t(BAND_WINDOWS + 8 * BAND_COUNTER_STRIDE) * sizeof(int));
+        if (L.shape.block == 256 && L.shape.ipt == 11) { L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles) * sizeof(int)); }
+    }
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
@@ -124,6 +130,31 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     return L;
 }
 
+// Column-band passes (tile_kernel_band): how many, for a call the host can only describe by its sizes.  0 = none.
+// Automatic choice (MI355X, 96 M uniformly spread nonzeros; profiles/r02_band_passes.txt), x in MiB:
+//   fp32   single pass   2 bands   3 bands   4 bands        fp64   single   2 bands   3 bands
+//    8        0.93         0.75      0.85      1.00           12     1.24     1.01      1.16
+//   12        1.18         0.86      0.88      1.00           16     1.37     1.21      1.20
+//   16        1.32         1.07      0.93      1.02           24     1.51     1.45      1.40
+//   24        1.46         1.32      1.20      1.12
+//   32        1.56         1.45      1.37      1.32      (6 MiB: equal; 4 MiB: bands lose)
+// only for the large-problem shape with non-temporal streams (> 256 MB of CSR) and at least 8 nonzeros per row, so
+// that a pass is the CSR stream and little else; whether the columns are in fact spread is decided on the device.
+static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, int rows, int nnz, const CallExtra &ex, int *force)
+{
+    *force = 0;
+    if (ex.no_bands || ex.tile_map != 0 || L.fused || L.shape.block != 256 || L.shape.ipt != 11) return 0;
+    if (L.flags & (MSPMV_TUNE_NO_VEC | DEV_FLAG_MASK)) return 0;
+    const int policy = g_tune[value_bytes == 8].band_passes.load();
+    if (policy < 0) return 0;
+    if (policy >= 2) { *force = 1; return x_bytes / value_bytes >= policy ? policy : 0; }
+    const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
+    if (stream_bytes <= (256ull << 20) || (L.flags & MSPMV_TUNE_FORCE_TEMPORAL) || (long long) nnz < 8LL * rows) return 0;
+    const double mib = (double) x_bytes / 1048576.0;
+    if (value_bytes == 4) return mib < 7 ? 0 : mib < 10.5 ? 2 : mib < 20 ? 3 : mib <= 40 ? 4 : 0;
+    return mib < 10 ? 0 : mib < 18 ? 2 : mib < 28 ? 3 : 0;
+}
+
 // CU count of the current device, queried once per device (never on the hot path again).
 static int device_cus()
 {
@@ -140,8 +171,9 @@ static int device_cus()
 
 // opt-in per-kernel event timing (mspmv_profile_begin/_end).  Process-global and meant for ONE
 // measuring host thread (mspmv.h says so); the mutex only keeps concurrent callers from corrupting it.
+constexpr int PROF_EVENTS = 4;
 struct Profiler {
-    std::vector<hipEvent_t> events;   // 4 per profiled call
+    std::vector<hipEvent_t> events;   // PROF_EVENTS per profiled call
     int capacity = 0, calls = 0;
     bool active = false;
     std::mutex lock;
@@ -156,7 +188,7 @@ static inline int prof_take_slot()
 }
 static inline void prof_mark(hipStream_t stream, int slot, int which)
 {
-    if (slot >= 0) (void) hipEventRecord(g_prof.events[size_t(slot) * 4 + which], stream);
+    if (slot >= 0) (void) hipEventRecord(g_prof.events[size_t(slot) * PROF_EVENTS + which], stream);
 }
 
 #define MSPMV_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
@@ -194,7 +226,7 @@ static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *n
 //   bits 20..23  persistent form: tiles per block
 //   bits 16..18  1 = staging only (WRONG results, timing ablation), 6 = per-phase cycle stamps written to the
 //                buffer given to mspmv_dev_set_trace, 7 = the reference's per-thread merge-path walk in the tile
-constexpr int MSPMV_DEV_FLAG_BITS = 1 | 0xff00 | 0x70000 | 0xf00000;
+constexpr int MSPMV_DEV_FLAG_BITS = DEV_FLAG_MASK;
 template <typename V, int BLOCK, int IPT>
 static bool launch_dev_variant(const Layout &L, const Params<V> &p, bool axpby, bool nt, const Coord *coords, Carry<V> *carries,
                                int chunk_log2, hipStream_t stream)
@@ -219,7 +251,7 @@ static bool launch_dev_variant(const Layout &L, const Params<V> &p, bool axpby, 
         long long want = (long long) per_cu * device_cus();                                                \
         if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
         const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
-        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2);   \
+        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, BandArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0});   \
     } while (0)
     if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
     else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
@@ -275,6 +307,30 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, map, lb);
         MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
     } else {
+    // column-band passes (band_passes_for): 64 sampled windows of column indices decide, on the device, whether the
+    // tile kernel (its BAND variant) runs its ordinary body or the passes
+    bool band = false, band_sampled = false;
+    unsigned band_grid = 0;
+    if constexpr (BLOCK == 256 && IPT == 11) {
+        if (vec && ex.band_passes > 1 && phase != PHASE_COORDS_ONLY) {
+            // the passes are run by as many blocks as are resident at once
+            static std::atomic<int> resident{0};
+            int per_cu = resident.load(std::memory_order_relaxed);
+            if (per_cu == 0) {
+                int n = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tile_kernel_vec<V, BLOCK, IPT, true, false, true, 0, false, true>, BLOCK, 0) != hipSuccess || n < 1) { (void) hipGetLastError(); n = 4; }
+                per_cu = std::min(n, 2048 / BLOCK);
+                resident.store(per_cu, std::memory_order_relaxed);
+            }
+            long long want = std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
+            if (want >= 8) want &= ~7LL;                                   // (8 interleaved tile sequences, one per XCD)
+            band_grid = (unsigned) want;
+            band = want >= 8 || want == L.num_tiles;
+        }
+    }
+    int *band_verdict = reinterpret_cast<int *>(base + L.band_off);
+    BandDetectArgs da; da.cols = p.cols; da.nnz = p.nnz; da.num_cols = ex.num_cols; da.line_shift = sizeof(V) == 4 ? 5 : 4;
+    da.verdict = band_verdict; da.first_block = 0;
     // 1. tile boundary coordinates
     prof_mark(stream, slot, 0);
     if (phase == PHASE_SKIP_COORDS) {
@@ -295,15 +351,29 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const long long threads = ((long long) p.rows + 1 + 3) / 4;       // 4 row indices per thread
         const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
         const int *row_offsets = p.row_end - 1;
-        if ((reinterpret_cast<uintptr_t>(row_offsets) & 15) == 0)
+        const bool aligned = (reinterpret_cast<uintptr_t>(row_offsets) & 15) == 0;
+        if (band) {
+            // + BAND_WINDOWS blocks that sample the column windows: no launch of their own
+            da.first_block = (int) grid;
+            const unsigned dgrid = grid + BAND_WINDOWS;
+            if (aligned) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true, true>), dim3(dgrid), dim3(SEARCH_BLOCK), 0,
+                                            stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
+            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, false, true>), dim3(dgrid), dim3(SEARCH_BLOCK), 0,
+                                    stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
+            band_sampled = true;
+        } else if (aligned)
             hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true>), dim3(grid), dim3(SEARCH_BLOCK), 0,
-                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords);
+                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
         else
             hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, false>), dim3(grid), dim3(SEARCH_BLOCK), 0,
-                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords);
+                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
         MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
     }
     if (phase == PHASE_COORDS_ONLY) return hipSuccess;
+    if (band && !band_sampled) {             // (prepared calls, the other coordinate passes)
+        hipLaunchKernelGGL((band_detect_kernel<SEARCH_BLOCK>), dim3(BAND_WINDOWS), dim3(SEARCH_BLOCK), 0, stream, da);
+        MSPMV_CHECK(after_launch(stream, debug_sync, "band_detect_kernel", BAND_WINDOWS, SEARCH_BLOCK));
+    }
     // 2. tiles
     prof_mark(stream, slot, 1);
     {
@@ -329,7 +399,20 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
 #ifdef MSPMV_DEV
             launched = launch_dev_variant<V, BLOCK, IPT>(L, p, axpby, nt, coords, carries, chunk_log2, stream);
 #endif
-#define MSPMV_LAUNCH(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2)
+            BandArgs ba; ba.verdict = nullptr; ba.counters = nullptr; ba.next = nullptr; ba.grid = 0; ba.bands = 0; ba.band_cols = 0; ba.force = 0;
+            if constexpr (BLOCK == 256 && IPT == 11) {
+                if (band && !launched) {
+                    // the BAND variant: the same kernel, whose first band_grid blocks run the column-band passes instead
+                    // when the verdicts (or mspmv_set_band_passes) say so
+                    ba.verdict = band_verdict; ba.counters = band_verdict + BAND_WINDOWS; ba.grid = (int) band_grid;
+                    ba.next = reinterpret_cast<int *>(base + L.band_next_off);
+                    ba.bands = ex.band_passes; ba.band_cols = ex.band_cols; ba.force = ex.band_force;
+                    if (axpby) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, true, false, true, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba);
+                    else       hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, false, false, true, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba);
+                    launched = true;
+                }
+            }
+#define MSPMV_LAUNCH(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
             if (!launched) {
                 if (axpby) { if (nt) MSPMV_LAUNCH(true, true); else MSPMV_LAUNCH(true, false); }
                 else if (nt) MSPMV_LAUNCH(false, true);
@@ -430,7 +513,12 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
     p.rows = rows; p.nnz = nnz; p.alpha = alpha; p.beta = beta;
     // a tiny x is gathered from LDS by the vectorised tile kernels (dynamic shared memory of the launch)
     p.x_lds = (cols > 0 && (size_t) cols * sizeof(V) <= (size_t) X_LDS_MAX_BYTES && !(L.flags & MSPMV_TUNE_NO_XLDS)) ? cols : 0;
-    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, ex);
+    p.band_lo = 0; p.band_len = 0; p.band_pass = 0;
+    CallExtra ex2 = ex;
+    ex2.band_passes = band_passes_for(L, (long long) cols * (long long) sizeof(V), (int) sizeof(V), rows, nnz, ex, &ex2.band_force);
+    ex2.band_cols = ex2.band_passes > 1 ? (cols + ex2.band_passes - 1) / ex2.band_passes : 0;
+    ex2.num_cols = cols;
+    return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, ex2);
 }
 template int csrmv_call<float>(void *, size_t *, const float *, const int32_t *, const int32_t *, const float *, float *, int32_t,
                                int32_t, int32_t, float, float, bool, hipStream_t, int, const CallExtra &);
@@ -601,9 +689,9 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
             Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off[ti]);
             const long long threads = ((long long) rows + 1 + 3) / 4;
             const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
-            if (ti == 0) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 7, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[0], coords);
-            else if (ti == 1) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[1], coords);
-            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 128 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[2], coords);
+            if (ti == 0) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 7, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[0], coords, BandDetectArgs{});
+            else if (ti == 1) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[1], coords, BandDetectArgs{});
+            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 128 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[2], coords, BandDetectArgs{});
             MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
             have_coords[ti] = true;
         }
@@ -770,12 +858,39 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     return hipErrorInvalidValue;
 }
 
+int mspmv_set_band_passes(int32_t value_bytes, int32_t passes)
+{
+    if ((value_bytes != 4 && value_bytes != 8) || passes == 1 || passes > 64) return hipErrorInvalidValue;
+    g_tune[value_bytes == 8].band_passes = passes < 0 ? -1 : passes;
+    return hipSuccess;
+}
+
+int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes)
+{
+    if (!passes || rows < 0 || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8) || (long long) rows + nnz > MAX_ITEMS)
+        return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, value_bytes);
+    CallExtra ex; int force = 0;
+    *passes = band_passes_for(L, (long long) cols * value_bytes, value_bytes, rows, nnz, ex, &force);
+    return hipSuccess;
+}
+
+int mspmv_debug_band_windows(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes, int32_t *h_verdicts,
+                             mspmv_stream_t stream_)
+{
+    if (!d_temp || !h_verdicts || (value_bytes != 4 && value_bytes != 8)) return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, value_bytes);
+    if (L.fused) return hipErrorInvalidValue;           // (small problems never sample)
+    MSPMV_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream_)));
+    return (int) hipMemcpy(h_verdicts, static_cast<const char *>(d_temp) + L.band_off, sizeof(int32_t) * BAND_WINDOWS, hipMemcpyDeviceToHost);
+}
+
 int mspmv_profile_begin(int32_t max_calls)
 {
     if (max_calls < 1 || max_calls > (1 << 20)) return hipErrorInvalidValue;
     std::lock_guard<std::mutex> g(g_prof.lock);
     for (hipEvent_t e : g_prof.events) if (e) (void) hipEventDestroy(e);
-    g_prof.events.assign(size_t(max_calls) * 4, nullptr);
+    g_prof.events.assign(size_t(max_calls) * PROF_EVENTS, nullptr);
     for (auto &e : g_prof.events) MSPMV_CHECK(hipEventCreate(&e));
     g_prof.capacity = max_calls; g_prof.calls = 0; g_prof.active = true;
     return hipSuccess;
@@ -790,9 +905,9 @@ int mspmv_profile_end(int32_t *calls, float *search_ms, float *tile_ms, float *f
     hipError_t first_error = hipSuccess;
     for (int c = 0; c < g_prof.calls; ++c) {
         // a slot whose four marks were not all recorded (a call that failed half way) is skipped
-        float ms[3]; bool ok = hipEventSynchronize(g_prof.events[size_t(c) * 4 + 3]) == hipSuccess;
+        float ms[3]; bool ok = hipEventSynchronize(g_prof.events[size_t(c) * PROF_EVENTS + 3]) == hipSuccess;
         for (int k = 0; k < 3 && ok; ++k)
-            ok = hipEventElapsedTime(&ms[k], g_prof.events[size_t(c) * 4 + k], g_prof.events[size_t(c) * 4 + k + 1]) == hipSuccess;
+            ok = hipEventElapsedTime(&ms[k], g_prof.events[size_t(c) * PROF_EVENTS + k], g_prof.events[size_t(c) * PROF_EVENTS + k + 1]) == hipSuccess;
         if (!ok) { (void) hipGetLastError(); continue; }
         for (int k = 0; k < 3; ++k) acc[k] += ms[k];
         ++n;

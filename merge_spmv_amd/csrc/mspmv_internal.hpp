@@ -19,6 +19,9 @@ struct CallExtra {
     int phase = PHASE_ALL;
     int tile_map = 0;       // 0: library default (XCD-chunked runs of 64 tiles); else the chunk_log2 code of
                             // xcd_chunked_tile (TILE_MAP_CONTIGUOUS_CODE: one contiguous tile range per XCD)
+    // column-band passes (filled in by csrmv_call, see band_passes_for): > 1 = tile_kernel_band may serve the call
+    int band_passes = 0, band_cols = 0, band_force = 0, num_cols = 0;
+    bool no_bands = false;  // callers that must not take them (the band-major plan: its stacked matrix is banded already)
 };
 constexpr int TILE_MAP_CONTIGUOUS_CODE = 30;
 

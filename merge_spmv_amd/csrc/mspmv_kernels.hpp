@@ -65,6 +65,9 @@ struct Params {
     V alpha;
     V beta;
     int x_lds;                        // > 0: x has this many entries and the tile kernels gather it from LDS
+    // column-band passes (BAND kernels only): this launch multiplies the nonzeros whose column lies in
+    // [band_lo, band_lo + band_len) and treats the others as zeros; band_pass > 0 adds its carries to the stored ones
+    int band_lo, band_len, band_pass;
 };
 
 // A tiny x (the reference's --dense=<cols> inputs: 5 or 32 entries) is copied to LDS once per block and
@@ -174,6 +177,85 @@ __global__ __launch_bounds__(BLOCK) void search_kernel(const int *__restrict__ r
 }
 
 // ---------------------------------------------------------------------------
+// Column-band passes (no counterpart in the reference).  A matrix whose columns are spread
+// uniformly over an x several times the 4 MiB of an XCD's L2 is gather-bound at the Infinity-Cache rate
+// (C2: 100 M gathers in 1.2 ms, the CSR stream alone takes 0.14 ms).  Streaming the matrix B times, each
+// pass multiplying only the nonzeros of one column band -- an x slice that stays in L2 -- is faster: C2
+// fp32 0.87 ms with B = 3.  Whether the columns ARE spread like that is not known to the host, and a
+// stateless, asynchronous call cannot wait for the answer: 64 extra blocks of the coordinate pass sample 64
+// windows of 2048 consecutive nonzeros, and the tile kernel (its BAND variant) reads the 64 verdicts and runs
+// either its ordinary body or the passes (run_band_passes).
+// ---------------------------------------------------------------------------
+constexpr int BAND_WINDOWS = WAVE;         // one verdict per lane of the wave that reads them
+constexpr int BAND_WINDOW = 2048;          // consecutive nonzeros per window
+constexpr int BAND_MAJORITY = 56;          // windows that must look uniform
+constexpr int BAND_BITMAP_WORDS = 2048;    // 65 536 bits, one per 128-byte line of x modulo 8 MiB
+// set bits expected from d distinct lines hashed uniformly: m (1 - exp(-d / m)); d = 0.93 * 2048 -> 1877
+constexpr int BAND_MIN_BITS = 1877;
+constexpr int BAND_COUNTER_STRIDE = 64;    // ints between the 8 claim counters of run_band_passes (they follow the verdicts)
+
+__device__ __forceinline__ bool band_mode(const int *__restrict__ verdict)      // wave-uniform
+{
+    const int v = verdict[threadIdx.x & (WAVE - 1)];
+    return __popcll(__ballot(v != 0)) >= BAND_MAJORITY;
+}
+
+struct BandDetectArgs {
+    const int *cols; int nnz, num_cols;
+    int line_shift;            // column index -> 128-byte line of x: 5 (fp32), 4 (fp64)
+    int *verdict;              // BAND_WINDOWS verdicts, then the claim counters
+    int first_block;           // coords_scatter_kernel<.., DETECT>: blocks from here on sample the windows
+};
+
+// verdict[w] = 1 when window w touches (almost) as many distinct 128-byte lines of x as it has nonzeros -- no
+// short-range reuse for a cache to exploit: R-MAT windows reach 0.6-0.88 of that, stencils and bands a few percent,
+// uniform columns 0.975-0.99 -- AND spans at least 3/4 of the columns.  Block `w` of BAND_WINDOWS; BLOCK threads.
+template <int BLOCK>
+__device__ __forceinline__ void band_detect_block(const BandDetectArgs &a, int w)
+{
+    constexpr int NW = BLOCK / WAVE;
+    __shared__ unsigned s_bits[BAND_BITMAP_WORDS];
+    __shared__ int s_red[3][NW];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < BAND_BITMAP_WORDS; i += BLOCK) s_bits[i] = 0u;
+    __syncthreads();
+    const long long start = a.nnz > BAND_WINDOW ? (long long) w * (a.nnz - BAND_WINDOW) / (BAND_WINDOWS - 1) : 0;
+    const int len = a.nnz < BAND_WINDOW ? a.nnz : BAND_WINDOW;
+    int fresh = 0, lo = 0x7fffffff, hi = -1;
+    for (int j = tid; j < len; j += BLOCK) {
+        const int c = a.cols[start + j];
+        lo = c < lo ? c : lo; hi = c > hi ? c : hi;
+        const unsigned line = ((unsigned) c >> a.line_shift) & (BAND_BITMAP_WORDS * 32u - 1u);
+        const unsigned bit = 1u << (line & 31u);
+        fresh += (atomicOr(&s_bits[line >> 5], bit) & bit) ? 0 : 1;
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+        fresh += __shfl_xor(fresh, d, WAVE);
+        const int l2 = __shfl_xor(lo, d, WAVE), h2 = __shfl_xor(hi, d, WAVE);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((tid & (WAVE - 1)) == 0) { s_red[0][tid / WAVE] = fresh; s_red[1][tid / WAVE] = lo; s_red[2][tid / WAVE] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < NW; ++k) {
+            fresh += s_red[0][k];
+            lo = s_red[1][k] < lo ? s_red[1][k] : lo; hi = s_red[2][k] > hi ? s_red[2][k] : hi;
+        }
+        const bool wide = 4LL * ((long long) hi - lo) >= 3LL * a.num_cols;
+        a.verdict[w] = (len == BAND_WINDOW && fresh >= BAND_MIN_BITS && wide) ? 1 : 0;
+        if (w < 8) a.verdict[BAND_WINDOWS + w * BAND_COUNTER_STRIDE] = 0;        // the claim counters of run_band_passes
+    }
+}
+
+// stand-alone form (calls that do not run the scatter coordinate pass: prepared calls, >= 10 M rows)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void band_detect_kernel(BandDetectArgs a)
+{
+    band_detect_block<BLOCK>(a, (int) blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
 // The same coordinates by ONE coalesced pass over the row offsets instead of
 // num_tiles independent searches (each 4 dependent, scattered loads): the
 // merge position of row-end r is m_r = r + row_end[r] (r row-ends and
@@ -186,10 +268,14 @@ __global__ __launch_bounds__(BLOCK) void search_kernel(const int *__restrict__ r
 // of 2^26 nonzeros owns ~37 000 of them).  Measured on MI355X: 3-15 us where
 // the search kernel took 27-52 us.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int TILE_ITEMS, bool VEC>
+template <int BLOCK, int TILE_ITEMS, bool VEC, bool DETECT = false>
 __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__restrict__ row_offsets, int rows, int nnz,
-                                                               int num_tiles, Coord *__restrict__ coords)
+                                                               int num_tiles, Coord *__restrict__ coords, BandDetectArgs da)
 {
+    if constexpr (DETECT) {
+        // 64 extra blocks at the end of the grid sample the column windows (column-band passes, above)
+        if ((int) blockIdx.x >= da.first_block) { band_detect_block<BLOCK>(da, (int) blockIdx.x - da.first_block); return; }
+    }
     // With M(i) = (i - 1) + row_offsets[i] (i >= 1; the merge position of row-end i - 1) and
     // M(0) = -1, row r owns the boundaries t with M(r) < t*TILE_ITEMS <= M(r + 1); row index
     // `rows` owns the ones past M(rows).  A thread takes 4 consecutive r (one 16-byte load).
@@ -726,11 +812,12 @@ __device__ __forceinline__ void seg_step(int &f, V &v)
 // Block-wide EXCLUSIVE segmented sum: returns the sum of `val` over the threads before this
 // one back to (and including) the nearest preceding thread with flag set.  One barrier inside.
 template <typename V, int BLOCK>
-__device__ __forceinline__ V block_exclusive_segsum(bool flag, V val, int *s_wave_flag, V *s_wave_val)
+__device__ __forceinline__ V block_exclusive_segsum(bool flag, V val, int *s_wave_flag, V *s_wave_val, int tid_in = -1)
 {
     constexpr int NW = BLOCK / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = threadIdx.x / WAVE;
+    const unsigned tidu = tid_in < 0 ? threadIdx.x : (unsigned) tid_in;       // (tid_in: see tile_kernel_band)
+    const int lane = tidu & (WAVE - 1);
+    const int wave = tidu / WAVE;
     int f = flag ? 1 : 0;
     V v = val;
     seg_step<V, 0x111, 0xf>(f, v);      // row_shr:1
@@ -756,7 +843,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
                                                    const end16_t *s_end, V *s_prod_raw, unsigned *s_flag,
                                                    int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
                                                    int pshift, unsigned long long *tr = nullptr, const LookBack *lb = nullptr,
-                                                   int tile = 0, int num_tiles = 0, int first_row_tile = 0)
+                                                   int tile = 0, int num_tiles = 0, int first_row_tile = 0, int tid_in = -1)
 {
     constexpr int CPT = IPT / 4 + 1;
     constexpr int NPT = CPT * 4;                  // staged products per thread
@@ -764,7 +851,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
     constexpr int UPT = NPT / EPU;
     constexpr int FLAG_WORDS = CPT * BLOCK * 4 / 32 + 1;
     static_assert(NPT <= 16 && FLAG_WORDS <= BLOCK, "flag word handling");
-    const int tid = threadIdx.x;
+    const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
 
     // ---- nonzero phase
     V s[NPT];
@@ -780,7 +867,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         s[k] = run;
     }
     if (tr && tid == 0) tr[6] = clock64();
-    const V carry_in = block_exclusive_segsum<V, BLOCK>(m != 0u, run, s_wave_flag, s_wave_val);
+    const V carry_in = block_exclusive_segsum<V, BLOCK>(m != 0u, run, s_wave_flag, s_wave_val, tid_in);
     const unsigned lead = (m & (0u - m)) - 1u;    // bits below the first row start (all ones when none)
 #pragma unroll
     for (int k = 0; k < NPT; ++k) s[k] += ((lead >> k) & 1u) ? carry_in : (V) 0;
@@ -794,6 +881,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
 #pragma unroll
             for (int k = 0; k < NPT; ++k) v = (tile_nnz > 0 && k == last % NPT) ? s[k] : v;
             Carry<V> c; c.key = c0.x; c.value = v;
+            if (p.band_pass > 0) c.value += carry_out->value;      // later column-band pass: same tile, same key
             *carry_out = c;
             if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, v);            // (nobody reads the last tile's carry)
         }
@@ -811,6 +899,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         const int e_last = tile_rows > 0 ? s_end[tile_rows - 1] : 0;
         Carry<V> c; c.key = c0.x + tile_rows;
         c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
+        if (p.band_pass > 0) c.value += carry_out->value;
         *carry_out = c;
         if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, c.value);
     }
@@ -939,15 +1028,16 @@ struct TileRegs {
 
 template <typename V, int BLOCK, int IPT, bool NT>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
-                                                    TileRegs<V, BLOCK, IPT> &r)
+                                                    TileRegs<V, BLOCK, IPT> &r, int tid_in = -1)
 {
+    const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
     constexpr int CPT = IPT / 4 + 1;
     const int a0 = c0.y & ~3;
     const int last_full = (p.nnz & ~3) - 4;        // first element of the array's last full chunk (nnz >= 4)
     const int safe = a0 < last_full ? a0 : last_full;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        int e0 = a0 + 4 * ((int) threadIdx.x + k * BLOCK);
+        int e0 = a0 + 4 * (tid + k * BLOCK);
         // a chunk past the tile (it belongs to the next tile) or past the last full chunk of
         // the array is not fetched: those lanes re-read the tile's first chunk instead (one
         // cached address), so no byte of HBM traffic is spent on data this tile does not use
@@ -961,13 +1051,13 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // and x gathers are issued, tile-relative row ends and products land in LDS (every slot of
 // both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
 // and the block is synchronised.
-template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false>
 __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw, V *s_prod_raw,
-                                           int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr)
+                                           int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1)
 {
     constexpr int CPT = IPT / 4 + 1;
-    const int tid = threadIdx.x;
+    const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
     const int *__restrict__ row_offsets = p.row_end - 1;
     const int tile_rows = c1.x - c0.x;
     const int tile_nnz = c1.y - c0.y;
@@ -988,13 +1078,17 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     }
     // ---- gather x for the current tile (its nonzeros were requested one iteration ago)
     V xv[CPT][4];
+    unsigned in_band = 0u;                     // BAND: one bit per staged nonzero of this thread (its column lies in the pass's band)
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int e0 = a0 + 4 * (tid + k * BLOCK);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
-            xv[k][i] = XL ? s_x[in ? regs.col[k].get(i) : 0] : p.x[in ? regs.col[k].get(i) : 0];
+            if (BAND) {
+                xv[k][i] = (V) 0;
+                if (in && (unsigned) (regs.col[k].get(i) - p.band_lo) < (unsigned) p.band_len) { xv[k][i] = p.x[regs.col[k].get(i)]; in_band |= 1u << (4 * k + i); }
+            } else xv[k][i] = XL ? s_x[in ? regs.col[k].get(i) : 0] : p.x[in ? regs.col[k].get(i) : 0];
         }
     }
     // ---- stage row ends
@@ -1024,7 +1118,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
         V prod[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
+            const bool in = BAND ? ((in_band >> (4 * k + i)) & 1u) != 0u
+                                 : (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
             prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
         }
         if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
@@ -1038,9 +1133,11 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     if (nz_tail || ro_tail) {
         __syncthreads();
         const int j = last_full_nz + 4 + tid;                       // absolute nonzero index
-        if (nz_tail && j < c1.y && j >= c0.y)
-            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0) : swz_prod(j - a0)] =
-                ld_stream<NT>(p.values + j) * (XL ? s_x[ld_stream<NT>(p.cols + j)] : p.x[ld_stream<NT>(p.cols + j)]);
+        if (nz_tail && j < c1.y && j >= c0.y) {
+            const int c = ld_stream<NT>(p.cols + j);
+            const bool inb = !BAND || (unsigned) (c - p.band_lo) < (unsigned) p.band_len;
+            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0) : swz_prod(j - a0)] = inb ? ld_stream<NT>(p.values + j) * (XL ? s_x[c] : p.x[c]) : (V) 0;
+        }
         const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
         const int r = i - first;
         if (ro_tail && r >= 0 && r < tile_rows) {
@@ -1064,14 +1161,14 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
 //    least IPT path items past every thread of a full tile.
 // Only whole chunks beyond the needed range are redirected to a cached address (no HBM bytes
 // for data the tile does not use).  This removes ~200 of the ~1100 instructions per wave per tile.
-template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false>
 __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
                                                     const TileRegs<V, BLOCK, IPT> &regs,
                                                     typename EndType<FL>::type *s_end_raw, V *s_prod_raw, unsigned *s_flag,
-                                                    const V *s_x = nullptr)
+                                                    const V *s_x = nullptr, int tid_in = -1)
 {
     constexpr int CPT = IPT / 4 + 1;
-    const int tid = threadIdx.x;
+    const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
     const int *__restrict__ row_offsets = p.row_end - 1;
     const int tile_rows = c1.x - c0.x;
     const int first = c0.x + 1;
@@ -1091,10 +1188,16 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
         }
     }
     V xv[CPT][4];
+    unsigned in_band = 0u;                     // BAND: one bit per staged nonzero of this thread
 #pragma unroll
     for (int k = 0; k < CPT; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[k][i] = XL ? s_x[(unsigned) regs.col[k].get(i)] : p.x[(unsigned) regs.col[k].get(i)];
+        for (int i = 0; i < 4; ++i) {
+            if (BAND) {
+                xv[k][i] = (V) 0;
+                if ((unsigned) (regs.col[k].get(i) - p.band_lo) < (unsigned) p.band_len) { xv[k][i] = p.x[(unsigned) regs.col[k].get(i)]; in_band |= 1u << (4 * k + i); }
+            } else xv[k][i] = XL ? s_x[(unsigned) regs.col[k].get(i)] : p.x[(unsigned) regs.col[k].get(i)];
+        }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int q = tid + k * BLOCK;
@@ -1119,7 +1222,10 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
         const int chunk = tid + k * BLOCK;
         V prod[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) prod[i] = regs.val[k].get(i) * xv[k][i];
+        for (int i = 0; i < 4; ++i) {
+            if (BAND) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? regs.val[k].get(i) * xv[k][i] : (V) 0;
+            else prod[i] = regs.val[k].get(i) * xv[k][i];
+        }
         if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
         else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
     }
@@ -1137,13 +1243,16 @@ __device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1,
     return tile != num_tiles - 1 && c1.y <= last_full_nz + 4 && i0 + 4 * ro_chunks <= last_full_ro + 4;
 }
 
-template <typename V, int BLOCK, int IPT, bool NT, bool FL>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool BAND = false>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw,
-                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr)
+                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1)
 {
     const bool interior = tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro);      // block-uniform
-    if (s_x != nullptr) {              // block-uniform: x lives in LDS (tiny x only)
+    if constexpr (BAND) {              // (a banded pass is for an x beyond L2: never the LDS copy)
+        if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, false, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, tid_in);
+        else stage_tile_careful<V, BLOCK, IPT, NT, FL, false, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, tid_in);
+    } else if (s_x != nullptr) {              // block-uniform: x lives in LDS (tiny x only)
         if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x);
         else stage_tile_careful<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
     } else if (interior)
@@ -1188,24 +1297,116 @@ __device__ __forceinline__ int xcd_chunked_tile(int b, int num_tiles, int chunk_
     return b;
 }
 
+// What the tile kernel needs to know about them (BAND variants of tile_kernel_vec; verdict == nullptr otherwise)
+struct BandArgs {
+    const int *verdict;        // BAND_WINDOWS verdicts of band_detect_block
+    int *counters;             // 8 claim counters, BAND_COUNTER_STRIDE ints apart, zeroed by band_detect_block
+    int *next;                 // num_tiles ints: next[t] = the tile the block that ran t in pass 0 took after it
+    int grid;                  // blocks that run the passes (as many as are resident at once, a multiple of 8); the others return
+    int bands, band_cols;
+    int force;                 // 1: passes whatever the verdicts say (mspmv_set_band_passes)
+};
+
+// The column-band passes of one call, run by the first `grid` blocks of the tile kernel's launch.
+// Pass 0 hands out the tiles dynamically -- as the hardware's block dispatcher does for the one-tile-per-block form; a
+// static split measured 18 % slower, and so did anything that lets the blocks work far apart in the matrix -- in
+// ascending order: block b starts with tile b, then takes tile 8 * n + (b & 7) for the next n of counter (b & 7)
+// (8 counters 256 bytes apart: one device-scope atomic per tile on ONE word serialises at ~10 ns, 0.3 ms for C2;
+// b & 7 is the block's XCD, and when its own sequence runs out a block helps with the others').  The claim for the
+// next tile is issued before the current tile is staged.  Each block chains what it took in next[] and the later
+// passes walk the block's own chain, so y[r] and carries[tile] are re-read by the very thread that wrote them: nothing
+// travels between CUs or XCDs (next[] is written and read by thread 0 of the same block, past the caches).
+// Pass 0 applies the caller's alpha and beta, the later ones add to y and to the stored carries; the ordinary fix-up
+// launch follows.  Blocks drift from one band to the next without a barrier: two slices share L2 only while they do.
+template <typename V, int BLOCK, int IPT>
+__device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__restrict__ coords, Carry<V> *__restrict__ carries,
+                                                int num_tiles, const BandArgs &ba, end16_t *s_end_raw, V *s_prod_raw, unsigned *s_flag,
+                                                int *s_wave_key, V *s_wave_val)
+{
+    constexpr int CPT = IPT / 4 + 1;
+    constexpr int SLOTS = CPT * BLOCK * 4;
+    __shared__ int s_next;
+    const int tid = threadIdx.x;
+    if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
+    const int last_full_nz = (p.nnz & ~3) - 4;
+    const int last_full_ro = ((p.rows + 1) & ~3) - 4;
+    const V beta0 = p.beta;
+    const int first_n = ba.grid / 8;           // sequence positions the blocks' first tiles used up (grid: a multiple of 8, or < 8 = all the tiles)
+    int seq = (int) blockIdx.x & 7;            // thread 0: the sequence it claims from (moves on when one is exhausted)
+    for (int b = 0; b < ba.bands; ++b) {
+        p.band_lo = b * ba.band_cols; p.band_len = ba.band_cols; p.band_pass = b;
+        p.beta = b == 0 ? beta0 : (V) 1;
+        __syncthreads();
+        if (tid == 0) s_next = blockIdx.x;     // every pass starts with the block's own first tile: no claim
+        __syncthreads();
+        for (;;) {
+            // (s_next: written before the barrier that ended the previous tile, or the one above)
+            const int tile = s_next;
+            if (tile >= num_tiles) break;
+            int following = num_tiles;
+            if (tid == 0) {
+                // the tile after this one: the atomic / the load is in flight while this tile is staged
+                if (b > 0) following = __hip_atomic_load(ba.next + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (ba.grid >= 8)
+                    for (int tries = 0; tries < 8; ++tries) {
+                        const int n = first_n + atomicAdd(ba.counters + seq * BAND_COUNTER_STRIDE, 1);
+                        following = 8 * n + seq;
+                        if (following < num_tiles) break;
+                        following = num_tiles; seq = (seq + 1) & 7;
+                    }
+            }
+            // the thread index goes through an empty asm once per tile: what the tile body derives from it (LDS addresses,
+            // lane offsets) is then recomputed per tile instead of being hoisted out of the loop and kept live across it,
+            // which costs ~40 registers per lane and with them a quarter of the resident waves
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            __builtin_assume(t >= 0 && t < BLOCK);
+            const Coord c0 = coords[tile];
+            const Coord c1 = coords[tile + 1];
+            TileRegs<V, BLOCK, IPT> regs;
+            issue_nonzero_loads<V, BLOCK, IPT, true>(p, c0, c1, regs, t);
+            stage_tile<V, BLOCK, IPT, true, true, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, t);
+            const int pshift = c0.y - (c0.y & ~3);
+            const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
+            consume_tile_flags<V, BLOCK, IPT, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
+                                                    s_wave_key, s_wave_val, carries + tile, pshift, nullptr, nullptr, 0, 0, 0, t);
+            if (tid == 0) {
+                s_next = following;
+                if (b == 0) __hip_atomic_store(ba.next + tile, following, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();          // all LDS reads of this tile done before the next tile's staging writes; s_next visible
+        }
+    }
+}
+
 #ifdef MSPMV_DEV
 // development: per-phase cycle stamps of the first 16 tiles of every block (ABLATE == 6 variant)
 __device__ unsigned long long *g_mspmv_trace = nullptr;
 #endif
 
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false>
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false, bool BAND = false>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
-                                                                Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2)
+                                                                Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2,
+                                                                BandArgs ba)
 {
     constexpr int NW = BLOCK / WAVE;
     constexpr int CPT = IPT / 4 + 1;
     constexpr int SLOTS = CPT * BLOCK * 4;         // >= TILE + 8
     constexpr bool FL = ABLATE != 7;
+
     __shared__ __attribute__((aligned(16))) typename EndType<FL>::type s_end_raw[SLOTS];
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];               // ABLATE 7 (development): the per-thread path walk instead
+    // BAND: a call that the column-band passes may serve better; the sampled windows decide, here, on the device.  The
+    // verdicts are requested now and looked at once the tile's coordinates are there too (one load latency, not two:
+    // with the residency capped by LDS every microsecond a block waits before streaming is throughput lost)
+    int band_v = 0;
+    if constexpr (BAND) {
+        static_assert(FL && !PERSIST && ABLATE == 0 && !XCD_REMAP, "band passes: production variant only");
+        band_v = ba.force ? 1 : ba.verdict[threadIdx.x & (WAVE - 1)];
+    }
     constexpr bool TRACE = ABLATE == 6;
     int trace_iter = 0;
 #ifdef MSPMV_DEV
@@ -1237,6 +1438,21 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
     int tile = physical(seq);
     Coord c0 = coords[tile];
     Coord c1 = coords[tile + 1];
+    if constexpr (BAND) {
+        // (the empty asm pins the order: coordinates requested, THEN the verdict awaited -- left alone the compiler
+        // compares it the moment it is loaded, a full memory latency at the head of every block.  Measured on a banded
+        // 99 M-nonzero matrix the passes do not serve: +8 us per call that way, +2 us this way.)
+        asm volatile("" : "+s"(c0.x), "+v"(band_v));
+        if (__popcll(__ballot(band_v != 0)) >= BAND_MAJORITY) {
+            // the passes instead: run by the first ba.grid blocks of this launch, the others return
+            if ((int) blockIdx.x < ba.grid) {
+                if (!AXPBY) { p.alpha = (V) 1; p.beta = (V) 0; }
+                p.x_lds = 0;
+                run_band_passes<V, BLOCK, IPT>(p, coords, carries, num_tiles, ba, s_end_raw, s_prod_raw, s_flag, s_wave_key, s_wave_val);
+            }
+            return;
+        }
+    }
     TileRegs<V, BLOCK, IPT> regs;
     issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
     const int last_full_nz = (p.nnz & ~3) - 4;
