@@ -107,11 +107,10 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     L.single_launch = L.fused && L.num_tiles > 1 && L.num_tiles <= SINGLE_LAUNCH_MAX_TILES &&
                       !(L.flags & (MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX));
     if (L.fused) { L.pub_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * 16); }
-    else {
-        // column-band passes: the window verdicts, 8 claim counters, and one int per tile (the chain of tiles each block ran)
-        L.band_off = off; off = align256(off + uint64_t(BAND_WINDOWS + 8 * BAND_COUNTER_STRIDE) * sizeof(int));
-        if (L.shape.block == 256 && L.shape.ipt == 11) { L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles) * sizeof(int)); }
-    }
+    // column-band passes: the window verdicts and 8 claim counters (always laid out: a buffer sized under one tuning stays
+    // large enough under MSPMV_TUNE_NO_FUSED), and one int per tile of the large-problem shape (the chain of tiles each block ran)
+    L.band_off = off; off = align256(off + uint64_t(BAND_WINDOWS + 8 * BAND_COUNTER_STRIDE) * sizeof(int));
+    if (!L.fused && L.shape.block == 256 && L.shape.ipt == 11) { L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles) * sizeof(int)); }
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
