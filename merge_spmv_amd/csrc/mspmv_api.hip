@@ -129,14 +129,17 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     return L;
 }
 
-// Column-band passes (tile_kernel_band): how many, for a call the host can only describe by its sizes.  0 = none.
-// Automatic choice (MI355X, 96 M uniformly spread nonzeros; profiles/r02_band_passes.txt), x in MiB:
-//   fp32   single pass   2 bands   3 bands   4 bands        fp64   single   2 bands   3 bands
-//    8        0.93         0.75      0.85      1.00           12     1.24     1.01      1.16
-//   12        1.18         0.86      0.88      1.00           16     1.37     1.21      1.20
-//   16        1.32         1.07      0.93      1.02           24     1.51     1.45      1.40
-//   24        1.46         1.32      1.20      1.12
-//   32        1.56         1.45      1.37      1.32      (6 MiB: equal; 4 MiB: bands lose)
+// Column-band passes (run_band_passes): how many, for a call the host can only describe by its sizes.  0 = none.
+// Automatic choice read from ms per SpMV on MI355X, 96 M uniformly spread nonzeros (tools/band_passes_bench.py,
+// profiles/r02_band_passes.txt), x in MiB:
+//   fp32   one pass   2 bands   3 bands   4 bands        fp64   one pass   2 bands   3 bands   4 bands
+//    4      0.549      0.622     0.767     0.920            8     0.995      0.870     1.042     1.298
+//    6      0.706      0.636     0.774     0.926           12     1.239      0.998     1.105     1.316
+//    8      0.933      0.706     0.783     0.934           16     1.363      1.204     1.161     1.356
+//   12      1.178      0.868     0.847     0.956           24     1.506      1.437     1.394     1.441
+//   16      1.308      1.085     0.939     1.000
+//   24      1.457      1.323     1.225     1.170
+//   32      1.585      1.445     1.397     1.371
 // only for the large-problem shape with non-temporal streams (> 256 MB of CSR) and at least 8 nonzeros per row, so
 // that a pass is the CSR stream and little else; whether the columns are in fact spread is decided on the device.
 static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, int rows, int nnz, const CallExtra &ex, int *force)
@@ -150,8 +153,8 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
     if (stream_bytes <= (256ull << 20) || (L.flags & MSPMV_TUNE_FORCE_TEMPORAL) || (long long) nnz < 8LL * rows) return 0;
     const double mib = (double) x_bytes / 1048576.0;
-    if (value_bytes == 4) return mib < 7 ? 0 : mib < 10.5 ? 2 : mib < 20 ? 3 : mib <= 40 ? 4 : 0;
-    return mib < 10 ? 0 : mib < 18 ? 2 : mib < 28 ? 3 : 0;
+    if (value_bytes == 4) return mib < 5.5 ? 0 : mib < 10.5 ? 2 : mib < 20 ? 3 : mib <= 40 ? 4 : 0;
+    return mib < 7 ? 0 : mib < 14 ? 2 : mib < 28 ? 3 : 0;
 }
 
 // CU count of the current device, queried once per device (never on the hot path again).
@@ -329,7 +332,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     }
     int *band_verdict = reinterpret_cast<int *>(base + L.band_off);
     BandDetectArgs da; da.cols = p.cols; da.nnz = p.nnz; da.num_cols = ex.num_cols; da.line_shift = sizeof(V) == 4 ? 5 : 4;
-    da.verdict = band_verdict; da.first_block = 0;
+    da.verdict = band_verdict;
     // 1. tile boundary coordinates
     prof_mark(stream, slot, 0);
     if (phase == PHASE_SKIP_COORDS) {
@@ -353,7 +356,6 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const bool aligned = (reinterpret_cast<uintptr_t>(row_offsets) & 15) == 0;
         if (band) {
             // + BAND_WINDOWS blocks that sample the column windows: no launch of their own
-            da.first_block = (int) grid;
             const unsigned dgrid = grid + BAND_WINDOWS;
             if (aligned) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true, true>), dim3(dgrid), dim3(SEARCH_BLOCK), 0,
                                             stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);

@@ -204,7 +204,6 @@ struct BandDetectArgs {
     const int *cols; int nnz, num_cols;
     int line_shift;            // column index -> 128-byte line of x: 5 (fp32), 4 (fp64)
     int *verdict;              // BAND_WINDOWS verdicts, then the claim counters
-    int first_block;           // coords_scatter_kernel<.., DETECT>: blocks from here on sample the windows
 };
 
 // verdict[w] = 1 when window w touches (almost) as many distinct 128-byte lines of x as it has nonzeros -- no
@@ -272,15 +271,17 @@ template <int BLOCK, int TILE_ITEMS, bool VEC, bool DETECT = false>
 __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__restrict__ row_offsets, int rows, int nnz,
                                                                int num_tiles, Coord *__restrict__ coords, BandDetectArgs da)
 {
+    // DETECT: the first BAND_WINDOWS blocks of the grid sample the column windows (column-band passes, above) -- first, so
+    // that their two dependent memory round trips run under the coordinate work instead of after it
     if constexpr (DETECT) {
-        // 64 extra blocks at the end of the grid sample the column windows (column-band passes, above)
-        if ((int) blockIdx.x >= da.first_block) { band_detect_block<BLOCK>(da, (int) blockIdx.x - da.first_block); return; }
+        if ((int) blockIdx.x < BAND_WINDOWS) { band_detect_block<BLOCK>(da, (int) blockIdx.x); return; }
     }
+    const unsigned block = DETECT ? blockIdx.x - BAND_WINDOWS : blockIdx.x;
     // With M(i) = (i - 1) + row_offsets[i] (i >= 1; the merge position of row-end i - 1) and
     // M(0) = -1, row r owns the boundaries t with M(r) < t*TILE_ITEMS <= M(r + 1); row index
     // `rows` owns the ones past M(rows).  A thread takes 4 consecutive r (one 16-byte load).
     const int lane = threadIdx.x & (WAVE - 1);
-    const long long gid = (long long) blockIdx.x * BLOCK + threadIdx.x;
+    const long long gid = (long long) block * BLOCK + threadIdx.x;
     const int total = rows + nnz;                              // < 2^31
     const long long base = gid * 4;                            // first r of this thread
     int o[5];                                                  // row_offsets[base .. base + 4]

@@ -6,7 +6,7 @@
 #   bench     headline bench lines: c2 (with prepared_plan + cpu_baseline), c2 fp64, dense32, c5 on one GPU,
 #             c5 through the N > 1 code path with one rank (RCCL) and with 2 ranks sharing the device (gloo)
 #   profiles  rocprofv3 kernel stats + PMC passes: headline c2, dense32, the prepared plan
-#   sweeps    every workload vs rocSPARSE, stream-policy and coordinate-pass A/Bs, plan band counts
+#   sweeps    every workload vs rocSPARSE, stream-policy and coordinate-pass A/Bs, plan band counts, column-band passes
 #   drivers   cpu_spmv / gpu_spmv with the reference's flags, small sizes, the multi-GPU operator on one device
 #   ceilings  tools/hw_ceilings.py (gather / stream ceilings, banded probe, scalar-gather probe)
 #   ingest    config 3 through the Matrix Market path at com-Orkut size
@@ -36,7 +36,8 @@ sweeps)
   SWEEP_DEFAULT_SHAPE=1 timeout 900 python tools/sweep.py c2 c2d dense32 dense32d dense5d band grid2d grid2d4096 grid3d web rmat c4 > $O/sweep_vs_rocsparse.txt 2>&1
   for fl in 32 64; do echo "== flags $fl"; SWEEP_FLAGS=$fl SWEEP_DEFAULT_SHAPE=1 python tools/sweep.py c2 rmat band grid2d grid2d4096 grid3d c4 dense32 dense5d 2>&1 | grep -v "rocSPARSE\|DEFAULT\|prepared"; done > $O/stream_policy.txt
   for fl in 0x10000000 0x20000000; do echo "== flags $fl"; SWEEP_FLAGS=$fl SWEEP_DEFAULT_SHAPE=1 python tools/sweep.py c2 dense5d band grid2d grid2d4096 grid3d rmat c4 2>&1 | grep -v "rocSPARSE\|DEFAULT\|prepared"; done > $O/coords_pass.txt
-  PLAN_BANDS=0,2,4,8,16 timeout 600 python tools/plan_bench.py c2 c2d rmat > $O/plan_bench.txt 2>&1 ;;
+  PLAN_BANDS=0,2,4,8,16 timeout 600 python tools/plan_bench.py c2 c2d rmat > $O/plan_bench.txt 2>&1
+  timeout 900 python tools/band_passes_bench.py > $O/band_passes.txt 2>&1 ;;
 drivers)
   bash tools/run_drivers.sh > $O/drivers.txt 2>&1
   timeout 300 python tools/small_sizes.py > $O/small_sizes.txt 2>&1
