@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--no-plan", action="store_true", help="skip the prepared_plan sub-record (N = 1, c2)")
     ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1, c5: skip rank 0's whole-matrix run")
     ap.add_argument("--tune", default=None, help="development: BLOCKxIPT[:flags] passed to mspmv_set_tuning")
+    ap.add_argument("--band-passes", type=int, default=0,
+                    help="A/B: mspmv_set_band_passes (0 automatic = the product default, -1 never, >= 2 always that many)")
     args = ap.parse_args()
 
     import torch
@@ -168,6 +170,8 @@ def main():
         M.set_tuning(4 if dtype_name == "f32" else 8, int(b or 0), int(i or 0), int(fl or "0", 0))
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
+    if args.band_passes:
+        M.set_band_passes(vb, args.band_passes)
     if workload == "dense32" and mg:
         raise SystemExit("dense32 is a single-GPU workload")
 
@@ -347,7 +351,7 @@ def main():
             if offered > 1:
                 spread = int(M.debug_band_windows(ws, local_rows, local_nnz, vb).sum())
                 rec["windows_spread_of_64"] = spread
-                rec["passes_run"] = offered if spread >= 56 else 0
+                rec["passes_run"] = offered if (spread >= 56 or args.band_passes >= 2) else 0
                 rec["note"] = ("the tile kernel streamed the CSR arrays `passes_run` times, each pass gathering one column band of x "
                                "(the slice stays in every XCD's L2); algorithmic bytes count the arrays once")
             out["roofline"]["column_band_passes"] = rec
