@@ -208,12 +208,12 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
 
 /* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of
- * 7-36 MiB (fp32; 10-28 MiB fp64) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
+ * 5.5-40 MiB (fp32; 7-28 MiB fp64) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
  * pass multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 7-29 %
- * faster.  The call stays stateless and asynchronous: a 64-block kernel samples 64 windows of 2048
- * consecutive column indices, and the ordinary tile kernel and the band kernel both read its verdicts and
- * return at once when the other is to run.  Results stay within the strict bound and are bitwise reproducible
- * (fixed pass order); rounding differs from the single-pass result in the last bits.
+ * faster.  The call stays stateless, asynchronous and three launches: 64 blocks added to the coordinate
+ * launch sample 64 windows of 2048 consecutive column indices, and the tile kernel reads their verdicts and
+ * runs either its ordinary body or the passes.  Results stay within the strict bound and are bitwise
+ * reproducible; rounding differs from the one-sweep result in the last bits (a re-association).
  *   passes = 0  automatic (default): by the sizes of the call (csrc/mspmv_api.hip: band_passes_for) and the verdicts
  *   passes < 0  never
  *   passes >= 2 always that many passes, on any call that takes the large-problem 256x11 tile (tests, tuning). */
