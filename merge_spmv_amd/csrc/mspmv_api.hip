@@ -154,7 +154,7 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     if (stream_bytes <= (256ull << 20) || (L.flags & MSPMV_TUNE_FORCE_TEMPORAL) || (long long) nnz < 8LL * rows) return 0;
     const double mib = (double) x_bytes / 1048576.0;
     if (value_bytes == 4) return mib < 5.5 ? 0 : mib < 10.5 ? 2 : mib < 20 ? 3 : mib <= 40 ? 4 : 0;
-    return mib < 7 ? 0 : mib < 14 ? 2 : mib < 28 ? 3 : 0;
+    return mib < 7 ? 0 : mib < 14 ? 2 : mib < 20 ? 3 : mib <= 36 ? 4 : 0;
 }
 
 // CU count of the current device, queried once per device (never on the hot path again).

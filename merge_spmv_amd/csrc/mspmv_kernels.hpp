@@ -514,6 +514,8 @@ __device__ __forceinline__ Vec4<double> ld_stream4(const double *p)
     r.b = NT ? __builtin_nontemporal_load(q + 1) : q[1];
     return r;
 }
+__device__ __forceinline__ void zero4(Vec4<float> &r) { r.v = float4v{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void zero4(Vec4<double> &r) { r.a = double2v{0.0, 0.0}; r.b = r.a; }
 __device__ __forceinline__ void st_lds4(float *p, const float (&v)[4])
 { float4v w; w.x = v[0]; w.y = v[1]; w.z = v[2]; w.w = v[3]; *reinterpret_cast<float4v *>(p) = w; }
 __device__ __forceinline__ void st_lds4(double *p, const double (&v)[4])
@@ -1020,6 +1022,12 @@ constexpr int tile_waves_per_simd()
     return w;
 }
 
+// Column-band passes, fp64: the values of a chunk are fetched only when one of its four columns lies in the pass's band
+// (with sorted columns a band's nonzeros are a run inside each row: C2 fp64 skips 57 % of the 32-byte value loads per pass,
+// 1.447 -> 1.342 ms).  Not for fp32: the extra live state spills there (0.87 -> 0.95 ms, and the scratch set-up costs the
+// ordinary body of the same kernel 20 %).
+template <typename V, bool BAND> constexpr bool band_lazy_values() { return BAND && sizeof(V) == 8; }
+
 template <typename V, int BLOCK, int IPT>
 struct TileRegs {
     static constexpr int CPT = IPT / 4 + 1;   // 4-element chunks per thread: covers TILE + 3
@@ -1027,7 +1035,7 @@ struct TileRegs {
     Vec4<V> val[CPT];
 };
 
-template <typename V, int BLOCK, int IPT, bool NT>
+template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
                                                     TileRegs<V, BLOCK, IPT> &r, int tid_in = -1)
 {
@@ -1044,7 +1052,7 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
         // cached address), so no byte of HBM traffic is spent on data this tile does not use
         e0 = (e0 < c1.y && e0 <= last_full) ? e0 : safe;
         r.col[k] = ld_stream4<NT>(p.cols + e0);
-        r.val[k] = ld_stream4<NT>(p.values + e0);
+        if (VALS) r.val[k] = ld_stream4<NT>(p.values + e0);      // (!VALS: column-band passes fetch the values later, by band)
     }
 }
 
@@ -1080,6 +1088,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     // ---- gather x for the current tile (its nonzeros were requested one iteration ago)
     V xv[CPT][4];
     unsigned in_band = 0u;                     // BAND: one bit per staged nonzero of this thread (its column lies in the pass's band)
+    constexpr bool LAZY = band_lazy_values<V, BAND>();
+    Vec4<V> bval[LAZY ? CPT : 1];              // LAZY: the values, fetched here and only for chunks with a nonzero of the band
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int e0 = a0 + 4 * (tid + k * BLOCK);
@@ -1090,6 +1100,10 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
                 xv[k][i] = (V) 0;
                 if (in && (unsigned) (regs.col[k].get(i) - p.band_lo) < (unsigned) p.band_len) { xv[k][i] = p.x[regs.col[k].get(i)]; in_band |= 1u << (4 * k + i); }
             } else xv[k][i] = XL ? s_x[in ? regs.col[k].get(i) : 0] : p.x[in ? regs.col[k].get(i) : 0];
+        }
+        if constexpr (LAZY) {
+            zero4(bval[k]);
+            if ((in_band >> (4 * k)) & 0xfu) bval[k] = ld_stream4<NT>(p.values + e0);     // (a bit set => a chunk of this tile, <= last_full_nz)
         }
     }
     // ---- stage row ends
@@ -1121,7 +1135,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
         for (int i = 0; i < 4; ++i) {
             const bool in = BAND ? ((in_band >> (4 * k + i)) & 1u) != 0u
                                  : (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
-            prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
+            if constexpr (LAZY) prod[i] = in ? bval[k].get(i) * xv[k][i] : (V) 0;
+            else prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
         }
         if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
         else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
@@ -1190,8 +1205,10 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
     }
     V xv[CPT][4];
     unsigned in_band = 0u;                     // BAND: one bit per staged nonzero of this thread
+    constexpr bool LAZY = band_lazy_values<V, BAND>();
+    Vec4<V> bval[LAZY ? CPT : 1];              // LAZY: the values, fetched here and only for chunks with a nonzero of the band
 #pragma unroll
-    for (int k = 0; k < CPT; ++k)
+    for (int k = 0; k < CPT; ++k) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (BAND) {
@@ -1199,6 +1216,17 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
                 if ((unsigned) (regs.col[k].get(i) - p.band_lo) < (unsigned) p.band_len) { xv[k][i] = p.x[(unsigned) regs.col[k].get(i)]; in_band |= 1u << (4 * k + i); }
             } else xv[k][i] = XL ? s_x[(unsigned) regs.col[k].get(i)] : p.x[(unsigned) regs.col[k].get(i)];
         }
+        if constexpr (LAZY) {
+            zero4(bval[k]);
+            if ((in_band >> (4 * k)) & 0xfu) {
+                // the address issue_nonzero_loads used for this chunk's columns (a chunk past the tile re-reads the tile's first)
+                const int a0 = c0.y & ~3, last_full = (p.nnz & ~3) - 4;
+                int e0 = a0 + 4 * (tid + k * BLOCK);
+                e0 = (e0 < c1.y && e0 <= last_full) ? e0 : (a0 < last_full ? a0 : last_full);
+                bval[k] = ld_stream4<NT>(p.values + e0);
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int q = tid + k * BLOCK;
@@ -1224,7 +1252,8 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
         V prod[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (BAND) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? regs.val[k].get(i) * xv[k][i] : (V) 0;
+            if constexpr (LAZY) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? bval[k].get(i) * xv[k][i] : (V) 0;
+            else if constexpr (BAND) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? regs.val[k].get(i) * xv[k][i] : (V) 0;
             else prod[i] = regs.val[k].get(i) * xv[k][i];
         }
         if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
@@ -1358,14 +1387,16 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
             }
             // the thread index goes through an empty asm once per tile: what the tile body derives from it (LDS addresses,
             // lane offsets) is then recomputed per tile instead of being hoisted out of the loop and kept live across it,
-            // which costs ~40 registers per lane and with them a quarter of the resident waves
+            // which costs ~40 registers per lane and with them a quarter of the resident waves.  (What is left spills 2-3
+            // registers per lane in the fp32 kernel; the variant that keeps them -- thread 0's claim state in LDS, the index
+            // laundered in place -- measured 3 % slower on C2, so the spill stays.)
             int t = tid;
             asm volatile("" : "+v"(t));
             __builtin_assume(t >= 0 && t < BLOCK);
             const Coord c0 = coords[tile];
             const Coord c1 = coords[tile + 1];
             TileRegs<V, BLOCK, IPT> regs;
-            issue_nonzero_loads<V, BLOCK, IPT, true>(p, c0, c1, regs, t);
+            issue_nonzero_loads<V, BLOCK, IPT, true, !band_lazy_values<V, true>()>(p, c0, c1, regs, t);     // (fp64: columns now, values by band in the staging)
             stage_tile<V, BLOCK, IPT, true, true, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, t);
             const int pshift = c0.y - (c0.y & ~3);
             const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);

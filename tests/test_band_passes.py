@@ -32,11 +32,11 @@ def test_automatic_policy_table():
     for vb in (4, 8):
         assert M.load_library().mspmv_set_band_passes(vb, 0) == 0
     C2 = (3_125_000, 3_125_000, 100_000_000)
-    assert M.band_passes(*C2, 4) == 3 and M.band_passes(*C2, 8) == 3           # 11.9 / 23.8 MiB of x
+    assert M.band_passes(*C2, 4) == 3 and M.band_passes(*C2, 8) == 4           # 11.9 / 23.8 MiB of x
     mib = lambda m, vb: m * 2**20 // vb
     rows, nnz = 3_000_000, 96_000_000
     assert [M.band_passes(rows, mib(m, 4), nnz, 4) for m in (4, 6, 8, 12, 16, 24, 32, 48)] == [0, 2, 2, 3, 3, 4, 4, 0]
-    assert [M.band_passes(rows, mib(m, 8), nnz, 8) for m in (4, 8, 12, 16, 24, 32)] == [0, 2, 2, 3, 3, 0]
+    assert [M.band_passes(rows, mib(m, 8), nnz, 8) for m in (4, 8, 12, 16, 24, 32, 48)] == [0, 2, 2, 3, 4, 4, 0]
     # a pass must be the CSR stream and little else: > 256 MB of it (non-temporal loads), >= 8 nonzeros per row
     assert M.band_passes(1_000_000, mib(12, 4), 30_000_000, 4) == 0
     assert M.band_passes(20_000_000, mib(12, 4), 100_000_000, 4) == 0

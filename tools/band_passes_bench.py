@@ -38,7 +38,7 @@ def cases():
     yield "c2_f64", lambda: G.uniform_csr(3_125_000, 3_125_000, 32, dtype=f64)
     for mb in (4, 6, 8, 12, 16, 24, 32):
         yield f"u{mb}MB_f32", (lambda n=mb * 2**20 // 4: G.uniform_csr(3_000_000, n, 32, dtype=f32))
-    for mb in (8, 12, 16, 24):
+    for mb in (8, 12, 16, 24, 32):
         yield f"u{mb}MB_f64", (lambda n=mb * 2**20 // 8: G.uniform_csr(3_000_000, n, 32, dtype=f64))
     yield from refused()
     yield "dense32_f32", lambda: G.dense_csr(3_125_000, 32, dtype=f32, ones=False)
