@@ -208,8 +208,8 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
 
 /* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of
- * 5.5-40 MiB (fp32; 7-28 MiB fp64) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
- * pass multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 7-29 %
+ * 5.5-40 MiB (fp32; 7-36 MiB fp64) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
+ * pass multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 10-29 %
  * faster.  The call stays stateless, asynchronous and three launches: 64 blocks added to the coordinate
  * launch sample 64 windows of 2048 consecutive column indices, and the tile kernel reads their verdicts and
  * runs either its ordinary body or the passes.  Results stay within the strict bound and are bitwise

@@ -133,11 +133,11 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
 // Automatic choice read from ms per SpMV on MI355X, 96 M uniformly spread nonzeros (tools/band_passes_bench.py,
 // profiles/r02_band_passes.txt), x in MiB:
 //   fp32   one pass   2 bands   3 bands   4 bands        fp64   one pass   2 bands   3 bands   4 bands
-//    4      0.549      0.622     0.767     0.920            8     0.995      0.870     1.042     1.298
-//    6      0.706      0.636     0.774     0.926           12     1.239      0.998     1.105     1.316
-//    8      0.933      0.706     0.783     0.934           16     1.363      1.204     1.161     1.356
-//   12      1.178      0.868     0.847     0.956           24     1.506      1.437     1.394     1.441
-//   16      1.308      1.085     0.939     1.000
+//    4      0.549      0.622     0.767     0.920            8     0.993      0.849     0.980     1.137
+//    6      0.706      0.636     0.774     0.926           12     1.234      0.939     1.020     1.145
+//    8      0.933      0.706     0.783     0.934           16     1.362      1.143     1.065     1.170
+//   12      1.178      0.868     0.847     0.956           24     1.502      1.379     1.289     1.248
+//   16      1.308      1.085     0.939     1.000           32     1.614      1.501     1.462     1.418
 //   24      1.457      1.323     1.225     1.170
 //   32      1.585      1.445     1.397     1.371
 // only for the large-problem shape with non-temporal streams (> 256 MB of CSR) and at least 8 nonzeros per row, so
