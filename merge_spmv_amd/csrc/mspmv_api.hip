@@ -315,7 +315,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     unsigned band_grid = 0;
     if constexpr (BLOCK == 256 && IPT == 11) {
         if (vec && ex.band_passes > 1 && phase != PHASE_COORDS_ONLY) {
-            // the passes are run by as many blocks as are resident at once
+            // the passes are run by 4 (fp64: 5) blocks per CU, or as many as are resident at once if that is fewer: the gathers
+            // of a pass hit L2, so the passes are not short of waves in flight, and with all 8 slots of a CU taken the
+            // ~35 000 blocks of the launch that only return would queue up behind the work instead of draining beside it
+            // (C2 fp32, blocks per CU 8 / 6 / 4 / 3: 0.857 / 0.842 / 0.832 / 0.843 ms; fp64, 5 / 4.4 / 3.1 / 2.5: 1.297 / 1.296 / 1.36 / 1.50)
             static std::atomic<int> resident{0};
             int per_cu = resident.load(std::memory_order_relaxed);
             if (per_cu == 0) {
@@ -324,7 +327,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                 per_cu = std::min(n, 2048 / BLOCK);
                 resident.store(per_cu, std::memory_order_relaxed);
             }
-            long long want = std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
+            const int band_per_cu = std::min(per_cu, sizeof(V) == 4 ? 4 : 5);
+            long long want = std::min<long long>(L.num_tiles, (long long) band_per_cu * device_cus());
             if (want >= 8) want &= ~7LL;                                   // (8 interleaved tile sequences, one per XCD)
             band_grid = (unsigned) want;
             band = want >= 8 || want == L.num_tiles;

@@ -1332,7 +1332,7 @@ struct BandArgs {
     const int *verdict;        // BAND_WINDOWS verdicts of band_detect_block
     int *counters;             // 8 claim counters, BAND_COUNTER_STRIDE ints apart, zeroed by band_detect_block
     int *next;                 // num_tiles ints: next[t] = the tile the block that ran t in pass 0 took after it
-    int grid;                  // blocks that run the passes (as many as are resident at once, a multiple of 8); the others return
+    int grid;                  // blocks that run the passes (4-5 per CU, a multiple of 8); the others return
     int bands, band_cols;
     int force;                 // 1: passes whatever the verdicts say (mspmv_set_band_passes)
 };
