@@ -181,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void search_kernel(const int *__restrict__ r
 // uniformly over an x several times the 4 MiB of an XCD's L2 is gather-bound at the Infinity-Cache rate
 // (C2: 100 M gathers in 1.2 ms, the CSR stream alone takes 0.14 ms).  Streaming the matrix B times, each
 // pass multiplying only the nonzeros of one column band -- an x slice that stays in L2 -- is faster: C2
-// fp32 0.87 ms with B = 3.  Whether the columns ARE spread like that is not known to the host, and a
+// fp32 0.83 ms with B = 3.  Whether the columns ARE spread like that is not known to the host, and a
 // stateless, asynchronous call cannot wait for the answer: 64 extra blocks of the coordinate pass sample 64
 // windows of 2048 consecutive nonzeros, and the tile kernel (its BAND variant) reads the 64 verdicts and runs
 // either its ordinary body or the passes (run_band_passes).
