@@ -19,6 +19,10 @@
 //                      segmented running sums over 12 consecutive products per thread + one
 //                      block-wide DPP segmented scan (consume_tile_flags), y stored per row from
 //                      registers, one (row, partial) carry per tile  (ref: DeviceSpmvKernel)
+//      tile_kernel_vec<.., BAND> : the same kernel with the column-band passes compiled in (run_band_passes): when 64
+//                      sampled windows of column indices (band_detect_block, riding on the coordinate launch) say the
+//                      columns are spread uniformly over an x several times L2, the first 4-5 blocks per CU stream the
+//                      matrix once per band of x instead (C2 fp32: 1.22 -> 0.83 ms); otherwise the ordinary body runs
 //      tile_kernel_fused : the same for <= 2048 tiles, each block searching its own two
 //                      coordinates (no pass 1): 64 fixed samples, 64 consecutive rows at the interpolated point,
 //                      64-ary rounds on the rest;
