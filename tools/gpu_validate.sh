@@ -49,7 +49,8 @@ ingest)
   ( time timeout 1500 python tools/c3_ingest.py ) > $O/c3_ingest.txt 2>&1 ;;
 fuzz)
   timeout 400 python tools/fuzz.py 120 31 > $O/fuzz.txt 2>&1
-  FUZZ_BIG=0.3 timeout 400 python tools/fuzz.py 120 32 >> $O/fuzz.txt 2>&1 ;;
+  FUZZ_BIG=0.3 timeout 400 python tools/fuzz.py 120 32 >> $O/fuzz.txt 2>&1
+  FUZZ_BAND=1 FUZZ_BIG=0.1 timeout 400 python tools/fuzz.py 120 33 >> $O/fuzz.txt 2>&1 ;;
 *) echo "unknown section $section" ;;
 esac
 done
