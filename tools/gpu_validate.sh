@@ -30,6 +30,7 @@ bench)
       --master-port 29512 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_c5_2ranks_one_device.txt 2>&1 ;;
 profiles)
   bash tools/gpu_profile.sh c2 > $O/prof_c2.log 2>&1
+  bash tools/gpu_profile.sh c2_f64 --dtype f64 > $O/prof_c2_f64.log 2>&1
   bash tools/gpu_profile.sh dense32 --workload dense32 > $O/prof_dense32.log 2>&1
   PROFILE_CMD="env PLAN_SKIP_BASE=1 PLAN_BANDS=0 python $PWD/tools/plan_bench.py c2" bash tools/gpu_profile.sh plan_c2 > $O/prof_plan_c2.log 2>&1 ;;
 sweeps)
