@@ -235,6 +235,31 @@ def test_detector_accepts_uniform_columns(prec, cols, want_passes):
 
 
 @gpu
+def test_band_passes_on_two_streams_at_once():
+    """Two SpMVs in band mode in flight together (own workspaces, own streams, one matrix): the blocks that run the passes
+    wait for nothing but memory, so sharing the CUs with another launch can only slow them down; results stay bitwise."""
+    tdt = torch.float32
+    rows, cols, per_row = 1_062_500, 2_400_000, 32
+    val, off, col, x = _uniform(rows, cols, per_row, tdt)
+    nnz = rows * per_row
+    ref = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
+    M.csrmv(val, off, col, x, y=ref, num_cols=cols, workspace=M.CsrMVWorkspace(rows, nnz, tdt))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    wss = [M.CsrMVWorkspace(rows, nnz, tdt) for _ in range(2)]
+    ys = [[torch.full((rows,), float("nan"), dtype=tdt, device="cuda") for _ in range(6)] for _ in range(2)]
+    for it in range(6):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                M.csrmv(val, off, col, x, y=ys[k][it], num_cols=cols, workspace=wss[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert int(M.debug_band_windows(wss[k], rows, nnz, 4).sum()) == 64
+        for it in range(6):
+            assert torch.equal(ys[k][it], ref), (k, it)
+
+
+@gpu
 @pytest.mark.parametrize("kind", ["rmat", "banded"])
 def test_detector_refuses_matrices_with_reuse(kind):
     """R-MAT (hot columns: 60-88 % distinct lines per window) and a banded matrix (a window spans a sliver of x) sit in
