@@ -372,7 +372,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         else
             hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, false>), dim3(grid), dim3(SEARCH_BLOCK), 0,
                                stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
-        MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
+        MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", band ? grid + BAND_WINDOWS : grid, SEARCH_BLOCK));
     }
     if (phase == PHASE_COORDS_ONLY) return hipSuccess;
     if (band && !band_sampled) {             // (prepared calls, the other coordinate passes)
