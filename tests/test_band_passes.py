@@ -140,6 +140,55 @@ def test_forced_passes_match_oracle(forced_shape, shape, passes, prec):
     assert np.all(diff <= 2 * (16 + passes) * eps * s + 1e-300)
 
 
+def _golden_cases():
+    from conftest import load_golden
+    return load_golden("matrices.json")["cases"]
+
+
+@gpu
+@pytest.mark.parametrize("case", _golden_cases(), ids=[c["label"] for c in _golden_cases()])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_forced_passes_on_the_reference_golden_matrices(forced_shape, case, prec):
+    """The reference's own test inputs (its generators and the Matrix Market fixtures) under its own protocol
+    (x = 1, compare with SpmvGold by its PASS rule, gpu_spmv.cu:521-525, utils.h:692-742), with three column-band passes
+    forced: exact where the arithmetic is exact (y = row length), the tile coordinates and carry keys bit for bit the
+    oracle's, the carries -- accumulated over the passes -- within the carry bound."""
+    import os
+    from conftest import ROOT
+    dtype, tdt = (np.float32, torch.float32) if prec == "f32" else (np.float64, torch.float64)
+    vb = 4 if prec == "f32" else 8
+    args = [os.path.join(ROOT, case["args"][0])] if case["kind"] == "mtx" else case["args"]
+    csr = O.make(case["kind"], *args, dtype=dtype)
+    if csr.cols < 3 or csr.nnz < 4 or csr.rows < 3:
+        pytest.skip("too small for three bands / the vectorised path")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    M.set_band_passes(vb, 3)
+    ws = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)
+    info = M.launch_info(csr.rows, csr.nnz, vb)
+    if info["num_tiles"] < 1:
+        pytest.skip("empty")
+    x = np.ones(csr.cols, dtype)
+    y = torch.full((csr.rows,), float("nan"), dtype=tdt, device="cuda")
+    M.csrmv(d(csr.values), d(csr.row_offsets), d(csr.column_indices), d(x), y=y, num_cols=csr.cols, workspace=ws)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy()
+    gold = O.spmv_gold(csr, x)
+    assert O.compare_results(yh, gold) == 0
+    if case["kind"] != "mtx":
+        assert np.array_equal(yh, gold)
+    g, s = O.spmv_gold_acc64(csr, x)
+    ok, worst = O.strict_check(csr, yh, g, s, items_per_thread=16 + 3)
+    assert ok, worst
+    coords, keys, vals = M.debug_read_tiles(ws.buffer, csr.rows, csr.nnz, vb)
+    want = O.tile_coords(csr, info["tile_items"])
+    assert np.array_equal(coords, want[: info["num_tiles"] + 1])
+    _, ck, cv = O.tiled_csrmv(csr, x, info["tile_items"])
+    assert np.array_equal(keys, ck)
+    eps = 2.0 ** -23 if vb == 4 else 2.0 ** -52
+    scale = float(np.abs(csr.values).max(initial=0)) * info["tile_items"]
+    assert np.all(np.abs(vals.astype(np.float64) - cv.astype(np.float64)) <= eps * scale + 1e-300)
+
+
 @gpu
 def test_forced_passes_more_than_columns_fall_back(forced_shape):
     rng = np.random.default_rng(3)
