@@ -159,14 +159,13 @@ def test_forced_passes_on_the_reference_golden_matrices(forced_shape, case, prec
     vb = 4 if prec == "f32" else 8
     args = [os.path.join(ROOT, case["args"][0])] if case["kind"] == "mtx" else case["args"]
     csr = O.make(case["kind"], *args, dtype=dtype)
-    if csr.cols < 3 or csr.nnz < 4 or csr.rows < 3:
-        pytest.skip("too small for three bands / the vectorised path")
+    # (inputs with fewer than 3 columns, 4 nonzeros or 3 rows take the ordinary path -- band_passes_for, the dword-per-lane
+    # kernel -- and must satisfy the same checks)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     M.set_band_passes(vb, 3)
     ws = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)
     info = M.launch_info(csr.rows, csr.nnz, vb)
-    if info["num_tiles"] < 1:
-        pytest.skip("empty")
+    assert info["num_tiles"] >= 1
     x = np.ones(csr.cols, dtype)
     y = torch.full((csr.rows,), float("nan"), dtype=tdt, device="cuda")
     M.csrmv(d(csr.values), d(csr.row_offsets), d(csr.column_indices), d(x), y=y, num_cols=csr.cols, workspace=ws)
