@@ -230,14 +230,33 @@ struct CooMatrix {
             Parsed q{0, 0, 0, 0.0, is_array, is_symmetric, is_skew};
             if (line[0] == '%') return q;
             if (is_array) { q.kind = sscanf(line, "%lf", &q.v) == 1 ? 1 : -3; return q; }
+            // strtol(., ., 0) as the reference calls it (:330-345), with a shortcut for what every real file holds: blanks,
+            // then a decimal number of at most 9 digits that does not start with 0 -- the same value and end pointer, a
+            // tenth of the time (strtol is locale-aware and checks three bases); anything else goes to strtol itself
+            auto index = [](char *l, char **t) -> int {
+                char *s = l;
+                while (*s == ' ' || *s == '\t') ++s;
+                if (*s >= '1' && *s <= '9') {
+                    int v = 0, digits = 0;
+                    while (*s >= '0' && *s <= '9' && digits < 10) { v = v * 10 + (*s - '0'); ++s; ++digits; }
+                    if (digits <= 9 && !(*s >= '0' && *s <= '9')) { *t = s; return v; }
+                }
+                return (int) strtol(l, t, 0);
+            };
             char *l = const_cast<char *>(line), *t = nullptr;
-            q.r = (int) strtol(l, &t, 0);
+            q.r = index(l, &t);
             if (t == l) { q.kind = -1; return q; }
             l = t;
-            q.c = (int) strtol(l, &t, 0);
+            q.c = index(l, &t);
             if (t == l) { q.kind = -2; return q; }
             l = t;
-            q.v = strtod(l, &t);
+            // the value: pattern files have none -- nothing but blanks up to the end of the line is what strtod reports as
+            // "no conversion" (t == l) -- so that case does not call it
+            {
+                const char *e = l;
+                while (*e == ' ' || *e == '\t' || *e == '\r') ++e;
+                if (*e == '\0') t = l; else q.v = strtod(l, &t);
+            }
             if (t == l) q.v = (double) default_value;
             q.kind = (is_symmetric && q.r != q.c) ? 2 : 1;
             return q;
