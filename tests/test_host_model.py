@@ -251,6 +251,33 @@ def test_parallel_market_reader_is_the_serial_reader(H, tmp_path, flavour):
         assert np.array_equal(np.asarray(par[6], np.float64), want.values.astype(np.float64))
 
 
+def test_market_index_fields_follow_strtol_base_0(H, tmp_path):
+    """The reader parses plain decimal indices itself and hands everything else to strtol(., ., 0) as the reference does
+    (sparse_matrix.h:330-345): signs, hex, octal, ten digits, form feeds and digits glued to text must come out the same,
+    and a value field made of blanks is a missing value (default 1.0, :351-355)."""
+    from oracle import oracle as O
+    lines = ["%%MatrixMarket matrix coordinate real general", "40 40 13",
+             "3 4 1.5", "+7 3 2.5", "0x10 0X1f -1", "010 7 3", "\t 12\t 13\t4e0", "  9   9   ", "9 8 \t", "1 2\r",
+             "\x0c5 6 7", "0000000005 3 1", "3 21.5", "1 1", "40 40 -0.25"]
+    path = str(tmp_path / "strtol.mtx")
+    with open(path, "w", newline="") as f:
+        f.write("\n".join(lines) + "\n")
+    want = O.csr_from_coo(*O.coo_market(path))
+    for fp32 in (True, False):
+        par = _host_market(H, "mtx", path, fp32)
+        ser = _host_market(H, "mtx_serial", path, fp32)
+        assert par == ser and par[0] == "ok", par
+        assert (par[1], par[2], par[3]) == (want.rows, want.cols, want.nnz)
+        assert par[4] == want.row_offsets.tolist() and par[5] == want.column_indices.tolist()
+        assert np.array_equal(np.asarray(par[6], np.float64), want.values.astype(np.float32 if fp32 else np.float64).astype(np.float64))
+    # "17abc 3 9": strtol stops at 'a', the column parse then fails on "abc" -> the reference's "badly formed col" exit
+    bad = str(tmp_path / "bad.mtx")
+    with open(bad, "w", newline="") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n5 5 1\n1abc 2 3\n")
+    res = _host_market(H, "mtx", bad, False)
+    assert res[0] == "error" and "badly formed col" in res[1], res
+
+
 def test_parallel_market_reader_throughput(H, tmp_path):
     """not a pass/fail speed gate (CI hosts vary) -- checks a 1M-entry file parses identically with all
     threads and prints both times for the record"""
