@@ -470,17 +470,31 @@ struct CsrMatrix {
                 for (size_t i = a; i < e; ++i) { const int k = tmp[i]; perm[(size_t) cursor[(size_t) (coo.row[(size_t) k] - r0)]++] = k; }
             }
         }
-        // stable sort by column inside each row, rows in parallel
+        // stable sort by column inside each row, rows in parallel.  The row's columns are fetched ONCE into (column, entry
+        // id) keys -- the ids of a row ascend in emission order, so sorting the 64-bit keys is the stable sort by column --
+        // instead of being looked up through the permutation in every comparison (two cache misses each on a 234 M-entry file)
         column_indices.resize(n); values.resize(n);
-#pragma omp parallel for schedule(dynamic, 1024)
-        for (int r = 0; r < num_rows; ++r) {
-            int *b = perm.data() + row_offsets[r], *e = perm.data() + row_offsets[(size_t) r + 1];
-            bool sorted = true;
-            for (int *q = b; q + 1 < e; ++q) if (coo.col[q[1]] < coo.col[q[0]]) { sorted = false; break; }
-            if (!sorted) std::stable_sort(b, e, [&](int a, int c) { return coo.col[a] < coo.col[c]; });
-            for (int *q = b; q < e; ++q) {
-                column_indices[q - perm.data()] = coo.col[*q];
-                values[q - perm.data()] = coo.val[*q];
+#pragma omp parallel
+        {
+            std::vector<unsigned long long> keys;
+#pragma omp for schedule(dynamic, 1024)
+            for (int r = 0; r < num_rows; ++r) {
+                const size_t b = (size_t) row_offsets[r], e = (size_t) row_offsets[(size_t) r + 1];
+                bool sorted = true;
+                int prev = -1;
+                for (size_t i = b; i < e; ++i) {
+                    const int c = coo.col[(size_t) perm[i]];
+                    column_indices[i] = c;
+                    if (c < prev) sorted = false;
+                    prev = c;
+                }
+                if (!sorted) {
+                    keys.resize(e - b);
+                    for (size_t i = b; i < e; ++i) keys[i - b] = ((unsigned long long) (unsigned) column_indices[i] << 32) | (unsigned) perm[i];
+                    std::sort(keys.begin(), keys.end());
+                    for (size_t i = b; i < e; ++i) { perm[i] = (int) (unsigned) keys[i - b]; column_indices[i] = (int) (keys[i - b] >> 32); }
+                }
+                for (size_t i = b; i < e; ++i) values[i] = coo.val[(size_t) perm[i]];
             }
         }
     }
