@@ -17,6 +17,8 @@
 #pragma once
 
 #include <omp.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -408,12 +410,39 @@ struct CsrMatrix {
         if (ok) {
             num_rows = dims[0]; num_cols = dims[1]; num_nonzeros = dims[2];
             row_offsets.resize((size_t) num_rows + 1); column_indices.resize((size_t) num_nonzeros); values.resize((size_t) num_nonzeros);
-            ok = fread(row_offsets.data(), sizeof(int), row_offsets.size(), f) == row_offsets.size() &&
-                 fread(column_indices.data(), sizeof(int), column_indices.size(), f) == column_indices.size() &&
-                 fread(values.data(), sizeof(ValueT), values.size(), f) == values.size() && fgetc(f) == EOF;
+            // the three arrays follow the 28-byte header back to back: every thread preads its share of each (and first
+            // touches the pages it fills); the file must end exactly there
+            const int fd = fileno(f);
+            const uint64_t at_off = 28, at_col = at_off + sizeof(int) * (uint64_t) row_offsets.size(),
+                           at_val = at_col + sizeof(int) * (uint64_t) column_indices.size(),
+                           at_end = at_val + sizeof(ValueT) * (uint64_t) values.size();
+            struct stat st;
+            ok = fstat(fd, &st) == 0 && (uint64_t) st.st_size == at_end;
+            auto read_all = [&](char *dst, uint64_t bytes, uint64_t file_at) {
+                bool good = true;
+                const int T = std::max(1, omp_get_max_threads());
+#pragma omp parallel for schedule(static, 1) reduction(&& : good)
+                for (int t = 0; t < T; ++t) {
+                    uint64_t lo = bytes * (uint64_t) t / T, hi = bytes * (uint64_t) (t + 1) / T;
+                    while (lo < hi && good) {
+                        const ssize_t got = pread(fd, dst + lo, (size_t) std::min<uint64_t>(hi - lo, 1u << 30), (off_t) (file_at + lo));
+                        if (got <= 0) good = false; else lo += (uint64_t) got;
+                    }
+                }
+                return good;
+            };
+            ok = ok && read_all(reinterpret_cast<char *>(row_offsets.data()), at_col - at_off, at_off) &&
+                 read_all(reinterpret_cast<char *>(column_indices.data()), at_val - at_col, at_col) &&
+                 read_all(reinterpret_cast<char *>(values.data()), at_end - at_val, at_val);
             ok = ok && row_offsets.front() == 0 && row_offsets.back() == num_nonzeros;
-            for (size_t r = 0; ok && r < (size_t) num_rows; ++r) ok = row_offsets[r] <= row_offsets[r + 1];
-            for (size_t k = 0; ok && k < (size_t) num_nonzeros; ++k) ok = (unsigned) column_indices[k] < (unsigned) num_cols;
+            if (ok) {
+                bool good = true;
+#pragma omp parallel for schedule(static) reduction(&& : good)
+                for (size_t r = 0; r < (size_t) num_rows; ++r) good = good && row_offsets[r] <= row_offsets[r + 1];
+#pragma omp parallel for schedule(static) reduction(&& : good)
+                for (size_t k = 0; k < (size_t) num_nonzeros; ++k) good = good && (unsigned) column_indices[k] < (unsigned) num_cols;
+                ok = good;
+            }
         }
         fclose(f);
         if (!ok) { num_rows = num_cols = num_nonzeros = 0; row_offsets.clear(); column_indices.clear(); values.clear(); }
