@@ -283,6 +283,44 @@ def test_detector_accepts_uniform_columns(prec, cols, want_passes):
 
 
 @gpu
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_headline_matrix_at_full_size(prec):
+    """BASELINE config 2 exactly as bench.py builds it (3 125 000^2, 32 per row, 10^8 nonzeros): the automatic call runs the
+    passes (64/64 windows), every row is within the strict bound of the fp64 segment sums, the result is bitwise the one
+    of the forced passes and differs from the one-sweep result only by re-association, and it is linear in x."""
+    from merge_spmv_amd import generators as G
+    tdt = torch.float32 if prec == "f32" else torch.float64
+    vb = 4 if prec == "f32" else 8
+    A = G.uniform_csr(3_125_000, 3_125_000, 32, dtype=tdt)
+    x = G.uniform_pm1(G.SEED_C2 + 2, A.cols, tdt, "cuda")
+    offered = M.band_passes(A.rows, A.cols, A.nnz, vb)
+    assert offered == (3 if prec == "f32" else 4)
+    ws = M.CsrMVWorkspace(A.rows, A.nnz, tdt)
+    run = lambda xx: M.csrmv(A.values, A.row_offsets, A.column_indices, xx, num_cols=A.cols, workspace=ws)
+    try:
+        y = run(x)
+        torch.cuda.synchronize()
+        assert int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum()) == 64
+        assert _strict_on_device(A.values, A.row_offsets, A.column_indices, x, y, offered)
+        M.set_band_passes(vb, offered)
+        assert torch.equal(run(x), y)
+        M.set_band_passes(vb, -1)
+        y1 = run(x)
+        assert _strict_on_device(A.values, A.row_offsets, A.column_indices, x, y1, 0)
+        eps = 2.0 ** -24 if prec == "f32" else 2.0 ** -53
+        # 32 products of magnitude < 1 per row: |sum| and sum|.| below 32
+        assert float((y.double() - y1.double()).abs().max()) <= 2 * (16 + offered + 6) * eps * 32
+        M.set_band_passes(vb, 0)
+        # linearity: A (x + 2 x2) = A x + 2 A x2 up to rounding
+        x2 = G.uniform_pm1(G.SEED_C2 + 7, A.cols, tdt, "cuda")
+        lhs = run(x + 2 * x2)
+        rhs = y + 2 * run(x2)
+        assert float((lhs.double() - rhs.double()).abs().max()) <= 8 * (16 + offered + 6) * eps * 32 * 3
+    finally:
+        M.set_band_passes(vb, 0)
+
+
+@gpu
 def test_band_passes_on_two_streams_at_once():
     """Two SpMVs in band mode in flight together (own workspaces, own streams, one matrix): the blocks that run the passes
     wait for nothing but memory, so sharing the CUs with another launch can only slow them down; results stay bitwise."""
