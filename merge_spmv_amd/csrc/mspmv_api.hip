@@ -140,8 +140,11 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
 //   16      1.308      1.085     0.939     1.000           32     1.614      1.501     1.462     1.418
 //   24      1.457      1.323     1.225     1.170
 //   32      1.585      1.445     1.397     1.371
-// only for the large-problem shape with non-temporal streams (> 256 MB of CSR) and at least 8 nonzeros per row, so
-// that a pass is the CSR stream and little else; whether the columns are in fact spread is decided on the device.
+// only for the large-problem shape, from 160 MiB of CSR stream (a matrix the windows refuse pays ~2-4 us for having been
+// asked: 5 % of a 41 us banded SpMV at 24 M nonzeros, 2.5 % from 80 M) and at least 8 nonzeros per row, so that a pass is the
+// CSR stream and little else; whether the columns are in fact spread is decided on the device.  Below 256 MB of stream the
+// passes use ordinary loads like the one-sweep kernel (the matrix then stays in the Infinity Cache from pass to pass:
+// 24 M uniformly spread nonzeros over 7.6 / 11.4 MiB of x: 242 -> 174 us, 301 -> 214 us).
 static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, int rows, int nnz, const CallExtra &ex, int *force)
 {
     *force = 0;
@@ -151,7 +154,7 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     if (policy < 0) return 0;
     if (policy >= 2) { *force = 1; return x_bytes / value_bytes >= policy ? policy : 0; }
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
-    if (stream_bytes <= (256ull << 20) || (L.flags & MSPMV_TUNE_FORCE_TEMPORAL) || (long long) nnz < 8LL * rows) return 0;
+    if (stream_bytes < (160ull << 20) || (long long) nnz < 8LL * rows) return 0;
     const double mib = (double) x_bytes / 1048576.0;
     if (value_bytes == 4) return mib < 5.5 ? 0 : mib < 10.5 ? 2 : mib < 20 ? 3 : mib <= 40 ? 4 : 0;
     return mib < 7 ? 0 : mib < 14 ? 2 : mib < 20 ? 3 : mib <= 36 ? 4 : 0;
@@ -412,8 +415,11 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                     ba.verdict = band_verdict; ba.counters = band_verdict + BAND_WINDOWS; ba.grid = (int) band_grid;
                     ba.next = reinterpret_cast<int *>(base + L.band_next_off);
                     ba.bands = ex.band_passes; ba.band_cols = ex.band_cols; ba.force = ex.band_force;
-                    if (axpby) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, true, false, true, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba);
-                    else       hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, false, false, true, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba);
+#define MSPMV_LAUNCH_BAND(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
+                    if (axpby) { if (nt) MSPMV_LAUNCH_BAND(true, true); else MSPMV_LAUNCH_BAND(true, false); }
+                    else if (nt) MSPMV_LAUNCH_BAND(false, true);
+                    else MSPMV_LAUNCH_BAND(false, false);
+#undef MSPMV_LAUNCH_BAND
                     launched = true;
                 }
             }

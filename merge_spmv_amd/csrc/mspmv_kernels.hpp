@@ -1352,7 +1352,7 @@ struct BandArgs {
 // travels between CUs or XCDs (next[] is written and read by thread 0 of the same block, past the caches).
 // Pass 0 applies the caller's alpha and beta, the later ones add to y and to the stored carries; the ordinary fix-up
 // launch follows.  Blocks drift from one band to the next without a barrier: two slices share L2 only while they do.
-template <typename V, int BLOCK, int IPT>
+template <typename V, int BLOCK, int IPT, bool NT>
 __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__restrict__ coords, Carry<V> *__restrict__ carries,
                                                 int num_tiles, const BandArgs &ba, end16_t *s_end_raw, V *s_prod_raw, unsigned *s_flag,
                                                 int *s_wave_key, V *s_wave_val)
@@ -1400,8 +1400,8 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
             const Coord c0 = coords[tile];
             const Coord c1 = coords[tile + 1];
             TileRegs<V, BLOCK, IPT> regs;
-            issue_nonzero_loads<V, BLOCK, IPT, true, !band_lazy_values<V, true>()>(p, c0, c1, regs, t);     // (fp64: columns now, values by band in the staging)
-            stage_tile<V, BLOCK, IPT, true, true, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, t);
+            issue_nonzero_loads<V, BLOCK, IPT, NT, !band_lazy_values<V, true>()>(p, c0, c1, regs, t);     // (fp64: columns now, values by band in the staging)
+            stage_tile<V, BLOCK, IPT, NT, true, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, t);
             const int pshift = c0.y - (c0.y & ~3);
             const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
             consume_tile_flags<V, BLOCK, IPT, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
             if ((int) blockIdx.x < ba.grid) {
                 if (!AXPBY) { p.alpha = (V) 1; p.beta = (V) 0; }
                 p.x_lds = 0;
-                run_band_passes<V, BLOCK, IPT>(p, coords, carries, num_tiles, ba, s_end_raw, s_prod_raw, s_flag, s_wave_key, s_wave_val);
+                run_band_passes<V, BLOCK, IPT, NT>(p, coords, carries, num_tiles, ba, s_end_raw, s_prod_raw, s_flag, s_wave_key, s_wave_val);
             }
             return;
         }

@@ -37,8 +37,10 @@ def test_automatic_policy_table():
     rows, nnz = 3_000_000, 96_000_000
     assert [M.band_passes(rows, mib(m, 4), nnz, 4) for m in (4, 6, 8, 12, 16, 24, 32, 48)] == [0, 2, 2, 3, 3, 4, 4, 0]
     assert [M.band_passes(rows, mib(m, 8), nnz, 8) for m in (4, 8, 12, 16, 24, 32, 48)] == [0, 2, 2, 3, 4, 4, 0]
-    # a pass must be the CSR stream and little else: > 256 MB of it (non-temporal loads), >= 8 nonzeros per row
-    assert M.band_passes(1_000_000, mib(12, 4), 30_000_000, 4) == 0
+    # a pass must be the CSR stream and little else: >= 160 MiB of it (what asking costs a refused matrix must stay small),
+    # >= 8 nonzeros per row
+    assert M.band_passes(1_000_000, mib(12, 4), 16_000_000, 4) == 0
+    assert M.band_passes(1_000_000, mib(12, 4), 24_000_000, 4) == 3
     assert M.band_passes(20_000_000, mib(12, 4), 100_000_000, 4) == 0
     # dense32 (x of 128 bytes), config 5 (x of 512 MB): never
     assert M.band_passes(3_125_000, 32, 100_000_000, 4) == 0

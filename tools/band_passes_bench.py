@@ -40,11 +40,15 @@ def cases():
         yield f"u{mb}MB_f32", (lambda n=mb * 2**20 // 4: G.uniform_csr(3_000_000, n, 32, dtype=f32))
     for mb in (8, 12, 16, 24, 32):
         yield f"u{mb}MB_f64", (lambda n=mb * 2**20 // 8: G.uniform_csr(3_000_000, n, 32, dtype=f64))
+    # 160-256 MB of CSR stream: ordinary loads, the matrix stays in the Infinity Cache from pass to pass
+    yield "u24Mnnz_7.6MB_f32", lambda: G.uniform_csr(1_000_000, 2_000_000, 24, dtype=f32)
+    yield "u24Mnnz_11MB_f32", lambda: G.uniform_csr(750_000, 3_000_000, 32, dtype=f32)
     yield from refused()
     yield "dense32_f32", lambda: G.dense_csr(3_125_000, 32, dtype=f32, ones=False)
 
 
 def refused():
+    yield "band_2M_x12_f32", lambda: banded(2_000_000, 12, f32)
     yield "band_3M_x33_f32", lambda: banded(3_000_000, 33, f32)
     yield "band_2M_x40_f64", lambda: banded(2_000_000, 40, f64)
     yield "rmat21_64M_f32", lambda: G.rmat_csr(21, 64_000_000, dtype=f32, seed=G.SEED_C3)
