@@ -216,7 +216,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
  * reproducible; rounding differs from the one-sweep result in the last bits (a re-association).
  *   passes = 0  automatic (default): by the sizes of the call (csrc/mspmv_api.hip: band_passes_for) and the verdicts
  *   passes < 0  never
- *   passes >= 2 always that many passes, on any call that takes the large-problem 256x11 tile (tests, tuning). */
+ *   passes >= 2 always that many passes, on any call that takes the 256x11 tile or, in fp64, the 256x7 tile (tests, tuning). */
 int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
 /* *passes = how many passes a call of these sizes is offered under the current setting (0: none; the aligned,
  * vectorised path is assumed); with the automatic setting the device-side verdicts still have the last word. */

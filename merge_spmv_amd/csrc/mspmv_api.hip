@@ -79,6 +79,10 @@ static Shape pick_shape(int value_bytes, long long items, int &flags)
     return Shape{256, 11};
 }
 
+// tile shapes whose vectorised kernel is also compiled with the column-band passes: the large-problem shape, and the fp64
+// shape of problems of up to 24 M path items
+static constexpr bool band_shape(int block, int ipt, int value_bytes) { return block == 256 && (ipt == 11 || (value_bytes == 8 && ipt == 7)); }
+
 struct Layout {
     Shape shape; int flags;
     int num_tiles;
@@ -110,7 +114,7 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
     // column-band passes: the window verdicts and 8 claim counters (always laid out: a buffer sized under one tuning stays
     // large enough under MSPMV_TUNE_NO_FUSED), and one int per tile of the large-problem shape (the chain of tiles each block ran)
     L.band_off = off; off = align256(off + uint64_t(BAND_WINDOWS + 8 * BAND_COUNTER_STRIDE) * sizeof(int));
-    if (!L.fused && L.shape.block == 256 && L.shape.ipt == 11) { L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles) * sizeof(int)); }
+    if (!L.fused && band_shape(L.shape.block, L.shape.ipt, value_bytes)) { L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles) * sizeof(int)); }
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
@@ -148,7 +152,7 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
 static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, int rows, int nnz, const CallExtra &ex, int *force)
 {
     *force = 0;
-    if (ex.no_bands || ex.tile_map != 0 || L.fused || L.shape.block != 256 || L.shape.ipt != 11) return 0;
+    if (ex.no_bands || ex.tile_map != 0 || L.fused || !band_shape(L.shape.block, L.shape.ipt, value_bytes)) return 0;
     if (L.flags & (MSPMV_TUNE_NO_VEC | DEV_FLAG_MASK)) return 0;
     const int policy = g_tune[value_bytes == 8].band_passes.load();
     if (policy < 0) return 0;
@@ -316,7 +320,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     // tile kernel (its BAND variant) runs its ordinary body or the passes
     bool band = false, band_sampled = false;
     unsigned band_grid = 0;
-    if constexpr (BLOCK == 256 && IPT == 11) {
+    if constexpr (band_shape(BLOCK, IPT, (int) sizeof(V))) {
         if (vec && ex.band_passes > 1 && phase != PHASE_COORDS_ONLY) {
             // the passes are run by 4 (fp64: 5) blocks per CU, or as many as are resident at once if that is fewer: the gathers
             // of a pass hit L2, so the passes are not short of waves in flight, and with all 8 slots of a CU taken the
@@ -408,7 +412,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             launched = launch_dev_variant<V, BLOCK, IPT>(L, p, axpby, nt, coords, carries, chunk_log2, stream);
 #endif
             BandArgs ba; ba.verdict = nullptr; ba.counters = nullptr; ba.next = nullptr; ba.grid = 0; ba.bands = 0; ba.band_cols = 0; ba.force = 0;
-            if constexpr (BLOCK == 256 && IPT == 11) {
+            if constexpr (band_shape(BLOCK, IPT, (int) sizeof(V))) {
                 if (band && !launched) {
                     // the BAND variant: the same kernel, whose first band_grid blocks run the column-band passes instead
                     // when the verdicts (or mspmv_set_band_passes) say so

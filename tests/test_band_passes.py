@@ -191,6 +191,39 @@ def test_forced_passes_on_the_reference_golden_matrices(forced_shape, case, prec
 
 
 @gpu
+@pytest.mark.parametrize("shape", ["short_rows", "power_law", "giant_row", "mostly_empty"])
+@pytest.mark.parametrize("passes", [2, 5])
+def test_forced_passes_on_the_fp64_mid_size_tile(shape, passes):
+    """fp64 problems of up to 24 M path items run 256x7 tiles: that kernel carries the passes too"""
+    rng = np.random.default_rng(len(shape) * 13 + passes)
+    rows, cols, lens = SHAPES[shape](rng)
+    csr = _random(rng, rows, cols, np.asarray(lens, np.int64), np.float64)
+    x = rng.uniform(-1, 1, cols)
+    d = lambda a: torch.from_numpy(a).cuda()
+    val, off, col, dx = d(csr.values), d(csr.row_offsets), d(csr.column_indices), d(x)
+    try:
+        M.set_tuning(8, 256, 7, NO_FUSED)
+        M.set_band_passes(8, passes)
+        assert M.band_passes(rows, cols, csr.nnz, 8) == passes
+        ws = M.CsrMVWorkspace(rows, csr.nnz, torch.float64)
+        y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        M.csrmv(val, off, col, dx, y=y, num_cols=cols, workspace=ws)
+        y2 = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        M.csrmv(val, off, col, dx, y=y2, num_cols=cols, workspace=ws)
+        torch.cuda.synchronize()
+        g, s = O.spmv_gold_acc64(csr, x)
+        ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=16 + passes)
+        assert ok, (shape, passes, worst)
+        assert torch.equal(y, y2)
+        M.set_band_passes(8, -1)
+        y1 = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        M.csrmv(val, off, col, dx, y=y1, num_cols=cols, workspace=ws)
+        assert O.strict_check(csr, y1.cpu().numpy(), g, s)[0]
+    finally:
+        M.set_tuning(8); M.set_band_passes(8, 0)
+
+
+@gpu
 def test_forced_passes_more_than_columns_fall_back(forced_shape):
     rng = np.random.default_rng(3)
     csr = _random(rng, 30000, 2, rng.integers(0, 4, 30000), np.float32)
