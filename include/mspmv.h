@@ -16,7 +16,11 @@
  *     otherwise *temp_bytes < needed -> hipErrorInvalidValue
  *     (util_device.cuh:90-93);
  *   - the caller owns every buffer including temp; the callee allocates
- *     nothing and keeps no state between calls;
+ *     nothing and keeps no state between calls (what a call leaves in temp
+ *     storage is scratch, except for mspmv_csrmv_prepare); the only library
+ *     state is the development override of mspmv_set_tuning /
+ *     mspmv_set_band_passes, which is per host thread, off by default and read
+ *     once per call on entry, and the opt-in event profiler;
  *   - all array pointers are DEVICE pointers; d_row_offsets has rows+1 entries
  *     ([0]=0, [rows]=nnz, non-decreasing), 0-based int32 column indices,
  *     duplicates allowed (sparse_matrix.h:645-650,666-728);
@@ -103,7 +107,11 @@ int mspmv_csrmm_f64(void *d_temp, size_t *temp_bytes, const double *d_values,
  * reference's DeviceSpmvSearchKernel, dispatch_spmv_orig.cuh:104-143 -- depend on d_row_offsets
  * alone, yet the reference's stateless CsrMV recomputes them on every call (8-22 us here, 5-15 % of
  * a mid-size SpMV).  mspmv_csrmv_prepare runs that pass once into the caller's temp storage
- * (same two-phase size query; the size equals mspmv_csrmv_*'s for the same rows/nnz/value_bytes);
+ * (same two-phase size query; the size equals mspmv_csrmv_*'s for the same rows/nnz/value_bytes).  The default
+ * one-launch kernel treats the coordinates it finds in temp storage as hints and verifies them, so a stateless
+ * call that follows another on the same temp storage and matrix already runs without a search; preparing makes
+ * the FIRST call as fast as the later ones, and it is what the classic pipeline (column-band candidates, tuning
+ * options) skips its coordinate launch on;
  * mspmv_csrmv_prepared_* then compute y = alpha*A*x + beta*y with the coordinates found there.
  * The caller guarantees that d_temp was prepared for this d_row_offsets / rows / nnz / value_bytes
  * and has since been used only by mspmv calls for the same matrix (they leave the coordinates
@@ -165,7 +173,11 @@ typedef struct mspmv_launch_info {
     int32_t fixup_chunk;       /* carry pairs per fix-up block                */
     int32_t fixup_levels;      /* fix-up launches (0 when num_tiles <= 1)     */
     int32_t flags;             /* MSPMV_TUNE_* bits in effect                 */
-    int32_t reserved;
+    int32_t snap_head_max;     /* > 0: calls of these sizes run ONE launch of row-snapped tiles (tile_kernel_snap;
+                                  16-byte aligned arrays assumed, decided again per call):
+                                  a tile boundary that falls <= this many nonzeros into a row is moved to the row's
+                                  first nonzero, so the per-tile carry that mspmv_debug_read_tiles returns is 0
+                                  there; 0: classic tiles                    */
     uint64_t temp_bytes;       /* what the size query returns                 */
     uint64_t coords_offset;    /* byte offsets of regions inside temp         */
     uint64_t carries_offset;
@@ -186,7 +198,9 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
                            int32_t *h_carry_keys, void *h_carry_values,
                            mspmv_stream_t stream);
 
-/* Tuning override for experiments (process-global atomics; 0 = library default): selects one of the
+/* Tuning override for experiments (per HOST THREAD: it affects the calls the same thread makes afterwards, including
+ * the size queries, and nothing else -- the plans of mspmv_csrmv_plan_* and mspmv_mg_plan_* always run the library
+ * defaults; 0 = library default): selects one of the
  * compiled tile shapes for value_bytes and/or the option bits below.  Returns 0, or
  * hipErrorInvalidValue if that shape was not compiled in or a bit is not one of these.  Every
  * combination accepted here computes correct results; kernels that exist only for timing
@@ -197,8 +211,9 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by a 64-ary wave search per boundary */
 #define MSPMV_TUNE_SCATTER_COORDS 0x10000000 /* ... always by one coalesced pass over all row offsets (the default below 10 M rows) */
 #define MSPMV_TUNE_INTERP_COORDS  0x20000000 /* ... always by one thread per boundary, interpolation search (the default from 10 M rows up) */
-#define MSPMV_TUNE_NO_FUSED   16  /* never use the self-searching small-problem kernel */
-#define MSPMV_TUNE_TWO_LAUNCH 0x40000000 /* small problems: carries added by the separate fix-up launch, not by the tiles themselves */
+#define MSPMV_TUNE_NO_FUSED   16  /* small problems take the large-problem tile shape too (256x11; fp64 up to 24 M path items: 256x7) */
+#define MSPMV_TUNE_TWO_LAUNCH 0x40000000 /* the classic three launches (coordinate pass, tile_kernel_vec with one carry per tile, fix-up) instead of ONE launch of
+                                           row-snapped tiles on verified coordinate hints (tile_kernel_snap) */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
 #define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
 #define MSPMV_TUNE_MULTILEVEL_FIX 128 /* carry fix-up in two/three chunked levels (one launch each) instead of the one-launch owner-computes kernel */

@@ -43,7 +43,7 @@ class _LaunchInfo(ctypes.Structure):
     _fields_ = [("block_threads", ctypes.c_int32), ("items_per_thread", ctypes.c_int32),
                 ("tile_items", ctypes.c_int32), ("num_tiles", ctypes.c_int32),
                 ("fixup_chunk", ctypes.c_int32), ("fixup_levels", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("snap_head_max", ctypes.c_int32),
                 ("temp_bytes", ctypes.c_uint64), ("coords_offset", ctypes.c_uint64),
                 ("carries_offset", ctypes.c_uint64)]
 

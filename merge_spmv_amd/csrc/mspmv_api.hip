@@ -24,47 +24,49 @@
 namespace mspmv {
 
 constexpr int SEARCH_BLOCK = 256;
-constexpr int SINGLE_LAUNCH_MAX_TILES = 2048;   // (a forced shape / MSPMV_FUSED_MAX_TILES may put more tiles on the self-searching kernel)
 constexpr int INTERP_MIN_ROWS = 10000000;       // coordinate pass: interpolation search from here up, scatter pass below
-constexpr int FUSED_CHUNK_LOG2 = 0;      // XCD-chunked mapping (see the tile_kernel_vec dispatch): no measurable effect below 2048 tiles
-constexpr int MM_CHUNK_LOG2 = 6;         // ... 0-3 % on the SpMM tiles
+constexpr int MM_CHUNK_LOG2 = 6;         // XCD-chunked mapping of the SpMM tiles: 0-3 %
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 constexpr int DEV_FLAG_MASK = 1 | 0xff00 | 0x70000 | 0xf00000;   // selectors of the -DMSPMV_DEV kernel variants
-constexpr int FUSED_MAX_TILES_DEFAULT = 1280;    // up to here: tiles search their own coordinates and add the carries themselves
-                                                 // (beyond, the self-searching kernel + fix-up is slower than the three-pass pipeline)
-// (MSPMV_FUSED_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
-static int fused_max_tiles()
+constexpr int SMALL_MAX_TILES_DEFAULT = 1280;    // up to here a problem takes the smallest compiled tile that keeps it within 896 tiles, or the largest
+// (MSPMV_SMALL_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
+static int small_max_tiles()
 {
-    static const int v = [] { const char *e = getenv("MSPMV_FUSED_MAX_TILES"); const int n = e ? atoi(e) : 0; return n > 0 ? n : FUSED_MAX_TILES_DEFAULT; }();
+    static const int v = [] { const char *e = getenv("MSPMV_SMALL_MAX_TILES"); const int n = e ? atoi(e) : 0; return n > 0 ? n : SMALL_MAX_TILES_DEFAULT; }();
     return v;
 }
-#define FUSED_MAX_TILES (fused_max_tiles())
+#define SMALL_MAX_TILES (small_max_tiles())
 
 static_assert(TILE_MAP_CONTIGUOUS_CODE == TILE_MAP_CONTIGUOUS, "mapping code shared with the kernels");
 
-// Tile shapes compiled in (selectable with mspmv_set_tuning; defaults: pick_shape).
+// Tile shapes compiled in.  The product library holds the shapes pick_shape can choose by itself; the three further
+// shapes per precision of the tuning sweeps (tools/sweep.py) exist only in the -DMSPMV_DEV build.
 struct Shape { int block, ipt; };
-static const Shape kShapesF32[] = {{256, 7}, {256, 5}, {256, 9}, {256, 11}, {128, 7}, {512, 7}, {256, 15}};
-static const Shape kShapesF64[] = {{256, 5}, {256, 3}, {256, 7}, {256, 9}, {128, 5}, {512, 5}, {256, 11}};
+#ifdef MSPMV_DEV
+static const Shape kShapesF32[] = {{256, 7}, {256, 9}, {256, 11}, {256, 15}, {256, 5}, {128, 7}, {512, 7}};
+static const Shape kShapesF64[] = {{256, 5}, {256, 7}, {256, 9}, {256, 11}, {256, 3}, {128, 5}, {512, 5}};
+#else
+static const Shape kShapesF32[] = {{256, 7}, {256, 9}, {256, 11}, {256, 15}};
+static const Shape kShapesF64[] = {{256, 5}, {256, 7}, {256, 9}, {256, 11}};
+#endif
 
-struct Tuning { std::atomic<int> block{0}, ipt{0}, flags{0}, band_passes{0}; };   // band_passes: mspmv_set_band_passes
-static Tuning g_tune[2];  // [0] = 4-byte values, [1] = 8-byte values
+// The development override of mspmv_set_tuning / mspmv_set_band_passes: per HOST THREAD (a measuring or testing aid; a
+// library user never touches it), read once per call at the C entry points.  [0] = 4-byte values, [1] = 8-byte values
+static thread_local Tune t_tune[2];
+static inline const Tune &thread_tune(int value_bytes) { return t_tune[value_bytes == 8]; }
 
 // Default shape (measured on MI355X; profiles/r02_small_problem_shapes.txt, r01_sweep_vs_rocsparse.txt):
-//  * a problem that fits ONE compiled tile takes it: one launch, no carries;
-//  * a problem that some compiled tile cuts into at most FUSED_MAX_TILES (1280) tiles runs tile_kernel_fused in ONE
-//    launch (the tiles search their own coordinates and add the carries themselves): the smallest tile that keeps it
+//  * a problem that fits ONE compiled tile takes it;
+//  * a problem that some compiled tile cuts into at most SMALL_MAX_TILES (1280) tiles: the smallest tile that keeps it
 //    within 896 tiles (more, smaller tiles = more CUs busy on a small matrix), else the largest tile;
-//  * everything larger runs the three-pass pipeline (coordinates, tiles, fix-up): 256x11 -- the fastest or within 1 % of
-//    the fastest shape on every large workload tried -- except fp64 problems of up to 24 M path items, where 256x7
-//    (7 resident blocks per CU instead of 5) is 2-4 % faster.
-static Shape pick_shape(int value_bytes, long long items, int &flags)
+//  * everything larger: 256x11 -- the fastest or within 1 % of the fastest shape on every large workload tried -- except
+//    fp64 problems of up to 24 M path items, where 256x7 (7 resident blocks per CU instead of 5) is 2-4 % faster.
+static Shape pick_shape(int value_bytes, long long items, const Tune &t)
 {
-    Tuning &t = g_tune[value_bytes == 8];
-    flags = t.flags.load();
-    if (t.block.load() > 0) return Shape{t.block.load(), t.ipt.load()};
+    if (t.block > 0) return Shape{t.block, t.ipt};
+    const int flags = t.flags;
     static const int ipts32[] = {7, 9, 11, 15}, ipts64[] = {5, 7, 9, 11};
     const int *ipts = value_bytes == 8 ? ipts64 : ipts32;
     auto tiles = [&](int ipt) { return (items + 256LL * ipt - 1) / (256LL * ipt); };
@@ -73,7 +75,7 @@ static Shape pick_shape(int value_bytes, long long items, int &flags)
             if (items <= 256LL * ipts[i]) return Shape{256, ipts[i]};
         for (int i = 0; i < 4; ++i)
             if (tiles(ipts[i]) <= 896) return Shape{256, ipts[i]};
-        if (tiles(ipts[3]) <= FUSED_MAX_TILES) return Shape{256, ipts[3]};
+        if (tiles(ipts[3]) <= SMALL_MAX_TILES) return Shape{256, ipts[3]};
     }
     if (value_bytes == 8 && items <= 24000000LL) return Shape{256, 7};
     return Shape{256, 11};
@@ -83,38 +85,48 @@ static Shape pick_shape(int value_bytes, long long items, int &flags)
 // shape of problems of up to 24 M path items
 static constexpr bool band_shape(int block, int ipt, int value_bytes) { return block == 256 && (ipt == 11 || (value_bytes == 8 && ipt == 7)); }
 
+// room the row-snapped tiles have for the nonzeros they adopt (kernels: snap_head_max)
+static constexpr int snap_head_max_host(int block, int ipt)
+{
+    const int slack = (ipt / 4 + 1) * block * 4 - block * ipt - 16;
+    return slack < 192 ? slack : 192;
+}
+
 struct Layout {
     Shape shape; int flags;
     int num_tiles;
-    bool fused;            // small: tile_kernel_fused (needs aligned arrays, decided again at launch)
     int fix_n[3];          // pairs entering fix-up level i (fix_n[0] == num_tiles)
     int fix_levels;
-    uint64_t coords_off, carries_off, fix_off[2], pub_off, band_off, band_next_off, total;
-    bool single_launch;    // fused AND the carries are added by the tiles themselves (no fix-up launch)
+    uint64_t coords_off, carries_off, fix_off[2], pub_off, band_off, band_next_off, rstart_off, err_off, total;
+    bool snap;             // ONE launch of tile_kernel_snap when the call allows it (aligned arrays, default block -> tile map, no column-band
+                           // passes on offer); the regions of the classic pipeline are laid out all the same
 };
 
-static Layout make_layout(int rows, int nnz, int value_bytes)
+static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
 {
     Layout L; memset(&L, 0, sizeof(L));
     const long long total = (long long) rows + nnz;
-    L.shape = pick_shape(value_bytes, total, L.flags);
+    L.flags = tune.flags;
+    L.shape = pick_shape(value_bytes, total, tune);
     const int tile = L.shape.block * L.shape.ipt;
     L.num_tiles = (int) ((total + tile - 1) / tile);
     const uint64_t pair = value_bytes == 8 ? 16 : 8;
     uint64_t off = 0;
     L.coords_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(Coord));
     L.carries_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * pair);
-    L.fused = !(L.flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED)) && L.num_tiles <= FUSED_MAX_TILES;
-    // small problems: the tiles publish their carries and add them themselves (2 x 8 bytes per tile); no fix-up launch
-    // (up to the tile count at which every block of the heaviest kernel is resident at once; measured: 4-975 tiles
-    // 2.2-3.2 us faster than two launches, 1405 tiles 1.2 us faster, 1912 tiles equal to 1 us slower)
-    L.single_launch = L.fused && L.num_tiles > 1 && L.num_tiles <= SINGLE_LAUNCH_MAX_TILES &&
-                      !(L.flags & (MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX));
-    if (L.fused) { L.pub_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * 16); }
+    // ONE launch (tile_kernel_snap) unless the tuning asks for a piece of the classic pipeline (coordinate pass, tile_kernel_vec or the
+    // dword-per-lane tile_kernel, fix-up)
+    constexpr int classic = MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX;
+    L.snap = L.num_tiles >= 1 && !(L.flags & (classic | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | DEV_FLAG_MASK));
+    // published carries of rows longer than the snap limit (16 bytes per tile)
+    L.pub_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * 16);
     // column-band passes: the window verdicts and 8 claim counters (always laid out: a buffer sized under one tuning stays
     // large enough under MSPMV_TUNE_NO_FUSED), and one int per tile of the large-problem shape (the chain of tiles each block ran)
     L.band_off = off; off = align256(off + uint64_t(BAND_WINDOWS + 8 * BAND_COUNTER_STRIDE) * sizeof(int));
-    if (!L.fused && band_shape(L.shape.block, L.shape.ipt, value_bytes)) { L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles) * sizeof(int)); }
+    L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * sizeof(int));
+    // row start of every boundary (4 bytes): with the coordinates, the hints of tile_kernel_snap
+    L.rstart_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(int));
+    L.err_off = off; off = align256(off + 4);           // error word: receives the call's tag when a bounded poll runs out
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
@@ -152,9 +164,9 @@ static Layout make_layout(int rows, int nnz, int value_bytes)
 static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, int rows, int nnz, const CallExtra &ex, int *force)
 {
     *force = 0;
-    if (ex.no_bands || ex.tile_map != 0 || L.fused || !band_shape(L.shape.block, L.shape.ipt, value_bytes)) return 0;
+    if (ex.no_bands || ex.tile_map != 0 || !band_shape(L.shape.block, L.shape.ipt, value_bytes)) return 0;
     if (L.flags & (MSPMV_TUNE_NO_VEC | DEV_FLAG_MASK)) return 0;
-    const int policy = g_tune[value_bytes == 8].band_passes.load();
+    const int policy = ex.tune.band_passes;
     if (policy < 0) return 0;
     if (policy >= 2) { *force = 1; return x_bytes / value_bytes >= policy ? policy : 0; }
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
@@ -216,15 +228,53 @@ static unsigned long long next_call_tag()
     return z ^ (z >> 31);
 }
 
-static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *name, unsigned grid, unsigned block)
+static hipError_t after_launch(hipStream_t stream, int debug_sync, const char *name, unsigned grid, unsigned block, int *d_error = nullptr, unsigned error_tag = 0)
 {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (debug_sync) {
         printf("mspmv: %s<<<%u, %u>>>\n", name, grid, block); fflush(stdout);
         e = hipStreamSynchronize(stream);
+        if (e == hipSuccess && d_error) {
+            // the error word of the one-launch kernels holds this call's tag when a block gave up waiting for another
+            // block's record (temp storage is not initialised, so any other value means nothing): the affected rows hold
+            // NaN or were not written
+            unsigned h = 0;
+            e = hipMemcpy(&h, d_error, sizeof(h), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && error_tag != 0 && h == error_tag) {
+                fprintf(stderr, "mspmv: %s: a bounded wait between workgroups ran out\n", name);
+                e = hipErrorLaunchFailure;
+            }
+        }
     }
     return e;
+}
+
+// Resident blocks of a kernel on the current device (blocks per CU from the occupancy calculator x CUs), computed once per
+// kernel instantiation and device: what bounds the waits between workgroups of the one-launch kernels.
+template <typename K>
+static int resident_blocks(K kernel, int block, std::atomic<int> (&cache)[64])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) { (void) hipGetLastError(); n = 2; }
+        v = std::min(n, 2048 / block) * device_cus();
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// Largest run length 2^k (<= the wanted one) of the XCD-chunked block -> tile mapping under which a tile that waits for a
+// lower-numbered TILE's record always finds that tile's block dispatched: inside a group of 8 * 2^k blocks a predecessor
+// can sit on a block up to 8 * 2^k - 1 later, and workgroups are dispatched in order, so one group must fit the resident
+// blocks -- twice over, to leave room for whatever else shares the device.
+static int safe_chunk_log2(int wanted_log2, int resident)
+{
+    int k = wanted_log2;
+    while (k > 0 && 16LL * (1LL << k) > resident) --k;
+    return k;
 }
 
 #ifdef MSPMV_DEV
@@ -289,32 +339,43 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     const bool vec = !(L.flags & MSPMV_TUNE_NO_VEC) && p.nnz >= 4 && p.rows >= 3 &&
                      ((reinterpret_cast<uintptr_t>(p.values) | reinterpret_cast<uintptr_t>(p.cols) |
                        reinterpret_cast<uintptr_t>(p.row_end - 1)) & 15) == 0;
-    const bool fused = L.fused && vec;
-    if (phase == PHASE_COORDS_ONLY && L.fused) return hipSuccess;      // those tiles search their own coordinates
-    if (phase == PHASE_SKIP_COORDS && L.fused && !vec) phase = PHASE_ALL;   // (unaligned arrays: nothing was prepared)
     // a profiler slot is taken only by calls that run all the passes it brackets
     const int slot = phase == PHASE_COORDS_ONLY ? -1 : prof_take_slot();
-    if (fused) {
-        // small problems: the tiles search their own coordinates (no coordinate pass)
+    if (L.snap && vec && ex.tile_map == 0 && ex.band_passes <= 1) {
+        // ---- ONE launch: row-snapped tiles on verified coordinate hints (tile_kernel_snap) ----
+        int *rstart = reinterpret_cast<int *>(base + L.rstart_off);
+        if (phase == PHASE_COORDS_ONLY) {
+            // mspmv_csrmv_prepare: fill in the hints (what the first call would otherwise find tile by tile)
+            BoundaryOut bo; bo.coords = coords; bo.rstart = rstart;
+            const bool interp = (L.flags & MSPMV_TUNE_INTERP_COORDS) || (!(L.flags & MSPMV_TUNE_SCATTER_COORDS) && p.rows >= INTERP_MIN_ROWS);
+            const unsigned cgrid = interp ? (unsigned) ((L.num_tiles + 1 + SEARCH_BLOCK - 1) / SEARCH_BLOCK)
+                                          : (unsigned) ((((long long) p.rows + 1 + 3) / 4 + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
+            if (interp) hipLaunchKernelGGL((coords_interp_kernel<SEARCH_BLOCK>), dim3(cgrid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows, p.nnz, tile_items, L.num_tiles, bo);
+            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true>), dim3(cgrid), dim3(SEARCH_BLOCK), 0, stream, p.row_end - 1, p.rows, p.nnz, L.num_tiles, bo, BandDetectArgs{});
+            return after_launch(stream, debug_sync, interp ? "coords_interp_kernel" : "coords_scatter_kernel", cgrid, SEARCH_BLOCK);
+        }
         prof_mark(stream, slot, 0);
         prof_mark(stream, slot, 1);
+        const unsigned long long tag = next_call_tag();
+        LookBack lb; lb.rec = reinterpret_cast<unsigned long long *>(base + L.pub_off);
+        lb.tag_a = (unsigned) (tag >> 32) | 1u; lb.tag_b = (unsigned) tag; lb.error = reinterpret_cast<int *>(base + L.err_off);
+        static std::atomic<int> snap_cache[64];
+        const int chunk_flag = (L.flags >> 24) & 0xf;
+        const int wanted = chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
+        const int chunk_log2 = safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
+        const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
+        const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (256ull << 20));
         const unsigned grid = (unsigned) L.num_tiles;
-        // (small problems always fit the Infinity Cache: ordinary loads)
-        const int fchunk_flag = (L.flags >> 24) & 0xf;
-        const int fchunk = fchunk_flag == 0 ? FUSED_CHUNK_LOG2 : fchunk_flag == 15 ? 0 : fchunk_flag;
         const size_t xl = (size_t) p.x_lds * sizeof(V);
-        LookBack lb; lb.rec = nullptr; lb.tag_a = lb.tag_b = 0;
-        int map = fchunk;
-        if (L.single_launch) {
-            const unsigned long long tag = next_call_tag();
-            lb.rec = reinterpret_cast<unsigned long long *>(base + L.pub_off);
-            lb.tag_a = (unsigned) (tag >> 32) | 1u;                 // never 0: a cleared record is never valid
-            lb.tag_b = (unsigned) tag;
-            map = 0;                                                // blocks take tiles in block order: a tile waits on a lower-numbered block only
-        }
-        if (axpby) hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, true, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, map, lb);
-        else       hipLaunchKernelGGL((tile_kernel_fused<V, BLOCK, IPT, false, false>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, carries, L.num_tiles, map, lb);
-        MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_fused", grid, BLOCK));
+#define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, rstart, carries, L.num_tiles, chunk_log2, lb)
+        if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
+        else if (nt) MSPMV_LAUNCH_SNAP(false, true);
+        else MSPMV_LAUNCH_SNAP(false, false);
+#undef MSPMV_LAUNCH_SNAP
+        MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_snap", grid, BLOCK, lb.error, lb.tag_a));
+        prof_mark(stream, slot, 2);
+        prof_mark(stream, slot, 3);
+        return hipSuccess;
     } else {
     // column-band passes (band_passes_for): 64 sampled windows of column indices decide, on the device, whether the
     // tile kernel (its BAND variant) runs its ordinary body or the passes
@@ -344,21 +405,22 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     int *band_verdict = reinterpret_cast<int *>(base + L.band_off);
     BandDetectArgs da; da.cols = p.cols; da.nnz = p.nnz; da.num_cols = ex.num_cols; da.line_shift = sizeof(V) == 4 ? 5 : 4;
     da.verdict = band_verdict;
-    // 1. tile boundary coordinates
+    // 1. tile boundary coordinates (also the row start of every boundary: a later prepared call may run tile_kernel_snap on them)
+    BoundaryOut bo; bo.coords = coords; bo.rstart = reinterpret_cast<int *>(base + L.rstart_off);
     prof_mark(stream, slot, 0);
     if (phase == PHASE_SKIP_COORDS) {
         // already in d_temp
     } else if (L.flags & MSPMV_TUNE_BINARY_SEARCH) {
         const unsigned grid = (unsigned) ((L.num_tiles + 1 + (SEARCH_BLOCK / WAVE) - 1) / (SEARCH_BLOCK / WAVE));
         hipLaunchKernelGGL((search_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows,
-                           p.nnz, tile_items, L.num_tiles, coords);
+                           p.nnz, tile_items, L.num_tiles, bo);
         MSPMV_CHECK(after_launch(stream, debug_sync, "search_kernel", grid, SEARCH_BLOCK));
     } else if ((L.flags & MSPMV_TUNE_INTERP_COORDS) || (!(L.flags & MSPMV_TUNE_SCATTER_COORDS) && p.rows >= INTERP_MIN_ROWS)) {
         // from 10 M rows up: one thread per boundary, interpolation search (latency-bound: <= 17 us whatever the row
         // count, 2-8 us on regular matrices) instead of reading all of row_offsets (20-23 us at 16.8 M rows)
         const unsigned grid = (unsigned) ((L.num_tiles + 1 + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
         hipLaunchKernelGGL((coords_interp_kernel<SEARCH_BLOCK>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, p.row_end, p.rows, p.nnz,
-                           tile_items, L.num_tiles, coords);
+                           tile_items, L.num_tiles, bo);
         MSPMV_CHECK(after_launch(stream, debug_sync, "coords_interp_kernel", grid, SEARCH_BLOCK));
     } else {
         const long long threads = ((long long) p.rows + 1 + 3) / 4;       // 4 row indices per thread
@@ -369,16 +431,16 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             // + BAND_WINDOWS blocks that sample the column windows: no launch of their own
             const unsigned dgrid = grid + BAND_WINDOWS;
             if (aligned) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true, true>), dim3(dgrid), dim3(SEARCH_BLOCK), 0,
-                                            stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
+                                            stream, row_offsets, p.rows, p.nnz, L.num_tiles, bo, da);
             else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, false, true>), dim3(dgrid), dim3(SEARCH_BLOCK), 0,
-                                    stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
+                                    stream, row_offsets, p.rows, p.nnz, L.num_tiles, bo, da);
             band_sampled = true;
         } else if (aligned)
             hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, true>), dim3(grid), dim3(SEARCH_BLOCK), 0,
-                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
+                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, bo, da);
         else
             hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, BLOCK * IPT, false>), dim3(grid), dim3(SEARCH_BLOCK), 0,
-                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, coords, da);
+                               stream, row_offsets, p.rows, p.nnz, L.num_tiles, bo, da);
         MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", band ? grid + BAND_WINDOWS : grid, SEARCH_BLOCK));
     }
     if (phase == PHASE_COORDS_ONLY) return hipSuccess;
@@ -444,7 +506,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     // 3. carry fix-up (not needed for a single tile: its carry is the (rows, 0) pair; nor when the self-searching
     //    tiles of a small problem have added the carries themselves)
     prof_mark(stream, slot, 2);
-    if (L.num_tiles > 1 && !(fused && L.single_launch)) {
+    if (L.num_tiles > 1) {
         if (L.flags & MSPMV_TUNE_ATOMIC_FIX) {
             const unsigned grid = (unsigned) ((L.num_tiles + FIX_BLOCK - 1) / FIX_BLOCK);
             hipLaunchKernelGGL((fixup_atomic_kernel<V, FIX_BLOCK>), dim3(grid), dim3(FIX_BLOCK), 0, stream, carries,
@@ -484,12 +546,14 @@ hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<flo
                                  int debug_sync, const CallExtra &ex)
 {
     MSPMV_SHAPE_CASE(float, 256, 7)
-    MSPMV_SHAPE_CASE(float, 256, 5)
     MSPMV_SHAPE_CASE(float, 256, 9)
     MSPMV_SHAPE_CASE(float, 256, 11)
+    MSPMV_SHAPE_CASE(float, 256, 15)
+#ifdef MSPMV_DEV
+    MSPMV_SHAPE_CASE(float, 256, 5)
     MSPMV_SHAPE_CASE(float, 128, 7)
     MSPMV_SHAPE_CASE(float, 512, 7)
-    MSPMV_SHAPE_CASE(float, 256, 15)
+#endif
     return hipErrorInvalidValue;
 }
 
@@ -498,12 +562,14 @@ hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<do
                                   hipStream_t stream, int debug_sync, const CallExtra &ex)
 {
     MSPMV_SHAPE_CASE(double, 256, 5)
-    MSPMV_SHAPE_CASE(double, 256, 3)
     MSPMV_SHAPE_CASE(double, 256, 7)
     MSPMV_SHAPE_CASE(double, 256, 9)
+    MSPMV_SHAPE_CASE(double, 256, 11)
+#ifdef MSPMV_DEV
+    MSPMV_SHAPE_CASE(double, 256, 3)
     MSPMV_SHAPE_CASE(double, 128, 5)
     MSPMV_SHAPE_CASE(double, 512, 5)
-    MSPMV_SHAPE_CASE(double, 256, 11)
+#endif
     return hipErrorInvalidValue;
 }
 
@@ -514,7 +580,7 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
     if ((long long) rows + nnz > MAX_ITEMS) return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, (int) sizeof(V));
+    const Layout L = make_layout(rows, nnz, (int) sizeof(V), ex.tune);
     if (d_temp == nullptr) {                      // size query (dispatch_spmv_orig.cuh:651-655)
         *temp_bytes = (size_t) L.total;
         return hipSuccess;
@@ -540,14 +606,14 @@ template int csrmv_call<float>(void *, size_t *, const float *, const int32_t *,
 template int csrmv_call<double>(void *, size_t *, const double *, const int32_t *, const int32_t *, const double *, double *,
                                 int32_t, int32_t, int32_t, double, double, bool, hipStream_t, int, const CallExtra &);
 
-uint64_t csrmv_temp_bytes(int32_t rows, int32_t nnz, int32_t value_bytes) { return make_layout(rows, nnz, value_bytes).total; }
+uint64_t csrmv_temp_bytes(int32_t rows, int32_t nnz, int32_t value_bytes) { return make_layout(rows, nnz, value_bytes, Tune{}).total; }
 
 template <typename V>
 static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets,
                       const int32_t *d_cols, const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha,
                       V beta, bool axpby, mspmv_stream_t stream_, int debug_sync, int phase = PHASE_ALL)
 {
-    CallExtra ex; ex.phase = phase;
+    CallExtra ex; ex.phase = phase; ex.tune = thread_tune((int) sizeof(V));
     return csrmv_call<V>(d_temp, temp_bytes, d_values, d_row_offsets, d_cols, d_x, d_y, rows, cols, nnz, alpha, beta, axpby,
                          reinterpret_cast<hipStream_t>(stream_), debug_sync, ex);
 }
@@ -704,9 +770,9 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
             Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off[ti]);
             const long long threads = ((long long) rows + 1 + 3) / 4;
             const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
-            if (ti == 0) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 7, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[0], coords, BandDetectArgs{});
-            else if (ti == 1) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[1], coords, BandDetectArgs{});
-            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 128 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[2], coords, BandDetectArgs{});
+            if (ti == 0) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 7, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[0], BoundaryOut{coords, nullptr}, BandDetectArgs{});
+            else if (ti == 1) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[1], BoundaryOut{coords, nullptr}, BandDetectArgs{});
+            else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 128 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[2], BoundaryOut{coords, nullptr}, BandDetectArgs{});
             MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
             have_coords[ti] = true;
         }
@@ -811,15 +877,16 @@ int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_
     if (!info || (value_bytes != 4 && value_bytes != 8) || rows < 0 || nnz < 0 ||
         (long long) rows + nnz > MAX_ITEMS)
         return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, value_bytes);
+    const Layout L = make_layout(rows, nnz, value_bytes, thread_tune(value_bytes));
     memset(info, 0, sizeof(*info));
     info->block_threads = L.shape.block;
     info->items_per_thread = L.shape.ipt;
     info->tile_items = L.shape.block * L.shape.ipt;
     info->num_tiles = L.num_tiles;
     info->fixup_chunk = FIX_CHUNK;
-    info->fixup_levels = L.single_launch ? 0 : L.fix_levels;     // (fix-up launches; 0: the tiles add the carries themselves)
+    info->fixup_levels = L.snap ? 0 : L.fix_levels;     // (fix-up launches; 0: the tiles add the carries themselves)
     info->flags = L.flags;
+    info->snap_head_max = L.snap ? snap_head_max_host(L.shape.block, L.shape.ipt) : 0;
     info->temp_bytes = L.total;
     info->coords_offset = L.coords_off;
     info->carries_offset = L.carries_off;
@@ -829,8 +896,8 @@ int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_
 int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes, int32_t *h_coords,
                            int32_t *h_carry_keys, void *h_carry_values, mspmv_stream_t stream_)
 {
-    if (!d_temp || (value_bytes != 4 && value_bytes != 8)) return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, value_bytes);
+    if (!d_temp || (value_bytes != 4 && value_bytes != 8) || rows < 0 || nnz < 0 || (long long) rows + nnz > MAX_ITEMS) return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, value_bytes, thread_tune(value_bytes));
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     MSPMV_CHECK(hipStreamSynchronize(stream));
     const char *base = static_cast<const char *>(d_temp);
@@ -863,7 +930,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     allowed |= MSPMV_DEV_FLAG_BITS;        // development kernels (mspmv_dev.hpp): never in the product library
 #endif
     if (flags & ~allowed) return hipErrorInvalidValue;
-    Tuning &t = g_tune[value_bytes == 8];
+    Tune &t = t_tune[value_bytes == 8];
     if (block_threads == 0 && items_per_thread == 0) { t.block = 0; t.ipt = 0; t.flags = flags; return hipSuccess; }
     for (int i = 0; i < count; ++i)
         if (tab[i].block == block_threads && tab[i].ipt == items_per_thread) {
@@ -876,7 +943,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
 int mspmv_set_band_passes(int32_t value_bytes, int32_t passes)
 {
     if ((value_bytes != 4 && value_bytes != 8) || passes == 1 || passes > 64) return hipErrorInvalidValue;
-    g_tune[value_bytes == 8].band_passes = passes < 0 ? -1 : passes;
+    t_tune[value_bytes == 8].band_passes = passes < 0 ? -1 : passes;
     return hipSuccess;
 }
 
@@ -884,8 +951,8 @@ int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value
 {
     if (!passes || rows < 0 || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8) || (long long) rows + nnz > MAX_ITEMS)
         return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, value_bytes);
-    CallExtra ex; int force = 0;
+    const Layout L = make_layout(rows, nnz, value_bytes, thread_tune(value_bytes));
+    CallExtra ex; ex.tune = thread_tune(value_bytes); int force = 0;
     *passes = band_passes_for(L, (long long) cols * value_bytes, value_bytes, rows, nnz, ex, &force);
     return hipSuccess;
 }
@@ -893,9 +960,9 @@ int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value
 int mspmv_debug_band_windows(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes, int32_t *h_verdicts,
                              mspmv_stream_t stream_)
 {
-    if (!d_temp || !h_verdicts || (value_bytes != 4 && value_bytes != 8)) return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, value_bytes);
-    if (L.fused) return hipErrorInvalidValue;           // (small problems never sample)
+    if (!d_temp || !h_verdicts || (value_bytes != 4 && value_bytes != 8) || rows < 0 || nnz < 0 || (long long) rows + nnz > MAX_ITEMS)
+        return hipErrorInvalidValue;
+    const Layout L = make_layout(rows, nnz, value_bytes, thread_tune(value_bytes));
     MSPMV_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream_)));
     return (int) hipMemcpy(h_verdicts, static_cast<const char *>(d_temp) + L.band_off, sizeof(int32_t) * BAND_WINDOWS, hipMemcpyDeviceToHost);
 }

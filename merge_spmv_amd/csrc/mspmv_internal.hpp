@@ -15,8 +15,15 @@ namespace mspmv {
 // depend on row_offsets alone and are reused across the SpMVs of a solver)
 enum { PHASE_ALL = 0, PHASE_COORDS_ONLY = 1, PHASE_SKIP_COORDS = 2 };
 
+// Tile shape / option bits / band-pass policy of ONE call (0 everywhere = the library defaults).  The C entry points copy
+// the calling host thread's development override (mspmv_set_tuning, mspmv_set_band_passes) into it once, on entry; the
+// prepared band-major plan and the multi-GPU plan always pass the defaults, so what they store at build time (tile
+// coordinates) can never disagree with what a later apply derives.
+struct Tune { int block = 0, ipt = 0, flags = 0, band_passes = 0; };
+
 struct CallExtra {
     int phase = PHASE_ALL;
+    Tune tune;
     int tile_map = 0;       // 0: library default (XCD-chunked runs of 64 tiles); else the chunk_log2 code of
                             // xcd_chunked_tile (TILE_MAP_CONTIGUOUS_CODE: one contiguous tile range per XCD)
     // column-band passes (filled in by csrmv_call, see band_passes_for): > 1 = tile_kernel_band may serve the call
@@ -32,7 +39,7 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
                const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha, V beta, bool axpby,
                hipStream_t stream, int debug_sync, const CallExtra &extra);
 
-// bytes of temp storage csrmv_call needs (what the size query returns)
+// bytes of temp storage csrmv_call needs under the default tuning (what the size query of the plans' inner calls returns)
 uint64_t csrmv_temp_bytes(int32_t rows, int32_t nnz, int32_t value_bytes);
 
 // largest rows + nnz one call accepts: 2^31 minus room for the chunk arithmetic of the

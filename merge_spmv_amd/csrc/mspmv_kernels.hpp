@@ -5,27 +5,29 @@
 // any CUB/hipCUB/rocPRIM primitive) is used.  The algorithm contract is
 // SURVEY.md Appendix B.
 //
-// Device passes per SpMV, all on the caller's stream (mspmv_api.hip picks):
+// What a SpMV runs, all on the caller's stream (mspmv_api.hip picks):
+//   ONE launch, the default: tile_kernel_snap -- one 256-thread block per merge tile (XCD-chunked tile order).  The tile's
+//                      two boundaries are HINTS read from the caller's temp storage and verified against four row offsets
+//                      (wrong: two waves search them -- wave_merge_path_guess -- and store the repaired hints); boundaries
+//                      that fall a short way into a row are snapped to the row's first nonzero, so there are no carries
+//                      and no fix-up for short rows; rows longer than that hand their pieces over as tagged records
+//                      (LookBack).  Inside the tile: 16-byte streaming of (col, val) and row offsets, gather of x (from a
+//                      per-block LDS copy when x is <= 4 KB), products and 16-bit tile-relative row ends staged in LDS, one
+//                      bit per row start; segmented running sums over 12 consecutive products per thread + one block-wide
+//                      DPP segmented scan (consume_tile_flags), y stored per row from registers  (ref: DeviceSpmvKernel)
+//   the classic three launches (column-band candidates, the band-major plan's tile order, unaligned arrays, tuning options):
 //   1. tile boundaries of the merge path -> coords[tile]            (ref: DeviceSpmvSearchKernel)
 //        coords_scatter_kernel : ONE coalesced pass over row_offsets (row end r sits at path position
 //                      r + row_end[r]); the default below 10 M rows;
 //        coords_interp_kernel  : one THREAD per boundary -- bracket in an LDS table of 1025 samples, secant steps,
 //                      exact binary search of what is left; latency-bound, the default from 10 M rows up;
 //        search_kernel : one WAVE per boundary, 64-ary search (option)
-//   2. tile_kernel_vec : one 256-thread block per merge tile (XCD-chunked tile order, or one contiguous tile
-//                      range per XCD for the prepared band-major plan), 16-byte streaming of (col, val) and row
-//                      offsets, gather of x (from a per-block LDS copy when x is <= 4 KB), products
-//                      and 16-bit tile-relative row ends staged in LDS, one bit per row start;
-//                      segmented running sums over 12 consecutive products per thread + one
-//                      block-wide DPP segmented scan (consume_tile_flags), y stored per row from
-//                      registers, one (row, partial) carry per tile  (ref: DeviceSpmvKernel)
+//      (the same kernels fill in the hints of tile_kernel_snap ahead of time: mspmv_csrmv_prepare)
+//   2. tile_kernel_vec : the same tile body on stored coordinates, one (row, partial) carry per tile
 //      tile_kernel_vec<.., BAND> : the same kernel with the column-band passes compiled in (run_band_passes): when 64
 //                      sampled windows of column indices (band_detect_block, riding on the coordinate launch) say the
 //                      columns are spread uniformly over an x several times L2, the first 4-5 blocks per CU stream the
 //                      matrix once per band of x instead (C2 fp32: 1.22 -> 0.83 ms); otherwise the ordinary body runs
-//      tile_kernel_fused : the same for <= 2048 tiles, each block searching its own two
-//                      coordinates (no pass 1): 64 fixed samples, 64 consecutive rows at the interpolated point,
-//                      64-ary rounds on the rest;
 //      tile_kernel     : dword-per-lane fallback for unaligned arrays, with the reference's
 //                      per-thread search + path walk (consume_tile_lds)
 //   3. fixup_onepass_kernel : deterministic reduce-by-key over the per-tile carries in one
@@ -73,6 +75,53 @@ struct Params {
     // [band_lo, band_lo + band_len) and treats the others as zeros; band_pass > 0 adds its carries to the stored ones
     int band_lo, band_len, band_pass;
 };
+
+// ---------------------------------------------------------------------------
+// Tagged records: how blocks of ONE launch hand each other 64 bits (tile_kernel_snap).  A record is two
+// 64-bit words, each carrying half of a per-call tag beside 32 bits of payload, written and read with relaxed agent-scope
+// atomics (visible across the XCDs' L2s without a cache flush).  A word is valid when its tag half matches, so no ordering
+// between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits, and the ONE consumer every
+// record has clears it -- none outlives the call, which also makes a captured call replayable with the same tags, even
+// after the matrix changed.  Polling is bounded (~seconds): running out writes the call's tag into the error word of its temp
+// storage (reported by the next debug_sync call) instead of hanging; it is never seen in practice, because the awaited
+// block is always one that was dispatched earlier or fits beside the waiting one (mspmv_api.hip: safe_chunk_log2).
+// ---------------------------------------------------------------------------
+constexpr int REC_MAX_POLLS = 1 << 21;      // x ~1 us
+__device__ __forceinline__ void rec_store(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned p0, unsigned p1)
+{
+    __hip_atomic_store(rec, ((unsigned long long) tag_a << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 1, ((unsigned long long) tag_b << 32) | p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits (bounded) until both words carry this call's tag, clears the record; false = timed out (payload undefined)
+__device__ __forceinline__ bool rec_take(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned &p0, unsigned &p1)
+{
+    for (int polls = 0; polls < REC_MAX_POLLS; ++polls) {
+        const unsigned long long w0 = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w1 = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned) (w0 >> 32) == tag_a && (unsigned) (w1 >> 32) == tag_b) {
+            __hip_atomic_store(rec, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p0 = (unsigned) w0; p1 = (unsigned) w1;
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// Where a coordinate pass puts what it finds about tile boundary t -- the merge-path point (x, y) of diagonal t * TILE:
+//   coords[t] = (x, y)                       what the tile kernels read; mspmv_debug_read_tiles
+//   rstart[t] = row_offsets[x]               the first nonzero of the row the boundary falls in (tile_kernel_snap; nullptr: not wanted)
+struct BoundaryOut {
+    Coord *coords;
+    int *rstart;
+};
+__device__ __forceinline__ void emit_boundary(const BoundaryOut &o, int t, int x, int y, int row_start)
+{
+    Coord c; c.x = x; c.y = y;
+    o.coords[t] = c;
+    if (o.rstart) o.rstart[t] = row_start;
+}
 
 // A tiny x (the reference's --dense=<cols> inputs: 5 or 32 entries) is copied to LDS once per block and
 // gathered there: the x gather then costs LDS reads instead of 12 vector-memory instructions per thread --
@@ -168,7 +217,7 @@ __device__ __forceinline__ Coord wave_merge_path_search_interp(int diagonal, con
 // thread per boundary, binary search).  coords has num_tiles+1 entries.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void search_kernel(const int *__restrict__ row_end, int rows, int nnz,
-                                                       int tile_items, int num_tiles, Coord *__restrict__ coords)
+                                                       int tile_items, int num_tiles, BoundaryOut out)
 {
     const int wave_in_block = threadIdx.x / WAVE;
     const int boundary = blockIdx.x * (BLOCK / WAVE) + wave_in_block;
@@ -177,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void search_kernel(const int *__restrict__ r
     long long d = (long long) boundary * tile_items;
     const int diagonal = (int) (d < total ? d : total);
     const Coord c = wave_merge_path_search(diagonal, row_end, rows, nnz);
-    if ((threadIdx.x & (WAVE - 1)) == 0) coords[boundary] = c;
+    if ((threadIdx.x & (WAVE - 1)) == 0) emit_boundary(out, boundary, c.x, c.y, c.x > 0 ? row_end[c.x - 1] : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -271,19 +320,15 @@ __global__ __launch_bounds__(BLOCK) void band_detect_kernel(BandDetectArgs a)
 // of 2^26 nonzeros owns ~37 000 of them).  Measured on MI355X: 3-15 us where
 // the search kernel took 27-52 us.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int TILE_ITEMS, bool VEC, bool DETECT = false>
-__global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__restrict__ row_offsets, int rows, int nnz,
-                                                               int num_tiles, Coord *__restrict__ coords, BandDetectArgs da)
+template <int BLOCK, int TILE_ITEMS, bool VEC>
+__device__ __forceinline__ void coords_scatter_block(const int *__restrict__ row_offsets, int rows, int nnz, int num_tiles,
+                                                     const BoundaryOut &out, unsigned block)
 {
-    // DETECT: the first BAND_WINDOWS blocks of the grid sample the column windows (column-band passes, above) -- first, so
-    // that their two dependent memory round trips run under the coordinate work instead of after it
-    if constexpr (DETECT) {
-        if ((int) blockIdx.x < BAND_WINDOWS) { band_detect_block<BLOCK>(da, (int) blockIdx.x); return; }
-    }
-    const unsigned block = DETECT ? blockIdx.x - BAND_WINDOWS : blockIdx.x;
     // With M(i) = (i - 1) + row_offsets[i] (i >= 1; the merge position of row-end i - 1) and
     // M(0) = -1, row r owns the boundaries t with M(r) < t*TILE_ITEMS <= M(r + 1); row index
     // `rows` owns the ones past M(rows).  A thread takes 4 consecutive r (one 16-byte load).
+    // A boundary owned by row r lies INSIDE row r (r row-ends consumed, between row_offsets[r] and
+    // row_offsets[r + 1] nonzeros), so the row's first nonzero is o[j] -- what tile_kernel_snap wants to know.
     const int lane = threadIdx.x & (WAVE - 1);
     const long long gid = (long long) block * BLOCK + threadIdx.x;
     const int total = rows + nnz;                              // < 2^31
@@ -310,8 +355,7 @@ __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__rest
             if (count > 0 && count <= 2) {
                 for (int t = t_lo[j]; t <= t_hi[j]; ++t) {
                     const long long d = (long long) t * TILE_ITEMS;
-                    Coord c; c.x = (int) r; c.y = (int) (d < total ? d : total) - (int) r;
-                    coords[t] = c;
+                    emit_boundary(out, t, (int) r, (int) (d < total ? d : total) - (int) r, o[j]);
                 }
             }
             any_long |= count > 2;
@@ -327,13 +371,25 @@ __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__rest
             pending &= pending - 1;
             const int lo = __shfl(t_lo[j], src, WAVE), hi = __shfl(t_hi[j], src, WAVE);
             const int rr = (int) __shfl((int) base, src, WAVE) + j;
+            const int rs = __shfl(o[j], src, WAVE);
             for (int t = lo + lane; t <= hi; t += WAVE) {
                 const long long d = (long long) t * TILE_ITEMS;
-                Coord c; c.x = rr; c.y = (int) (d < total ? d : total) - rr;
-                coords[t] = c;
+                emit_boundary(out, t, rr, (int) (d < total ? d : total) - rr, rs);
             }
         }
     }
+}
+
+template <int BLOCK, int TILE_ITEMS, bool VEC, bool DETECT = false>
+__global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__restrict__ row_offsets, int rows, int nnz,
+                                                               int num_tiles, BoundaryOut out, BandDetectArgs da)
+{
+    // DETECT: the first BAND_WINDOWS blocks of the grid sample the column windows (column-band passes, above) -- first, so
+    // that their two dependent memory round trips run under the coordinate work instead of after it
+    if constexpr (DETECT) {
+        if ((int) blockIdx.x < BAND_WINDOWS) { band_detect_block<BLOCK>(da, (int) blockIdx.x); return; }
+    }
+    coords_scatter_block<BLOCK, TILE_ITEMS, VEC>(row_offsets, rows, nnz, num_tiles, out, DETECT ? blockIdx.x - BAND_WINDOWS : blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -353,33 +409,35 @@ __global__ __launch_bounds__(BLOCK) void coords_scatter_kernel(const int *__rest
 // grid2d-4096 20.3 -> 16.5; below that size the scatter pass is at least as fast on irregular matrices).
 // ---------------------------------------------------------------------------
 constexpr int INTERP_SAMPLES = 1024;
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void coords_interp_kernel(const int *__restrict__ row_end, int rows, int nnz, int tile_items,
-                                                              int num_tiles, Coord *__restrict__ coords)
+// s_m: SAMPLES + 1 ints of LDS (M values fit 32 bits: rows + nnz + 1 < 2^31); has a barrier inside
+template <int BLOCK, int SAMPLES = INTERP_SAMPLES>
+__device__ __forceinline__ void coords_interp_block(const int *__restrict__ row_end, int rows, int nnz, int tile_items, int num_tiles,
+                                                    const BoundaryOut &out, unsigned block, int *s_m)
 {
-    static_assert(INTERP_SAMPLES % BLOCK == 0, "whole rounds of sample loads");
-    __shared__ long long s_m[INTERP_SAMPLES + 1];
-    const long long total = (long long) rows + nnz;
-    auto sample_pos = [&](int k) { return (int) ((long long) k * rows / INTERP_SAMPLES); };
-    auto m_of = [&](int p) { return p < rows ? (long long) row_end[p] + p + 1 : total + 1; };
-    for (int k = threadIdx.x; k < INTERP_SAMPLES; k += BLOCK) s_m[k] = m_of(sample_pos(k));
-    if (threadIdx.x == 0) s_m[INTERP_SAMPLES] = total + 1;          // M(rows) = +inf
+    static_assert(SAMPLES % BLOCK == 0, "whole rounds of sample loads");
+    const int total = rows + nnz;
+    auto sample_pos = [&](int k) { return (int) ((long long) k * rows / SAMPLES); };
+    auto m_of = [&](int p) { return p < rows ? row_end[p] + p + 1 : total + 1; };
+    for (int k = threadIdx.x; k < SAMPLES; k += BLOCK) s_m[k] = m_of(sample_pos(k));
+    if (threadIdx.x == 0) s_m[SAMPLES] = total + 1;          // M(rows) = +inf
     __syncthreads();
-    const int boundary = blockIdx.x * BLOCK + threadIdx.x;
-    if (boundary > num_tiles) return;
-    long long d = (long long) boundary * tile_items; d = d < total ? d : total;
-    // bracket: first sample k with M(p_k) > d  (k = INTERP_SAMPLES always qualifies)
-    int klo = 0, khi = INTERP_SAMPLES;
+    const long long boundary_ll = (long long) block * BLOCK + threadIdx.x;
+    if (boundary_ll > num_tiles) return;
+    const int boundary = (int) boundary_ll;
+    long long dl = (long long) boundary * tile_items;
+    const int d = (int) (dl < total ? dl : total);
+    // bracket: first sample k with M(p_k) > d  (k = SAMPLES always qualifies)
+    int klo = 0, khi = SAMPLES;
     while (klo < khi) { const int mid = (klo + khi) >> 1; if (s_m[mid] > d) khi = mid; else klo = mid + 1; }
     int b = sample_pos(klo);                                       // M(b) = m_hi > d
-    long long m_hi = s_m[klo];
+    int m_hi = s_m[klo];
     int p_lo = klo == 0 ? -1 : sample_pos(klo - 1);                // M(p_lo) = m_lo <= d   (p_lo = -1: nothing below)
-    long long m_lo = klo == 0 ? 0 : s_m[klo - 1];
+    int m_lo = klo == 0 ? 0 : s_m[klo - 1];
     // secant steps: evaluate M at the interpolated point, keep the half that holds the answer
     for (int it = 0; it < 4 && b - p_lo > 1; ++it) {
         long long g = p_lo + 1 + (long long) ((double) (d - m_lo) * (double) (b - p_lo - 1) / (double) (m_hi - m_lo));
         const int p = (int) (g <= p_lo ? p_lo + 1 : g >= b ? b - 1 : g);
-        const long long mp = m_of(p);
+        const int mp = m_of(p);
         if (mp > d) { b = p; m_hi = mp; } else { p_lo = p; m_lo = mp; }
     }
     // short walk from both ends, then an exact binary search over what is left (nothing, on a smooth matrix)
@@ -387,8 +445,16 @@ __global__ __launch_bounds__(BLOCK) void coords_interp_kernel(const int *__restr
     for (int step = 0; step < 2 && a < b; ++step) { if (m_of(a) > d) b = a; else ++a; }
     for (int step = 0; step < 2 && a < b; ++step) { if (m_of(b - 1) > d) --b; else a = b; }
     while (a < b) { const int mid = (int) (((long long) a + b) >> 1); if (m_of(mid) > d) b = mid; else a = mid + 1; }
-    Coord c; c.x = b < rows ? b : rows; c.y = (int) (d - b);
-    coords[boundary] = c;
+    const int x = b < rows ? b : rows;
+    emit_boundary(out, boundary, x, d - b, x > 0 ? row_end[x - 1] : 0);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void coords_interp_kernel(const int *__restrict__ row_end, int rows, int nnz, int tile_items,
+                                                              int num_tiles, BoundaryOut out)
+{
+    __shared__ int s_m[INTERP_SAMPLES + 1];
+    coords_interp_block<BLOCK>(row_end, rows, nnz, tile_items, num_tiles, out, blockIdx.x, s_m);
 }
 
 // ---------------------------------------------------------------------------
@@ -658,27 +724,23 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 }
 
 // ---------------------------------------------------------------------------
-// Carries without a second launch (small problems: tile_kernel_fused).  The per-tile carries are LOCAL partial sums --
-// no tile needs another tile's result to compute its own -- so the fix-up "y[row] += carries of the tiles before the one in
-// which the row ends" can be done by that tile itself.  Every tile PUBLISHES its carry as soon as its scan is done.  A
-// tile with row ends knows exactly which earlier tiles hold pieces of its first row r = c0.x: the row's first nonzero is
-// path item r + row_offsets[r], i.e. it lies in tile (r + row_offsets[r]) / TILE, so the pieces are the carries of tiles
-// [that tile, this tile) -- one for rows shorter than a tile (an empty one when the row starts on the tile boundary), many
-// for a giant row.  The tile takes exactly those records (one lane each: up to 64 by wave 0 alone while the other waves run the row
-// phase, longer lists by the whole block), adds them to its first row in a fixed order and clears them.  There is no
-// chain of waits (a waiting tile waits for blocks that wait for nobody before publishing), blocks take tiles in block
-// order on this path, and workgroups are dispatched in order: an awaited block is running or done.  The reference's
-// fp64 fix-up relies on the same property (decoupled look-back, agent_segment_fixup.cuh:262-341 with
-// single_pass_scan_operators.cuh); unlike it, nothing here spins on a chain.
-// A record is two 64-bit words, each carrying half of a per-call tag beside its payload, written and read with
-// relaxed agent-scope atomics (visible across the XCDs' L2s without a cache flush): a word is valid when its tag
-// matches, so no ordering between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits,
-// and consumers clear what they read -- every record has exactly one consumer, so none outlives the call, which also
-// makes a captured call replayable with the same tags, even after the matrix changed.  Polling is bounded (~seconds); running out poisons the row with NaN instead of hanging.
+// Carries without a second launch (tile_kernel_snap, for the rows its boundary snapping leaves open).  The per-tile carries
+// are LOCAL partial sums -- no tile needs another tile's result to compute its own -- so the fix-up "y[row] += carries of
+// the tiles before the one in which the row ends" can be done by that tile itself.  A tile that leaves a row open PUBLISHES
+// its partial sum as soon as its scan is done.  The tile in which the row ENDS knows exactly which earlier tiles hold
+// pieces of it: the row's first nonzero is path item r + row_offsets[r], i.e. it lies in tile (r + row_offsets[r]) / TILE,
+// so the pieces are the carries of tiles [that tile, this tile).  It takes exactly those records (one lane each: up to 64 by
+// wave 0 alone while the other waves run the row phase, longer lists by the whole block), adds them to its first row in a
+// fixed order and clears them.  There is no chain of waits (a waiting tile waits for blocks that wait for nobody before
+// publishing), and workgroups are dispatched in order: an awaited block is running or done (mspmv_api.hip:
+// safe_chunk_log2 keeps that true under the XCD-chunked tile order).  The reference's fp64 fix-up relies on the same
+// property (decoupled look-back, agent_segment_fixup.cuh:262-341 with single_pass_scan_operators.cuh); unlike it,
+// nothing here spins on a chain.  Records: rec_store / rec_take above.
 // ---------------------------------------------------------------------------
 struct LookBack {
     unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
     unsigned tag_a, tag_b;        // tag_a is never 0 (a cleared word is never valid)
+    int *error;                   // error word of the call's temp storage: receives tag_a when a poll runs out
 };
 template <typename V> struct LbBits;
 template <> struct LbBits<float> {
@@ -695,24 +757,15 @@ template <typename V>
 __device__ __forceinline__ void lb_publish(const LookBack &lb, int tile, V value)
 {
     unsigned p0, p1; LbBits<V>::split(value, p0, p1);
-    __hip_atomic_store(&lb.rec[2 * (size_t) tile], ((unsigned long long) lb.tag_a << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&lb.rec[2 * (size_t) tile + 1], ((unsigned long long) lb.tag_b << 32) | p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rec_store(lb.rec + 2 * (size_t) tile, lb.tag_a, lb.tag_b, p0, p1);
 }
-constexpr int LB_MAX_POLLS = 1 << 21;       // x ~1 us: seconds; running out poisons the row with NaN instead of hanging
 // the carry tile s published: waits (bounded) until both words carry this call's tag, then clears the record
 template <typename V>
 __device__ __forceinline__ V lb_take(const LookBack &lb, int s)
 {
-    for (int polls = 0; polls < LB_MAX_POLLS; ++polls) {
-        const unsigned long long w0 = __hip_atomic_load(&lb.rec[2 * (size_t) s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long w1 = __hip_atomic_load(&lb.rec[2 * (size_t) s + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned) (w0 >> 32) == lb.tag_a && (unsigned) (w1 >> 32) == lb.tag_b) {
-            __hip_atomic_store(&lb.rec[2 * (size_t) s], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&lb.rec[2 * (size_t) s + 1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return LbBits<V>::join((unsigned) w0, (unsigned) w1);
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
+    unsigned p0, p1;
+    if (rec_take(lb.rec + 2 * (size_t) s, lb.tag_a, lb.tag_b, p0, p1)) return LbBits<V>::join(p0, p1);
+    if (lb.error) __hip_atomic_store(lb.error, (int) lb.tag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (this call's tag: temp storage is not initialised)
     return (V) __builtin_nan("");           // never seen in practice: loud, not a hang
 }
 // Sum of the carries of tiles [tile - count, tile) -- the pieces of this tile's first row held by earlier tiles --
@@ -731,11 +784,39 @@ __device__ __forceinline__ V lb_take_wave(const LookBack &lb, int tile, int coun
 // The same for a long list (a row spanning more than 64 tiles), by the whole block: thread j takes tiles tile-1-j,
 // tile-1-j-BLOCK, ... in that order; wave butterflies; the wave partials in wave order.  Block-uniform call (it has a
 // barrier); the result is valid on thread 0.
-template <typename V, int BLOCK>
+template <typename V, int BLOCK, int U>
 __device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int count, V *s_wave_val)
 {
+    // U records per thread and round are requested before any is looked at (a round costs one memory latency whatever its
+    // width: with U = 4 a row spanning 37 000 tiles is 37 rounds); one that is not there yet -- only ever among the nearest
+    // tiles -- is then polled for.  The order of the additions is fixed by (thread, round, slot).  (U is what the register
+    // budget of the calling kernel allows.)
     V part = 0;
-    for (int i = threadIdx.x; i < count; i += BLOCK) part += lb_take<V>(lb, tile - 1 - i);
+    for (int i0 = threadIdx.x; i0 < count; i0 += U * BLOCK) {
+        unsigned long long w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * BLOCK;
+            w0[u] = w1[u] = 0ull;
+            if (i < count) {
+                unsigned long long *r = lb.rec + 2 * (size_t) (tile - 1 - i);
+                w0[u] = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1[u] = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * BLOCK;
+            if (i < count) {
+                if ((unsigned) (w0[u] >> 32) == lb.tag_a && (unsigned) (w1[u] >> 32) == lb.tag_b) {
+                    unsigned long long *r = lb.rec + 2 * (size_t) (tile - 1 - i);
+                    __hip_atomic_store(r, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(r + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    part += LbBits<V>::join((unsigned) w0[u], (unsigned) w1[u]);
+                } else part += lb_take<V>(lb, tile - 1 - i);
+            }
+        }
+    }
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
     if ((threadIdx.x & (WAVE - 1)) == 0) s_wave_val[threadIdx.x / WAVE] = part;
@@ -845,13 +926,14 @@ __device__ __forceinline__ V block_exclusive_segsum(bool flag, V val, int *s_wav
     return lane == 0 ? pv : (ef ? ev : pv + ev);
 }
 
-template <typename V, int BLOCK, int IPT, bool AXPBY>
+template <typename V, int BLOCK, int IPT, bool AXPBY, int LB_BATCH = 1>
 __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coord c0, int tile_rows, int tile_nnz,
                                                    const end16_t *s_end, V *s_prod_raw, unsigned *s_flag,
                                                    int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
                                                    int pshift, unsigned long long *tr = nullptr, const LookBack *lb = nullptr,
-                                                   int tile = 0, int num_tiles = 0, int first_row_tile = 0, int tid_in = -1)
+                                                   int tile = 0, bool publish = false, int first_row_tile = 0, int tid_in = -1)
 {
+    constexpr int TAKE_BATCH = LB_BATCH;
     constexpr int CPT = IPT / 4 + 1;
     constexpr int NPT = CPT * 4;                  // staged products per thread
     constexpr int EPU = 16 / (int) sizeof(V);     // elements per 16-byte unit
@@ -890,7 +972,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
             Carry<V> c; c.key = c0.x; c.value = v;
             if (p.band_pass > 0) c.value += carry_out->value;      // later column-band pass: same tile, same key
             *carry_out = c;
-            if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, v);            // (nobody reads the last tile's carry)
+            if (lb && publish) lb_publish<V>(*lb, tile, v);                         // (only when some tile will take it)
         }
         return;
     }
@@ -908,14 +990,14 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
         if (p.band_pass > 0) c.value += carry_out->value;
         *carry_out = c;
-        if (lb && tile + 1 < num_tiles) lb_publish<V>(*lb, tile, c.value);
+        if (lb && publish) lb_publish<V>(*lb, tile, c.value);
     }
     // single-launch path: the pieces of this tile's first row held by tiles [first_row_tile, tile) (thread 0 stores row 0).
     // Up to 64 of them: wave 0 alone, while the other waves go on with the row phase; more: the whole block.
     V first_row_carry = 0;
     if (lb) {
         const int pieces = tile - first_row_tile;            // block-uniform
-        if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK>(*lb, tile, pieces, s_wave_val);
+        if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, tile, pieces, s_wave_val);
         else if (pieces > 0 && tid < WAVE) first_row_carry = lb_take_wave<V>(*lb, tile, pieces);
     }
 
@@ -1405,7 +1487,7 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
             const int pshift = c0.y - (c0.y & ~3);
             const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
             consume_tile_flags<V, BLOCK, IPT, true>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                                    s_wave_key, s_wave_val, carries + tile, pshift, nullptr, nullptr, 0, 0, 0, t);
+                                                    s_wave_key, s_wave_val, carries + tile, pshift, nullptr, nullptr, 0, false, 0, t);
             if (tid == 0) {
                 s_next = following;
                 if (b == 0) __hip_atomic_store(ba.next + tile, following, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1729,72 +1811,195 @@ __global__ __launch_bounds__(BLOCK) void fixup_onepass_kernel(const Carry<V> *__
 }
 
 // ---------------------------------------------------------------------------
-// Small problems (at most one resident wave of tiles, <= 2048): every block finds
-// its own two tile coordinates -- wave 0 searches the tile's start diagonal and
-// wave 1 its end diagonal, concurrently, with the 64-ary wave search -- so the
-// coordinate pass (a launch and 6-9 us) disappears.  Measured: -5 % on a 3 M-nnz R-MAT
-// matrix; +10-35 % (worse) from 11 000 tiles up, hence the threshold.
-// Tried and removed: applying the carries in the same launch (last block to take
-// a ticket runs the fix-up after an agent-scope release/acquire, CDNA guide G16):
-// ~1800 release fences + ticket atomics on one word cost ~80 us, against ~10 us
-// for the separate fix-up launch.
+// ONE launch for problems of any size: tile_kernel_snap (the default of every call that the vectorised staging can serve,
+// and that is not a candidate for the column-band passes).  No coordinate launch,
+// no fix-up launch, no dependency between workgroups except for rows longer than HEAD_MAX.
+//  * COORDINATES ARE HINTS, VERIFIED.  The point (x, y) of a tile boundary is characterised by two row offsets:
+//    row_offsets[x] <= y <= row_offsets[x + 1].  A tile therefore takes whatever the caller's temp storage holds for its
+//    two boundaries -- left there by an earlier call on the same matrix, by mspmv_csrmv_prepare, or garbage --, starts
+//    streaming on that assumption, and checks the four row offsets that decide it (requested first, so they are back
+//    before the nonzeros).  Right (every call but the first on a given temp buffer): the tile has paid what a stored
+//    coordinate costs, one cached load, and the call has no coordinate pass at all.  Wrong: waves 0 and 1 search the two
+//    boundaries (wave_merge_path_guess: one window of row offsets around the arithmetic guess on a regular matrix, the
+//    64-ary sampled search on any other), the tile is staged again, and the corrected hints are stored for the next call.
+//    Nothing depends on the hints being right, so the call stays stateless in the reference's sense (temp storage is
+//    scratch); what a second call on the same buffer saves is the search, 8-19 us per call as a launch of its own.
+//  * ROW-SNAPPED TILES: no carries, every y[r] written exactly once.  A merge-path boundary falls inside some row x,
+//    `head` nonzeros after the row's first one.  When head <= HEAD_MAX the boundary is moved back to the row's first
+//    nonzero: the tile BEFORE it stops at the end of its last complete row and the tile AFTER it also multiplies those
+//    <= HEAD_MAX nonzeros -- both sides decide from the same two numbers, so they agree.  Tiles stay merge-path tiles
+//    (their work differs by at most HEAD_MAX items, 5-10 % of a tile; LDS has that much room in every compiled shape), but
+//    a matrix of short rows -- every grid, band, dense-block or FEM matrix -- has no row left open at any tile end:
+//    nothing to publish, nothing to wait for, nothing to fix up.
+//  * Long rows (head > HEAD_MAX): the tiles holding a piece of the row publish their partial sums
+//    as tagged records and the tile in which the row ENDS takes exactly those (up to 64 by wave 0 alone, longer lists by
+//    the whole block, 8 records per thread and round), adds them in a fixed order and clears them.  A publisher never
+//    waits before it publishes, so there are no chains; a waiting tile needs lower-numbered TILES to have been dispatched,
+//    which the block -> tile mapping guarantees as long as one of its XCD runs fits the resident blocks twice over
+//    (mspmv_api.hip: safe_chunk_log2).  Deterministic and bitwise reproducible: the result does not depend on whether
+//    the hints were right.
 // ---------------------------------------------------------------------------
+// Merge-path point of a diagonal WITHOUT a coordinate pass and, on a regular matrix, at the price of the one memory round
+// trip that loading a stored coordinate costs: the row is guessed arithmetically -- x ~ diagonal * rows / (rows + nnz),
+// exact when every row has the same length -- and the wave looks at the 64 rows around the guess (two cache lines of
+// row_offsets, which the tile is about to read anyway).  M(p) = row_end[p] + p + 1 is strictly increasing and the point
+// is the first p with M(p) > diagonal, so the window holds the answer iff its first row fails the test (or the window
+// starts at row 0) and some row passes it.  Otherwise the window's own slope gives a second guess (a matrix whose row
+// lengths vary smoothly: grids, bands, FEM meshes), and if that window misses as well the 64-ary search over fixed
+// samples runs (wave_merge_path_search_interp: any matrix, 3-4 dependent loads).  Exact; all lanes return the same
+// point; row_start = row_offsets[x], the first nonzero of the row the point falls in.
+__device__ __forceinline__ Coord wave_merge_path_guess(int diagonal, const int *__restrict__ row_end, int rows, int nnz, int &row_start)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int inf = rows + nnz + 1;                                  // < 2^31
+    long long g = (long long) diagonal * rows / ((long long) rows + nnz);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int w0 = (int) g - WAVE / 2;
+        const int w_max = rows - (WAVE - 1) > 0 ? rows - (WAVE - 1) : 0;
+        w0 = w0 < 0 ? 0 : w0 > w_max ? w_max : w0;
+        const int p = w0 + lane;
+        const int e = p < rows ? row_end[p] : 0;
+        const int m = p < rows ? e + p + 1 : inf;                    // (p == rows: M = +inf)
+        const unsigned long long mask = __ballot(m > diagonal);
+        const bool first_fails = !(mask & 1ull);
+        if (mask != 0ull && (first_fails || w0 == 0)) {
+            const int f = __ffsll((long long) mask) - 1;
+            const int x = w0 + f;                                    // <= rows
+            // row_offsets[x] = row_end[x - 1]: in the window unless x == w0 (then w0 == 0: row 0 starts at 0)
+            row_start = f > 0 ? __shfl(e, f - 1, WAVE) : 0;
+            Coord c; c.x = x < rows ? x : rows; c.y = diagonal - c.x;
+            if (x >= rows) row_start = nnz;
+            return c;
+        }
+        if (mask == 0ull && w0 + WAVE >= rows) break;                // (cannot happen: lane of p == rows always passes) -- fall back
+        // second guess from the window's slope
+        const int m_a = __shfl(m, 0, WAVE), m_b = __shfl(m, WAVE - 1, WAVE);
+        if (m_b >= inf || m_b <= m_a) break;
+        g = w0 + (long long) ((double) (diagonal - m_a) * (double) (WAVE - 1) / (double) (m_b - m_a));
+        if (g < 0) g = 0; if (g > rows) g = rows;
+    }
+    const Coord c = wave_merge_path_search_interp(diagonal, row_end, rows, nnz);
+    row_start = c.x >= rows ? nnz : c.x > 0 ? row_end[c.x - 1] : 0;
+    return c;
+}
+
+template <int BLOCK, int IPT>
+constexpr int snap_head_max()
+{
+    constexpr int slack = (IPT / 4 + 1) * BLOCK * 4 - BLOCK * IPT - 16;
+    return slack < 192 ? slack : 192;
+}
+
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, AXPBY>())) void tile_kernel_fused(Params<V> p, Coord *__restrict__ coords,
-                                                           Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2,
-                                                           LookBack lb)
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Params<V> p, Coord *__restrict__ coords,
+                                                           int *__restrict__ rstart, Carry<V> *__restrict__ carries, int num_tiles,
+                                                           int xcd_chunk_log2, LookBack lb)
 {
     constexpr int TILE = BLOCK * IPT;
     constexpr int NW = BLOCK / WAVE;
     constexpr int CPT = IPT / 4 + 1;
     constexpr int SLOTS = CPT * BLOCK * 4;
-    static_assert(BLOCK >= 2 * WAVE, "two waves search");
+    constexpr int HEAD_MAX = snap_head_max<BLOCK, IPT>();
+    static_assert(HEAD_MAX >= 64 && TILE + HEAD_MAX + 16 <= SLOTS, "room for the snapped rows");
     __shared__ __attribute__((aligned(16))) end16_t s_end_raw[SLOTS];
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
-    __shared__ Coord s_coord[2];
-
+    __shared__ int s_bnd[6];
+    __shared__ int s_ok;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
+
     const int tid = threadIdx.x;
     const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     const V *const s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
-    const long long total = (long long) p.rows + p.nnz;
-    {
-        const int wave = tid / WAVE;
-        if (wave < 2) {
-            const long long d = (long long) (tile + wave) * TILE;
-            const Coord c = wave_merge_path_search_interp((int) (d < total ? d : total), p.row_end, p.rows, p.nnz);
-            if ((tid & (WAVE - 1)) == 0) s_coord[wave] = c;
-        }
+    const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
+    if (tid < 2) {
+        Coord h = coords[tile + tid]; int rs = rstart[tile + tid];                                       // the hints
+        if (single) { h.x = tid ? p.rows : 0; h.y = tid ? p.nnz : 0; rs = h.y; }
+        s_bnd[3 * tid] = h.x; s_bnd[3 * tid + 1] = rs; s_bnd[3 * tid + 2] = h.y;
     }
     __syncthreads();
-    const Coord c0 = s_coord[0], c1 = s_coord[1];
-    if (tid == 0) {                                  // keep the coordinates inspectable (mspmv_debug_read_tiles)
-        coords[tile] = c0;
-        if (tile == num_tiles - 1) coords[num_tiles] = c1;
-    }
+    const int total = p.rows + p.nnz;                               // < 2^31
+    const long long d0l = (long long) tile * TILE, d1l = d0l + TILE;
+    const int d0 = (int) (d0l < total ? d0l : total), d1 = (int) (d1l < total ? d1l : total);
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
-    TileRegs<V, BLOCK, IPT> regs;
-    issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
-    stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+    int x0 = s_bnd[0], rs0 = s_bnd[1], x1 = s_bnd[3], rs1 = s_bnd[4];
+    const int hint_y0 = s_bnd[2], hint_y1 = s_bnd[5];
+    int y0 = d0 - x0, y1 = d1 - x1;
+    bool snap0 = y0 - rs0 <= HEAD_MAX, snap1 = y1 - rs1 <= HEAD_MAX;
+    Coord c0, c1;
+    c0.x = x0; c0.y = snap0 ? rs0 : y0;
+    c1.x = x1; c1.y = snap1 ? rs1 : y1;
+    // hints: anything may be in there.  Only values that keep every speculative access inside the arrays and the LDS tile
+    // are tried at all (block-uniform)
+    bool good = x0 >= 0 && x0 <= x1 && x1 <= p.rows && y0 >= 0 && y1 >= y0 && y1 <= p.nnz && rs0 >= 0 && rs0 <= y0 &&
+                rs1 >= rs0 && rs1 <= y1 && c1.y >= c0.y;
+    if (good) {
+        // the four row offsets that decide whether (x0, rs0) and (x1, rs1) are the points of diagonals d0 and d1: requested
+        // BEFORE the tile's streams, so they are back first
+        int vre = 0;
+        if (tid < 4) {
+            int idx = (tid < 2 ? x0 : x1) - 1 + (tid & 1);          // x0 - 1, x0, x1 - 1, x1
+            idx = idx < 0 ? 0 : idx >= p.rows ? p.rows - 1 : idx;   // (rows >= 3 on this path)
+            vre = p.row_end[idx];
+        }
+        TileRegs<V, BLOCK, IPT> regs;
+        issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
+        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+        // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
+        // memory latency; a barrier is cheap)
+        if (tid < WAVE) {
+            const int before0 = __shfl(vre, 0, WAVE), at0 = __shfl(vre, 1, WAVE), before1 = __shfl(vre, 2, WAVE), at1 = __shfl(vre, 3, WAVE);
+            // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
+            const bool ok0 = (x0 > 0 ? before0 == rs0 : rs0 == 0) && (x0 < p.rows ? y0 <= at0 : d0 == total);
+            const bool ok1 = (x1 > 0 ? before1 == rs1 : rs1 == 0) && (x1 < p.rows ? y1 <= at1 : d1 == total);
+            if (tid == 0) s_ok = (single || (ok0 && ok1)) ? 1 : 0;
+        }
+        __syncthreads();
+        good = s_ok != 0;
+        if (!good && tid < SLOTS / 32 + 1) s_flag[tid] = 0u;       // (the staging above touched nothing but LDS)
+    }
+    if (!good) {
+        // no usable hints (the first call on this temp storage, or another matrix since): find the two boundaries, stage (again)
+        __syncthreads();
+        const int wave = tid / WAVE;
+        if (wave < 2) {
+            int rs = 0;
+            const Coord c = wave_merge_path_guess(wave == 0 ? d0 : d1, p.row_end, p.rows, p.nnz, rs);
+            if ((tid & (WAVE - 1)) == 0) { s_bnd[3 * wave] = c.x; s_bnd[3 * wave + 1] = rs; }
+        }
+        __syncthreads();
+        x0 = s_bnd[0]; rs0 = s_bnd[1]; x1 = s_bnd[3]; rs1 = s_bnd[4];
+        y0 = d0 - x0; y1 = d1 - x1;
+        snap0 = y0 - rs0 <= HEAD_MAX; snap1 = y1 - rs1 <= HEAD_MAX;
+        c0.x = x0; c0.y = snap0 ? rs0 : y0;
+        c1.x = x1; c1.y = snap1 ? rs1 : y1;
+        TileRegs<V, BLOCK, IPT> regs;
+        issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
+        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+    }
+    if (tid == 0) {
+        // the hints of the next call on this temp storage (and what mspmv_debug_read_tiles returns): stored when they were not there
+        if (!good || single || hint_y0 != y0) { Coord h; h.x = x0; h.y = y0; coords[tile] = h; rstart[tile] = rs0; }
+        if (tile == num_tiles - 1 && (!good || single || hint_y1 != y1)) { Coord h; h.x = x1; h.y = y1; coords[num_tiles] = h; rstart[num_tiles] = rs1; }
+    }
+    // the tiles that hold published pieces of this tile's first row (only when the row ends here and began > HEAD_MAX
+    // nonzeros before the tile): from the tile of its first nonzero (path item x0 + rs0) -- or the one after, if that one
+    // handed its short piece on by the rule above -- up to this tile
+    int first_piece = tile;
+    if (!snap0 && x1 > x0) {
+        const long long item = (long long) x0 + rs0;
+        const int ft = (int) (item / TILE);
+        const long long tail_ft = (long long) (ft + 1) * TILE - item;
+        first_piece = ft + (tail_ft <= HEAD_MAX ? 1 : 0);
+    }
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
-    // the tile holding the first nonzero of this tile's first row r = c0.x: path item r + row_offsets[r].  When the row
-    // starts exactly on a tile boundary the tile before that boundary holds an EMPTY piece of it (carry 0): it is taken
-    // too, so that every published record has exactly one consumer and none outlives the call.
-    int first_row_tile = tile;
-    if (lb.rec && c1.x > c0.x) {
-        const long long d_start = (long long) c0.x + (c0.x > 0 ? p.row_end[c0.x - 1] : 0);
-        first_row_tile = (int) (d_start / TILE);
-        if (d_start % TILE == 0 && first_row_tile > 0) --first_row_tile;
-    }
-    consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                             s_wave_key, s_wave_val, carries + tile, pshift, nullptr, lb.rec ? &lb : nullptr, tile, num_tiles,
-                                             first_row_tile < tile ? first_row_tile : tile);
+    consume_tile_flags<V, BLOCK, IPT, AXPBY, 4>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
+                                                s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lb, tile, !snap1, first_piece);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

@@ -198,3 +198,30 @@ def rmat_csr(scale: int, edges: int, dtype=torch.float64, device="cuda", seed: i
     csr = DeviceCsr(row_hi - row_lo, n, offsets.to(torch.int32) if offsets[-1] < 2**31 else offsets,
                     c.to(torch.int32), vals)
     return (csr, e) if return_edge_ids else csr
+
+
+# BASELINE config 3 names two SuiteSparse matrices that cannot be fetched offline; these are their sizes
+# (ufl_matrices.txt:2379 webbase-1M; SNAP com-Orkut: 117 185 083 stored entries of a symmetric pattern matrix)
+C3_WEBBASE_SCALE, C3_WEBBASE_EDGES = 20, 3_105_536
+C3_ORKUT_SCALE, C3_ORKUT_EDGES = 22, 117_185_083
+
+
+def rmat_symmetric_csr(scale: int, edges: int, dtype=torch.float64, device="cuda", seed: int = SEED_C3) -> DeviceCsr:
+    """The com-Orkut-sized stand-in of config 3: `edges` R-MAT entries read as the stored half of a SYMMETRIC matrix,
+    i.e. mirrored the way InitMarket mirrors a `symmetric` Matrix Market file (sparse_matrix.h:362-368: (c, r) is added
+    for every stored (r, c) with r != c).  CSR sorted by (row, col), duplicates kept; the value of a stored entry e is
+    uniform [-1, 1) from stream seed + 1 counter e, and its mirror image carries the same value."""
+    n = 1 << scale
+    r, c = rmat_edges(scale, 0, edges, device, seed)
+    e = torch.arange(edges, dtype=torch.int64, device=device)
+    off_diag = r != c
+    rr = torch.cat([r, c[off_diag]]); cc = torch.cat([c, r[off_diag]]); ee = torch.cat([e, e[off_diag]])
+    del r, c, e, off_diag
+    order = torch.sort(rr * n + cc, stable=True).indices
+    cols = cc[order].to(torch.int32); ee = ee[order]
+    lens = torch.bincount(rr, minlength=n)
+    del rr, cc, order
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=offsets[1:])
+    vals = (uniform01(seed + 1, ee) * 2.0 - 1.0).to(dtype)
+    return DeviceCsr(n, n, offsets.to(torch.int32), cols, vals)

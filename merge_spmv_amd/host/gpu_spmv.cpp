@@ -8,7 +8,7 @@
 // HybMV, where the reference ran cuSPARSE (gpu_spmv.cu:106-364,565-578).
 //
 //   gpu_spmv [--device=<id>] [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32]
-//            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor]
+//            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor] [--no-hyb]
 //            [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] [--mg-exchange=peer|rccl]
 //            [--band-passes=<n>]
 //            --mtx=<file> | --dense=<cols> [--size=<nnz>] | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
@@ -335,7 +335,7 @@ float TestRocsparseHybmv(const RunConfig &c, const CsrMatrix<V> &a, const std::v
     return ms;
 }
 
-struct Extras { bool vendor = true, prepared = false, plan = false, mg_one_device = false; int plan_bands = 0, mg_exchange = MSPMV_MG_EXCHANGE_AUTO; std::vector<int> gpus; };
+struct Extras { bool vendor = true, hyb = true, prepared = false, plan = false, mg_one_device = false; int plan_bands = 0, mg_exchange = MSPMV_MG_EXCHANGE_AUTO; std::vector<int> gpus; };
 
 template <typename V>
 void Run(const RunConfig &c, const Device &dev, const Extras &ex)
@@ -398,9 +398,11 @@ void Run(const RunConfig &c, const Device &dev, const Extras &ex)
         avg_ms = TestRocsparseCsrmv(c, csr, x, y_in, gold, p, iterations, setup_ms, handle);
         DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
         if (!c.quiet) printf("\n\n");
-        printf("rocSPARSE HybMV, "); fflush(stdout);
-        avg_ms = TestRocsparseHybmv(c, csr, x, y_in, gold, p, iterations, setup_ms, handle);
-        DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+        if (ex.hyb) {
+            printf("rocSPARSE HybMV, "); fflush(stdout);
+            avg_ms = TestRocsparseHybmv(c, csr, x, y_in, gold, p, iterations, setup_ms, handle);
+            DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+        }
         ROCSPARSE_OK(rocsparse_destroy_handle(handle));
     }
 }
@@ -414,7 +416,7 @@ int main(int argc, char **argv)
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
-               "[--no-strict] [--no-vendor] [--cache] [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
+               "[--no-strict] [--no-vendor] [--no-hyb] [--cache] [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
                "[--mg-exchange=peer|rccl] [--band-passes=<n>]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
@@ -424,6 +426,7 @@ int main(int argc, char **argv)
     const Device dev = DeviceInit(c);
     Extras ex;
     ex.vendor = !args.CheckCmdLineFlag("no-vendor");
+    ex.hyb = !args.CheckCmdLineFlag("no-hyb");          // (the CSR -> HYB conversion takes seconds on some small matrices)
     ex.prepared = args.CheckCmdLineFlag("prepared");
     ex.plan = args.CheckCmdLineFlag("plan");
     args.GetCmdLineArgument("plan", ex.plan_bands);

@@ -66,24 +66,39 @@ def test_tuning_rejects_unknown_shapes():
     M.set_tuning(4)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
     # default shapes: one tile when the problem fits one; the smallest tile that keeps a small problem within 896 tiles,
-    # else the largest if that keeps it within 1280 (both: ONE launch, the tiles add the carries themselves);
-    # beyond: the three-pass pipeline with 256x11 (fp64 up to 24 M path items: 256x7)
+    # else the largest if that keeps it within 1280; beyond: 256x11 (fp64 up to 24 M path items: 256x7).  Always ONE launch
+    # of row-snapped tiles (tile_kernel_snap, no fix-up) unless MSPMV_TUNE_TWO_LAUNCH asks for the classic three
     assert M.launch_info(300_000, 1_000_000, 4)["items_per_thread"] == 7         # 1.3M items / 1792 = 726 tiles
     assert M.launch_info(1_000_000, 3_500_000, 4)["items_per_thread"] == 15      # 4.5M items / 3840 = 1172 tiles
-    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 0           # no fix-up launch
+    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 0 and M.launch_info(1_000_000, 3_500_000, 4)["snap_head_max"] == 192
     M.set_tuning(4, 0, 0, 0x40000000)                                            # ... unless asked for: one launch of the one-pass kernel
     assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 1
     M.set_tuning(4, 0, 0, 128)                                                   # the chunked multi-level variant
     assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2           # 1172 carries / 512 per block -> 2 launches
     M.set_tuning(4)
-    assert M.launch_info(1_000_000, 5_000_000, 4)["items_per_thread"] == 11      # 6M items: 1563 tiles even at 256x15 -> three passes
-    assert M.launch_info(1_000_000, 5_000_000, 4)["fixup_levels"] == 1
+    assert M.launch_info(1_000_000, 5_000_000, 4)["items_per_thread"] == 11      # 6M items: 1563 tiles even at 256x15 -> the large-problem shape
+    assert M.launch_info(1_000_000, 5_000_000, 4)["fixup_levels"] == 0 and M.launch_info(1_000_000, 5_000_000, 4)["snap_head_max"] == 192
+    M.set_tuning(4, 0, 0, 0x40000000)
+    assert M.launch_info(1_000_000, 5_000_000, 4)["fixup_levels"] == 1 and M.launch_info(1_000_000, 5_000_000, 4)["snap_head_max"] == 0
+    M.set_tuning(4)
+    # the override is per host thread: another thread sees the defaults
+    import threading
+    M.set_tuning(4, 256, 9)
+    seen = {}
+    th = threading.Thread(target=lambda: seen.update(ipt=M.launch_info(10, 10, 4)["items_per_thread"]))
+    th.start(); th.join()
+    assert seen["ipt"] == 7 and M.launch_info(10, 10, 4)["items_per_thread"] == 9
+    M.set_tuning(4)
     assert M.launch_info(1_000_000, 5_000_000, 8)["items_per_thread"] == 7       # fp64 mid-size: 256x7
     assert M.launch_info(4_000_000, 30_000_000, 8)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 4)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 11
     with pytest.raises(M.MspmvError):
         M.set_tuning(4, 250, 7)
+    # the shapes of the tuning sweeps exist only in the development build
+    for vb, b, i in ((4, 128, 7), (4, 512, 7), (4, 256, 5), (8, 128, 5), (8, 512, 5), (8, 256, 3)):
+        with pytest.raises(M.MspmvError):
+            M.set_tuning(vb, b, i)
     # the product library has no timing-experiment kernels: their flag bits (persistent grid, staging-only
     # ablation that returns wrong y, cycle stamps, XCD remap; include/mspmv_dev.h) are rejected
     for dev_bits in (1, 0x100, 0x10000, 0x60000, 0x70000, 0x100000):

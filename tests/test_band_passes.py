@@ -403,13 +403,20 @@ def test_detector_refuses_matrices_with_reuse(kind):
         M.csrmv(val, off, col, x, y=y, num_cols=cols, workspace=ws)
         torch.cuda.synchronize()
         assert int(M.debug_band_windows(ws, rows, nnz, 4).sum()) == 0
+        # with the passes switched off the call is no longer a candidate and runs ONE launch of row-snapped tiles; the
+        # refused candidate ran the classic tiles + fix-up: the same sums as the classic pipeline forced by hand, bit for bit
         M.set_band_passes(4, -1)
+        M.set_tuning(4, 0, 0, 0x40000000)
         yn = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
         M.csrmv(val, off, col, x, y=yn, num_cols=cols, workspace=ws)
         assert torch.equal(y, yn)
         assert _strict_on_device(val, off, col, x, y, 0)
+        M.set_tuning(4)
+        ys = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
+        M.csrmv(val, off, col, x, y=ys, num_cols=cols, workspace=ws)
+        assert _strict_on_device(val, off, col, x, ys, 0)
     finally:
-        M.set_band_passes(4, 0)
+        M.set_band_passes(4, 0); M.set_tuning(4)
 
 
 @gpu

@@ -278,8 +278,9 @@ def test_bench_multi_rank_path_on_one_device():
     reduced scale: (a) 2 ranks sharing the device, carries over gloo through the Python twin; (b) ONE rank forced through
     the N > 1 code path: nccl process group, shipped RCCL id, the C operator's multi-process form with its
     ncclAllGather inside the timed loop, the same-job single-GPU leg."""
-    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000")
+    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000", "--single-gpu-leg")
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo"}, 2, *small)
+    assert out["per_rank"]["tile_ms_max"] >= out["per_rank"]["tile_ms_min"] > 0 and out["per_rank"]["nnz_per_rank_max"] > 0
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f64" and out["value"] > 0
     assert "C5 R-MAT scale 18" in out["config"]["workload"] and "merge-path diagonal split over 2 GPUs" in out["config"]["partition"]
     assert out["single_gpu_same_workload"]["n_gpus"] == 1 and out["single_gpu_same_workload"]["value"] > 0

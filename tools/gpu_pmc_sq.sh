@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/sq_$TAG
 RAW=/tmp/sq_raw_$TAG
 rm -rf $OUT $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline $BARGS"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs $BARGS"
 i=0
 PMCS=${PMCS:-full}
 if [ "$PMCS" = "lds" ]; then

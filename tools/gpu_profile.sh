@@ -11,7 +11,7 @@ rm -rf $OUT $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
 # PROFILE_CMD overrides the profiled command (e.g. tools/plan_bench.py for the prepared plan); the default is the
 # headline bench without its prepared_plan leg (that leg launches the same kernel symbol on another matrix)
-BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-plan $*"}
+BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-plan --no-configs $*"}
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o bench -- $BENCH > $OUT/bench_trace.log 2>&1
 tail -2 $OUT/bench_trace.log
 for f in $(find $RAW/trace -name "*stats*.csv"); do cp $f $OUT/; done

@@ -10,8 +10,8 @@ import torch
 import merge_spmv_amd as M
 from merge_spmv_amd import generators as G
 
-SHAPES = {4: [(256, 7), (256, 5), (256, 9), (256, 11), (128, 7), (512, 7), (256, 15)],
-          8: [(256, 5), (256, 3), (256, 7), (256, 9), (128, 5), (512, 5), (256, 11)]}
+SHAPES = {4: [(256, 7), (256, 9), (256, 11), (256, 15)],             # product shapes; the dev build (MSPMV_LIB=libmspmv_dev.so) adds 256x5 / 128x7 / 512x7
+          8: [(256, 5), (256, 7), (256, 9), (256, 11)]}
 
 
 def workloads(names):
