@@ -218,6 +218,9 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
                 rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
             # cheap sanity on the result: finite, and the row sums of |y| are not all zero (parity proper is tests/ -m gpu)
             rec["y_finite"] = bool(torch.isfinite(y).all().item())
+            if name.startswith("C5") or "Orkut" in name:
+                # scale-free graphs with an x beyond the caches: the opt-in hot-column plan on the same matrix
+                rec["hot_column_plan"] = M.hotcols_bench_record(A, x, y, steps=k, warmup=2, peak_gbs=HBM_PEAK_GBS)
             out.append(rec)
             del A, x, ws, y
         except Exception as e:                   # e.g. out of memory on a smaller part: report, keep the headline

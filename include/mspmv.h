@@ -163,6 +163,39 @@ int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_
                                int32_t rows, int32_t cols, int32_t nnz, int32_t bands,
                                double alpha, double beta, mspmv_stream_t stream, int debug_sync);
 
+/* ---- extension: HOT-COLUMN PLAN for a matrix whose x is far larger than the caches and whose columns are referenced
+ * very unevenly (scale-free graphs: BASELINE config 5; opt-in, the stateless calls never use it).  Such a CsrMV runs at
+ * the DRAM random-line rate -- 57 G gathers/s on MI355X, 0.09 of the HBM roofline -- because the few hot columns that
+ * take most of the references are scattered over all of x, each sharing its cache line with cold ones.
+ * mspmv_csrmv_hotcols_build renumbers the columns ONCE in order of reference count (by class: floor(log2(count + 1)),
+ * hottest first -- a histogram and one ranking pass, no sort) into the caller's storage: the renumbered column indices
+ * (4 * nnz bytes; values and row offsets are used from the caller's arrays, not copied), the permutation, x in the new
+ * numbering and the inner call's temp storage.  mspmv_csrmv_hotcols_apply_* then permutes x (one pass over cols entries)
+ * and runs the ordinary stateless CsrMV on the renumbered indices:
+ *     y = alpha * A * x + beta * y        (beta == 0: y is never read).
+ * A column permutation only changes where x is read -- every row still sums the same products in the same order -- so y
+ * is BIT FOR BIT the result of mspmv_csrmv_* / _axpby_*.  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
+ * the band-major plan below (caller-owned storage of mspmv_csrmv_hotcols_size bytes, the same rows / cols / nnz /
+ * value_bytes to every call, asynchronous on `stream`); d_values / d_row_offsets passed to _apply must be the arrays
+ * the plan was built for.  No reference counterpart (its HYB column is the precedent for set-up timed apart,
+ * gpu_spmv.cu:106-257). ---- */
+int mspmv_csrmv_hotcols_size(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, size_t *plan_bytes);
+int mspmv_csrmv_hotcols_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets,
+                              const int32_t *d_column_indices, int32_t rows, int32_t cols, int32_t nnz,
+                              int32_t value_bytes, mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_hotcols_apply_f32(void *d_plan, size_t plan_bytes, const float *d_values,
+                                  const int32_t *d_row_offsets, const float *d_x, float *d_y,
+                                  int32_t rows, int32_t cols, int32_t nnz, float alpha, float beta,
+                                  mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_hotcols_apply_f64(void *d_plan, size_t plan_bytes, const double *d_values,
+                                  const int32_t *d_row_offsets, const double *d_x, double *d_y,
+                                  int32_t rows, int32_t cols, int32_t nnz, double alpha, double beta,
+                                  mspmv_stream_t stream, int debug_sync);
+/* the plan's pieces (device pointers into d_plan): order[k] = the original column that became column k (cols entries),
+ * and the renumbered column indices (nnz entries) */
+const int32_t *mspmv_csrmv_hotcols_order(const void *d_plan, int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes);
+const int32_t *mspmv_csrmv_hotcols_columns(const void *d_plan, int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes);
+
 /* ---- introspection (the counterpart of the reference's debug_synchronous
  * launch log, dispatch_spmv_orig.cuh:685-739, as data) ---- */
 typedef struct mspmv_launch_info {

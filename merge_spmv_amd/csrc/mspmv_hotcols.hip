@@ -1,0 +1,254 @@
+// mspmv_hotcols.hip -- the opt-in HOT-COLUMN PLAN of include/mspmv.h (mspmv_csrmv_hotcols_*): the columns renumbered,
+// once, in order of how often the matrix references them, for matrices whose x is far larger than the caches.
+//
+// Why.  BASELINE config 5 (R-MAT scale 26: x = 512 MB, 2 * 10^9 references) runs at the DRAM random-line rate: 57 G
+// gathers/s, 0.09 of the HBM roofline, whatever the kernel does (profiles/r02_hw_ceilings.txt: 54.6 G/s over tables
+// >= 128 MiB).  But a scale-free matrix references its columns very unevenly -- at scale 26 the 524 288 most referenced
+// columns (4 MB of x) take 62 % of the references and the 4 M most referenced (34 MB) 90 % -- and in the matrix as given
+// those hot columns are scattered over all of x, each sharing its 128-byte line with cold ones (R-MAT: the 314 000
+// columns with at most six set bits occupy 110 000 lines = 14 MB; packed they are 2.5 MB).  Renumbered by reference
+// count, the hot columns are contiguous: the hottest few MB stay in every XCD's L2, the next few hundred in the
+// Infinity Cache, and config 5 runs in 20.6 ms instead of 34.2 (tools/hot_columns.py, profiles/r03_hot_columns.txt).
+//
+// What.  A column permutation only changes WHERE x is read: the CSR arrays keep their order, so every row sums the same
+// products in the same order and y is bit for bit the stateless call's.  The plan holds
+//   new_cols[nnz]   the renumbered column indices (the caller's values and row offsets are used as they are: no copy),
+//   order[cols]     order[k] = the original column that became column k,
+//   xp[cols]        x in the new numbering, refreshed by one gather pass per SpMV (0.7 ms for config 5's 67 M columns:
+//                   what a caller pays for keeping x in the original order),
+// and the temp storage of the inner stateless call.  Hotness is by CLASS -- floor(log2(count + 1)), 32 classes,
+// hottest first; inside a class the original order is kept block-wise -- which needs no sort: a histogram of the
+// columns (one atomic per nonzero), a 32-entry scan, one ranking pass.  The reference's driver does the same kind of
+// thing for its HYB column: conversion timed once as set-up, SpMV timed separately (gpu_spmv.cu:106-257).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mspmv.h"
+#include "mspmv_internal.hpp"
+
+namespace {
+
+using namespace mspmv;
+
+constexpr int CLASSES = 33;                 // floor(log2(count + 1)) of a count < 2^32: 0 .. 32
+constexpr int HC_BLOCK = 256;
+
+struct HotLayout {
+    uint64_t cols_off, order_off, xp_off, counts_off, class_off, temp_off, total;
+    uint64_t temp_bytes;
+};
+
+bool make_layout(int rows, int cols, int nnz, int value_bytes, HotLayout &L)
+{
+    memset(&L, 0, sizeof(L));
+    if ((long long) rows + nnz > MAX_ITEMS) return false;
+    uint64_t off = 0;
+    L.cols_off = off; off = align256(off + uint64_t(std::max(nnz, 1)) * 4);
+    L.order_off = off; off = align256(off + uint64_t(std::max(cols, 1)) * 4);
+    L.xp_off = off; off = align256(off + uint64_t(std::max(cols, 1)) * value_bytes);
+    L.counts_off = off; off = align256(off + uint64_t(std::max(cols, 1)) * 4);          // reference counts, then the ranks
+    L.class_off = off; off = align256(off + uint64_t(3 * CLASSES) * 4);                 // class sizes, bases, cursors
+    L.temp_bytes = csrmv_temp_bytes(rows, nnz, value_bytes);
+    L.temp_off = off; off = align256(off + L.temp_bytes);
+    L.total = off;
+    return true;
+}
+
+__device__ __forceinline__ int hot_class(unsigned count) { return count == 0xffffffffu ? 32 : 32 - __builtin_clz(count + 1u) - 0; }   // floor(log2(count + 1)) + 0
+
+// counts[c] += 1 per reference.  Hot columns are hit by many lanes at once: a wave first folds equal neighbours
+// (sorted rows put equal or near columns side by side only rarely, so this is plain atomics for most lanes).
+__global__ __launch_bounds__(HC_BLOCK) void hot_count_kernel(const int *__restrict__ cols, long long nnz, unsigned *__restrict__ counts, int num_cols)
+{
+    const long long stride = (long long) gridDim.x * HC_BLOCK;
+    for (long long j = (long long) blockIdx.x * HC_BLOCK + threadIdx.x; j < nnz; j += stride) {
+        const unsigned c = (unsigned) cols[j];
+        if (c < (unsigned) num_cols) atomicAdd(&counts[c], 1u);          // (an out-of-range index is left alone: the SpMV would fault on it either way)
+    }
+}
+
+// class sizes: sizes[k] = number of columns of class k
+__global__ __launch_bounds__(HC_BLOCK) void hot_class_sizes_kernel(const unsigned *__restrict__ counts, int num_cols, unsigned *__restrict__ sizes)
+{
+    __shared__ unsigned s_n[CLASSES];
+    if (threadIdx.x < CLASSES) s_n[threadIdx.x] = 0u;
+    __syncthreads();
+    const int c = blockIdx.x * HC_BLOCK + threadIdx.x;
+    if (c < num_cols) atomicAdd(&s_n[hot_class(counts[c])], 1u);
+    __syncthreads();
+    if (threadIdx.x < CLASSES && s_n[threadIdx.x]) atomicAdd(&sizes[threadIdx.x], s_n[threadIdx.x]);
+}
+
+// bases: hottest class first.  sizes / bases / cursors are three consecutive arrays of CLASSES words.
+__global__ void hot_class_bases_kernel(unsigned *__restrict__ cls)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned run = 0;
+    for (int k = CLASSES - 1; k >= 0; --k) { cls[CLASSES + k] = run; cls[2 * CLASSES + k] = 0u; run += cls[k]; }
+}
+
+// rank[c] = base[class] + position inside the class.  A block reserves, per class, one range for all its columns of
+// that class (one global atomic per class and block) and numbers them inside it in thread order, so neighbouring
+// original columns of one class stay neighbours.  counts[] is overwritten by the ranks; order[rank] = c.
+__global__ __launch_bounds__(HC_BLOCK) void hot_rank_kernel(unsigned *__restrict__ counts_then_rank, int num_cols, unsigned *__restrict__ cls,
+                                                            int *__restrict__ order)
+{
+    __shared__ unsigned s_n[CLASSES], s_base[CLASSES];
+    __shared__ unsigned char s_cls[HC_BLOCK];
+    if (threadIdx.x < CLASSES) s_n[threadIdx.x] = 0u;
+    __syncthreads();
+    const int c = blockIdx.x * HC_BLOCK + threadIdx.x;
+    const int k = c < num_cols ? hot_class(counts_then_rank[c]) : -1;
+    s_cls[threadIdx.x] = (unsigned char) (k < 0 ? 255 : k);
+    if (k >= 0) atomicAdd(&s_n[k], 1u);
+    __syncthreads();
+    if (threadIdx.x < CLASSES && s_n[threadIdx.x])
+        s_base[threadIdx.x] = cls[CLASSES + threadIdx.x] + atomicAdd(&cls[2 * CLASSES + threadIdx.x], s_n[threadIdx.x]);
+    __syncthreads();
+    if (k >= 0) {
+        unsigned before = 0;                                            // columns of my class earlier in this block
+        for (int t = 0; t < (int) threadIdx.x; ++t) before += s_cls[t] == (unsigned char) k ? 1u : 0u;
+        const unsigned r = s_base[k] + before;
+        counts_then_rank[c] = r;
+        order[r] = c;
+    }
+}
+
+__global__ __launch_bounds__(HC_BLOCK) void hot_relabel_kernel(const int *__restrict__ cols, long long nnz, const unsigned *__restrict__ rank,
+                                                               int *__restrict__ new_cols, int num_cols)
+{
+    const long long stride = (long long) gridDim.x * HC_BLOCK;
+    for (long long j = (long long) blockIdx.x * HC_BLOCK + threadIdx.x; j < nnz; j += stride) {
+        const unsigned c = (unsigned) cols[j];
+        new_cols[j] = c < (unsigned) num_cols ? (int) rank[c] : (int) c;
+    }
+}
+
+// xp[k] = x[order[k]]: the one extra pass per SpMV (a gather in the ORIGINAL numbering; the writes are coalesced)
+template <typename V>
+__global__ __launch_bounds__(HC_BLOCK) void hot_permute_x_kernel(const V *__restrict__ x, const int *__restrict__ order, V *__restrict__ xp, int num_cols)
+{
+    const int k = blockIdx.x * HC_BLOCK + threadIdx.x;
+    if (k < num_cols) xp[k] = x[order[k]];
+}
+
+#define HC_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int) e_; } while (0)
+
+int launched(hipStream_t stream, int debug_sync, const char *name, unsigned grid)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int) e;
+    if (debug_sync) { printf("mspmv: %s<<<%u, %d>>>\n", name, grid, HC_BLOCK); fflush(stdout); e = hipStreamSynchronize(stream); }
+    return (int) e;
+}
+
+int hot_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets, const int32_t *d_cols, int32_t rows, int32_t cols, int32_t nnz,
+              int32_t value_bytes, hipStream_t stream, int debug_sync)
+{
+    if (!d_plan || rows < 0 || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8) || !d_row_offsets || (nnz > 0 && !d_cols)) return hipErrorInvalidValue;
+    HotLayout L;
+    if (!make_layout(rows, cols, nnz, value_bytes, L) || plan_bytes < L.total) return hipErrorInvalidValue;
+    char *base = static_cast<char *>(d_plan);
+    unsigned *counts = reinterpret_cast<unsigned *>(base + L.counts_off);
+    unsigned *cls = reinterpret_cast<unsigned *>(base + L.class_off);
+    int *order = reinterpret_cast<int *>(base + L.order_off);
+    int *new_cols = reinterpret_cast<int *>(base + L.cols_off);
+    HC_HIP(hipMemsetAsync(counts, 0, (size_t) std::max(cols, 1) * 4, stream));
+    HC_HIP(hipMemsetAsync(cls, 0, (size_t) 3 * CLASSES * 4, stream));
+    if (cols == 0) return hipSuccess;
+    const unsigned cgrid = (unsigned) ((cols + HC_BLOCK - 1) / HC_BLOCK);
+    const unsigned ngrid = (unsigned) std::min<long long>(((long long) nnz + HC_BLOCK - 1) / HC_BLOCK, 1 << 16);
+    if (nnz > 0) {
+        hipLaunchKernelGGL(hot_count_kernel, dim3(ngrid), dim3(HC_BLOCK), 0, stream, d_cols, (long long) nnz, counts, cols);
+        if (int e = launched(stream, debug_sync, "hot_count_kernel", ngrid)) return e;
+    }
+    hipLaunchKernelGGL(hot_class_sizes_kernel, dim3(cgrid), dim3(HC_BLOCK), 0, stream, counts, cols, cls);
+    if (int e = launched(stream, debug_sync, "hot_class_sizes_kernel", cgrid)) return e;
+    hipLaunchKernelGGL(hot_class_bases_kernel, dim3(1), dim3(64), 0, stream, cls);
+    if (int e = launched(stream, debug_sync, "hot_class_bases_kernel", 1)) return e;
+    hipLaunchKernelGGL(hot_rank_kernel, dim3(cgrid), dim3(HC_BLOCK), 0, stream, counts, cols, cls, order);
+    if (int e = launched(stream, debug_sync, "hot_rank_kernel", cgrid)) return e;
+    if (nnz > 0) {
+        hipLaunchKernelGGL(hot_relabel_kernel, dim3(ngrid), dim3(HC_BLOCK), 0, stream, d_cols, (long long) nnz, counts, new_cols, cols);
+        if (int e = launched(stream, debug_sync, "hot_relabel_kernel", ngrid)) return e;
+    }
+    // the hints of the inner call's tiles (they depend on the row offsets alone)
+    CallExtra ex; ex.phase = PHASE_COORDS_ONLY;
+    size_t tb = (size_t) L.temp_bytes;
+    if (value_bytes == 4)
+        return csrmv_call<float>(base + L.temp_off, &tb, nullptr, d_row_offsets, nullptr, nullptr, nullptr, rows, 0, nnz, 1.f, 0.f, false, stream, debug_sync, ex);
+    return csrmv_call<double>(base + L.temp_off, &tb, nullptr, d_row_offsets, nullptr, nullptr, nullptr, rows, 0, nnz, 1.0, 0.0, false, stream, debug_sync, ex);
+}
+
+template <typename V>
+int hot_apply(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t *d_row_offsets, const V *d_x, V *d_y, int32_t rows, int32_t cols,
+              int32_t nnz, V alpha, V beta, hipStream_t stream, int debug_sync)
+{
+    if (!d_plan || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
+    HotLayout L;
+    if (!make_layout(rows, cols, nnz, (int) sizeof(V), L) || plan_bytes < L.total) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    if (!d_y || !d_row_offsets || (nnz > 0 && (!d_x || !d_values))) return hipErrorInvalidValue;
+    char *base = static_cast<char *>(d_plan);
+    V *xp = reinterpret_cast<V *>(base + L.xp_off);
+    if (cols > 0 && nnz > 0) {
+        const unsigned grid = (unsigned) ((cols + HC_BLOCK - 1) / HC_BLOCK);
+        hipLaunchKernelGGL((hot_permute_x_kernel<V>), dim3(grid), dim3(HC_BLOCK), 0, stream, d_x, reinterpret_cast<const int *>(base + L.order_off), xp, cols);
+        if (int e = launched(stream, debug_sync, "hot_permute_x_kernel", grid)) return e;
+    }
+    CallExtra ex; ex.phase = PHASE_ALL;            // (hints from the build; verified by the tiles as always)
+    size_t tb = (size_t) L.temp_bytes;
+    return csrmv_call<V>(base + L.temp_off, &tb, d_values, d_row_offsets, reinterpret_cast<const int *>(base + L.cols_off), xp, d_y, rows, cols, nnz,
+                         alpha, beta, !(alpha == (V) 1 && beta == (V) 0), stream, debug_sync, ex);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mspmv_csrmv_hotcols_size(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, size_t *plan_bytes)
+{
+    if (!plan_bytes || rows < 0 || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8)) return hipErrorInvalidValue;
+    HotLayout L;
+    if (!make_layout(rows, cols, nnz, value_bytes, L)) return hipErrorInvalidValue;
+    *plan_bytes = (size_t) L.total;
+    return hipSuccess;
+}
+
+int mspmv_csrmv_hotcols_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets, const int32_t *d_column_indices, int32_t rows,
+                              int32_t cols, int32_t nnz, int32_t value_bytes, mspmv_stream_t stream, int debug_sync)
+{
+    return hot_build(d_plan, plan_bytes, d_row_offsets, d_column_indices, rows, cols, nnz, value_bytes, reinterpret_cast<hipStream_t>(stream), debug_sync);
+}
+
+int mspmv_csrmv_hotcols_apply_f32(void *d_plan, size_t plan_bytes, const float *d_values, const int32_t *d_row_offsets, const float *d_x, float *d_y,
+                                  int32_t rows, int32_t cols, int32_t nnz, float alpha, float beta, mspmv_stream_t stream, int debug_sync)
+{
+    return hot_apply<float>(d_plan, plan_bytes, d_values, d_row_offsets, d_x, d_y, rows, cols, nnz, alpha, beta, reinterpret_cast<hipStream_t>(stream), debug_sync);
+}
+
+int mspmv_csrmv_hotcols_apply_f64(void *d_plan, size_t plan_bytes, const double *d_values, const int32_t *d_row_offsets, const double *d_x, double *d_y,
+                                  int32_t rows, int32_t cols, int32_t nnz, double alpha, double beta, mspmv_stream_t stream, int debug_sync)
+{
+    return hot_apply<double>(d_plan, plan_bytes, d_values, d_row_offsets, d_x, d_y, rows, cols, nnz, alpha, beta, reinterpret_cast<hipStream_t>(stream), debug_sync);
+}
+
+/* the plan's pieces, for callers that keep x in the plan's numbering themselves (an iterative method on a symmetric permutation)
+ * and for the tests: order[k] = the original column that became column k (cols int32), the renumbered column indices (nnz int32) */
+const int32_t *mspmv_csrmv_hotcols_order(const void *d_plan, int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes)
+{
+    HotLayout L;
+    if (!d_plan || !make_layout(rows, cols, nnz, value_bytes, L)) return nullptr;
+    return reinterpret_cast<const int32_t *>(static_cast<const char *>(d_plan) + L.order_off);
+}
+const int32_t *mspmv_csrmv_hotcols_columns(const void *d_plan, int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes)
+{
+    HotLayout L;
+    if (!d_plan || !make_layout(rows, cols, nnz, value_bytes, L)) return nullptr;
+    return reinterpret_cast<const int32_t *>(static_cast<const char *>(d_plan) + L.cols_off);
+}
+
+}  // extern "C"

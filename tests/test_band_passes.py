@@ -50,7 +50,7 @@ def test_automatic_policy_table():
         assert M.band_passes(*C2, 4) == 0
         M.set_band_passes(4, 5)
         assert M.band_passes(*C2, 4) == 5 and M.band_passes(1 << 26, 1 << 26, 2_000_000_000, 4) == 5
-        assert M.band_passes(1000, 1000, 5000, 4) == 0          # small problems run the self-searching kernel: no passes
+        assert M.band_passes(1000, 1000, 5000, 4) == 0          # (a forced count needs as many columns per band ... and the large-problem tile shape)
     finally:
         M.set_band_passes(4, 0)
 
@@ -417,6 +417,48 @@ def test_detector_refuses_matrices_with_reuse(kind):
         assert _strict_on_device(val, off, col, x, ys, 0)
     finally:
         M.set_band_passes(4, 0); M.set_tuning(4)
+
+
+@gpu
+@pytest.mark.parametrize("uniform_share,expect_passes", [(0.45, False), (0.70, False), (0.95, True)])
+def test_detector_with_split_votes(uniform_share, expect_passes):
+    """A matrix whose first rows have uniformly spread columns and whose remaining rows are banded: the 64 windows are
+    spaced evenly over the nonzeros, so about `uniform_share` of them vote "spread".  Below the 56-of-64 majority the call
+    must run the ordinary body (bit for bit the classic pipeline's result); above it the passes (bit for bit the forced
+    passes' result); either way every row stays within the strict bound."""
+    tdt, vb = torch.float32, 4
+    rows, cols, per_row = 1_062_500, 2_400_000, 32
+    n_uni = int(rows * uniform_share)
+    val_u, _, col_u, x = _uniform(n_uni, cols, per_row, tdt)
+    r = torch.arange(rows - n_uni, device="cuda", dtype=torch.int64)
+    start = ((r * 2) % (cols - per_row)).clamp(0, cols - per_row)
+    col_b = (start[:, None] + torch.arange(per_row, device="cuda")[None, :]).reshape(-1).to(torch.int32)
+    g = torch.Generator(device="cuda"); g.manual_seed(13)
+    val_b = (torch.rand((rows - n_uni) * per_row, generator=g, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+    val = torch.cat([val_u, val_b]); col = torch.cat([col_u, col_b])
+    off = (torch.arange(rows + 1, device="cuda", dtype=torch.int64) * per_row).to(torch.int32)
+    nnz = rows * per_row
+    ws = M.CsrMVWorkspace(rows, nnz, tdt)
+    try:
+        M.set_band_passes(vb, 0)
+        offered = M.band_passes(rows, cols, nnz, vb)
+        assert offered == 2
+        y = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
+        M.csrmv(val, off, col, x, y=y, num_cols=cols, workspace=ws)
+        torch.cuda.synchronize()
+        votes = int(M.debug_band_windows(ws, rows, nnz, vb).sum())
+        assert abs(votes - 64 * uniform_share) <= 3, votes
+        assert (votes >= 56) == expect_passes
+        assert _strict_on_device(val, off, col, x, y, offered)
+        yr = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
+        if expect_passes:
+            M.set_band_passes(vb, offered)                       # forced passes
+        else:
+            M.set_band_passes(vb, -1); M.set_tuning(vb, 0, 0, 0x40000000)      # classic tiles + fix-up, no passes on offer
+        M.csrmv(val, off, col, x, y=yr, num_cols=cols, workspace=M.CsrMVWorkspace(rows, nnz, tdt))
+        assert torch.equal(y, yr)
+    finally:
+        M.set_band_passes(vb, 0); M.set_tuning(vb)
 
 
 @gpu
