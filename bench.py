@@ -19,9 +19,10 @@ edges, ONE matrix independent of N, merge-partitioned by diagonal into N swaths 
 every rank builds its swath in its own HBM from the counter-based generator and drives it through the C
 multi-GPU operator (mspmv_mg_plan_*: the part's CsrMV launches + ONE RCCL all-gather of the N
 boundary-row carries + the owner's add, all below the C ABI).  Strong scaling: `value` = 2 * nnz_total /
-max-over-ranks time; `per_rank` carries the spread of the ranks' tile-kernel and step times.  With --single-gpu-leg rank 0
-then also runs the WHOLE matrix alone on its GPU in the same job (`single_gpu_same_workload`); by default that figure
-comes from the N = 1 run of this bench (configs: "C5 at G = 1"), because generating 36 GB on one rank idles the others.
+max-over-ranks time; `per_rank` carries the spread of the ranks' tile-kernel and step times, `hot_column_plan` the same job
+with every rank's columns renumbered by reference count (mspmv_mg_plan_hot_columns: opt-in, set-up apart).  Rank 0 then also
+runs the WHOLE matrix alone on its GPU in the same job (`single_gpu_same_workload`, 5 steps; --no-single-gpu-leg skips it), so
+the line is self-contained for an efficiency figure.
 "c2" can also be run sharded (--workload c2 --gpus N: weak scaling, N x 3 125 000 rows over the same
 3 125 000 columns); "dense32" is C2's pure-streaming variant (--dense=32 --size=100000000).
 
@@ -241,9 +242,8 @@ def main():
     ap.add_argument("--c5-edges", type=int, default=2_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plan", action="store_true", help="skip the prepared_plan sub-record (N = 1, c2)")
-    ap.add_argument("--single-gpu-leg", action="store_true",
-                    help="N > 1, c5: rank 0 also generates and times the WHOLE matrix alone afterwards (minutes of set-up during which the "
-                         "other ranks idle; off by default -- the N = 1 run of the same bench carries that figure as configs['C5 at G = 1'])")
+    ap.add_argument("--no-single-gpu-leg", action="store_true",
+                    help="N > 1, c5: skip rank 0's run of the WHOLE matrix alone afterwards (about 15 s during which the other ranks idle)")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records (the other single-GPU configurations)")
     ap.add_argument("--configs-budget", type=float, default=150.0, help="seconds the `configs` leg may take before it stops starting new ones")
     ap.add_argument("--dist-timeout", type=int, default=900, help="N > 1: seconds a collective may block before the job aborts")
@@ -406,9 +406,30 @@ def main():
     op_sync()
     prof = M.profile_end()
 
+    # ---- N > 1 through the C operator: the same steps with every rank's columns renumbered by reference count ----------------
+    hot = None
+    if plan is not None and workload == "c5":
+        torch.cuda.synchronize(); th0 = time.perf_counter()
+        plan.hot_columns(True)
+        op_sync(); hot_setup_ms = (time.perf_counter() - th0) * 1e3
+        for _ in range(max(2, min(args.warmup, 5))):
+            op()
+        barrier()
+        th0 = time.perf_counter()
+        for _ in range(args.steps):
+            op()
+        barrier()
+        th = torch.tensor([time.perf_counter() - th0, hot_setup_ms], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        hot_ms = float(th[0].item()) * 1e3 / args.steps
+        hot = {"api": "mspmv_mg_plan_hot_columns (opt-in; every rank renumbers its part's columns by reference count once; x permuted per step, inside the timed loop)",
+               "setup_ms_max_over_ranks": round(float(th[1].item()), 2), "ms_per_step": round(hot_ms, 5),
+               "value": round(2.0 * nnz_total / (hot_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
+
     # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
     single = None
-    if mg and workload == "c5" and args.single_gpu_leg:
+    if mg and workload == "c5" and not args.no_single_gpu_leg:
         if plan is not None:
             plan.close()
         plan = None; shard = None; sharded = None
@@ -417,8 +438,8 @@ def main():
             W = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
             wws = M.CsrMVWorkspace(W.rows, W.nnz, tdt, device=dev)
             wy = torch.empty(W.rows, dtype=tdt, device=dev)
-            k = max(5, min(args.steps, 50))
-            for _ in range(3):
+            k = 5
+            for _ in range(2):
                 M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             for _ in range(k):
@@ -507,6 +528,8 @@ def main():
                 out["exchange"]["backend"] = {1: "RCCL ncclAllGather (1 element per rank) below the C ABI", 2: "peer reads"}.get(exchange["exchange"])
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if hot is not None:
+            out["hot_column_plan"] = hot
         if single is not None:
             out["single_gpu_same_workload"] = single
         if not mg and workload == "c2" and not args.no_plan and hasattr(M, "CsrMVPlan"):

@@ -372,6 +372,11 @@ void *mspmv_mg_plan_x(mspmv_mg_plan_t *plan, int32_t local_index);
 void *mspmv_mg_plan_y(mspmv_mg_plan_t *plan, int32_t local_index);
 mspmv_stream_t mspmv_mg_plan_stream(mspmv_mg_plan_t *plan, int32_t local_index);
 int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info);
+/* enable != 0: every local part's columns are renumbered by reference count (the hot-column plan above, built once per
+ * part in plan-owned storage of 4 * local_nnz + 16 * cols bytes; every part must be attached) and mspmv_mg_csrmv permutes
+ * x into the part's numbering before its SpMV -- for a scale-free matrix with an x far beyond the caches (config 5).
+ * Results are bit for bit the ones without it.  enable == 0 releases the storage. */
+int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable);
 int mspmv_mg_csrmv(mspmv_mg_plan_t *plan);
 int mspmv_mg_allgather_rows(mspmv_mg_plan_t *plan);
 int mspmv_mg_synchronize(mspmv_mg_plan_t *plan);

@@ -141,6 +141,8 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_mg_plan_create.argtypes = [ctypes.POINTER(vp), i32, i32, vp, vp, vp, vp, i64, i32, i32, vp]
     lib.mspmv_mg_plan_set_part.restype = ctypes.c_int
     lib.mspmv_mg_plan_set_part.argtypes = [vp, i32, vp, vp, vp]
+    lib.mspmv_mg_plan_hot_columns.restype = ctypes.c_int
+    lib.mspmv_mg_plan_hot_columns.argtypes = [vp, i32]
     for name in ("mspmv_mg_plan_x", "mspmv_mg_plan_y", "mspmv_mg_plan_stream"):
         getattr(lib, name).restype = vp
         getattr(lib, name).argtypes = [vp, i32]

@@ -30,7 +30,7 @@ constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 constexpr int DEV_FLAG_MASK = 1 | 0xff00 | 0x70000 | 0xf00000;   // selectors of the -DMSPMV_DEV kernel variants
-constexpr int SMALL_MAX_TILES_DEFAULT = 1280;    // up to here a problem takes the smallest compiled tile that keeps it within 896 tiles, or the largest
+constexpr int SMALL_MAX_TILES_DEFAULT = 1024;    // fp32: up to this many 256x7 tiles a problem takes that shape, 256x11 beyond
 // (MSPMV_SMALL_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
 static int small_max_tiles()
 {
@@ -41,15 +41,17 @@ static int small_max_tiles()
 
 static_assert(TILE_MAP_CONTIGUOUS_CODE == TILE_MAP_CONTIGUOUS, "mapping code shared with the kernels");
 
-// Tile shapes compiled in.  The product library holds the shapes pick_shape can choose by itself; the three further
-// shapes per precision of the tuning sweeps (tools/sweep.py) exist only in the -DMSPMV_DEV build.
+// Tile shapes compiled in.  The product library holds the two shapes per precision that pick_shape chooses from -- a sweep
+// of every shape over 40 k ... 100 M nonzeros (tools/small_shapes.py, tools/sweep.py; profiles/r03_small_shapes.txt) found
+// no size at which another one wins by more than noise --; the further shapes of the tuning sweeps exist only in the
+// -DMSPMV_DEV build.
 struct Shape { int block, ipt; };
 #ifdef MSPMV_DEV
-static const Shape kShapesF32[] = {{256, 7}, {256, 9}, {256, 11}, {256, 15}, {256, 5}, {128, 7}, {512, 7}};
-static const Shape kShapesF64[] = {{256, 5}, {256, 7}, {256, 9}, {256, 11}, {256, 3}, {128, 5}, {512, 5}};
+static const Shape kShapesF32[] = {{256, 7}, {256, 11}, {256, 9}, {256, 15}, {256, 5}, {128, 7}, {512, 7}};
+static const Shape kShapesF64[] = {{256, 7}, {256, 11}, {256, 5}, {256, 9}, {256, 3}, {128, 5}, {512, 5}};
 #else
-static const Shape kShapesF32[] = {{256, 7}, {256, 9}, {256, 11}, {256, 15}};
-static const Shape kShapesF64[] = {{256, 5}, {256, 7}, {256, 9}, {256, 11}};
+static const Shape kShapesF32[] = {{256, 7}, {256, 11}};
+static const Shape kShapesF64[] = {{256, 7}, {256, 11}};
 #endif
 
 // The development override of mspmv_set_tuning / mspmv_set_band_passes: per HOST THREAD (a measuring or testing aid; a
@@ -57,27 +59,18 @@ static const Shape kShapesF64[] = {{256, 5}, {256, 7}, {256, 9}, {256, 11}};
 static thread_local Tune t_tune[2];
 static inline const Tune &thread_tune(int value_bytes) { return t_tune[value_bytes == 8]; }
 
-// Default shape (measured on MI355X; profiles/r02_small_problem_shapes.txt, r01_sweep_vs_rocsparse.txt):
-//  * a problem that fits ONE compiled tile takes it;
-//  * a problem that some compiled tile cuts into at most SMALL_MAX_TILES (1280) tiles: the smallest tile that keeps it
-//    within 896 tiles (more, smaller tiles = more CUs busy on a small matrix), else the largest tile;
-//  * everything larger: 256x11 -- the fastest or within 1 % of the fastest shape on every large workload tried -- except
-//    fp64 problems of up to 24 M path items, where 256x7 (7 resident blocks per CU instead of 5) is 2-4 % faster.
+// Default shape (measured on MI355X with the one-launch kernel; profiles/r03_small_shapes.txt, r03_sweep_vs_rocsparse.txt):
+//  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (1024) tiles -- more, smaller tiles keep more CUs
+//    busy on a small matrix: 4.4-5.6 us per call up to 1.4 M nonzeros where 256x11 takes 4.9-5.9 --, 256x11 beyond (the
+//    fastest or within 1 % of the fastest shape on every larger workload tried);
+//  * fp64: 256x7 (7 resident blocks per CU instead of 5) up to 24 M path items, 256x11 beyond;
+//  * MSPMV_TUNE_NO_FUSED / _NO_VEC: the large-problem choice whatever the size (tests).
 static Shape pick_shape(int value_bytes, long long items, const Tune &t)
 {
     if (t.block > 0) return Shape{t.block, t.ipt};
-    const int flags = t.flags;
-    static const int ipts32[] = {7, 9, 11, 15}, ipts64[] = {5, 7, 9, 11};
-    const int *ipts = value_bytes == 8 ? ipts64 : ipts32;
-    auto tiles = [&](int ipt) { return (items + 256LL * ipt - 1) / (256LL * ipt); };
-    if (!(flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED))) {
-        for (int i = 0; i < 4; ++i)
-            if (items <= 256LL * ipts[i]) return Shape{256, ipts[i]};
-        for (int i = 0; i < 4; ++i)
-            if (tiles(ipts[i]) <= 896) return Shape{256, ipts[i]};
-        if (tiles(ipts[3]) <= SMALL_MAX_TILES) return Shape{256, ipts[3]};
-    }
-    if (value_bytes == 8 && items <= 24000000LL) return Shape{256, 7};
+    const bool small_ok = !(t.flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED));
+    if (value_bytes == 8) return items <= 24000000LL ? Shape{256, 7} : Shape{256, 11};
+    if (small_ok && (items + 256LL * 7 - 1) / (256LL * 7) <= SMALL_MAX_TILES) return Shape{256, 7};
     return Shape{256, 11};
 }
 
@@ -546,10 +539,10 @@ hipError_t dispatch_shape<float>(const Layout &L, void *d_temp, const Params<flo
                                  int debug_sync, const CallExtra &ex)
 {
     MSPMV_SHAPE_CASE(float, 256, 7)
-    MSPMV_SHAPE_CASE(float, 256, 9)
     MSPMV_SHAPE_CASE(float, 256, 11)
-    MSPMV_SHAPE_CASE(float, 256, 15)
 #ifdef MSPMV_DEV
+    MSPMV_SHAPE_CASE(float, 256, 9)
+    MSPMV_SHAPE_CASE(float, 256, 15)
     MSPMV_SHAPE_CASE(float, 256, 5)
     MSPMV_SHAPE_CASE(float, 128, 7)
     MSPMV_SHAPE_CASE(float, 512, 7)
@@ -561,11 +554,11 @@ template <>
 hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<double> &p, bool axpby,
                                   hipStream_t stream, int debug_sync, const CallExtra &ex)
 {
-    MSPMV_SHAPE_CASE(double, 256, 5)
     MSPMV_SHAPE_CASE(double, 256, 7)
-    MSPMV_SHAPE_CASE(double, 256, 9)
     MSPMV_SHAPE_CASE(double, 256, 11)
 #ifdef MSPMV_DEV
+    MSPMV_SHAPE_CASE(double, 256, 5)
+    MSPMV_SHAPE_CASE(double, 256, 9)
     MSPMV_SHAPE_CASE(double, 256, 3)
     MSPMV_SHAPE_CASE(double, 128, 5)
     MSPMV_SHAPE_CASE(double, 512, 5)

@@ -138,6 +138,7 @@ struct Part {
     hipEvent_t done = nullptr, applied = nullptr, pushed = nullptr;
     bool applied_valid = false, pushed_valid = false, done_valid = false;
     ncclComm_t comm = nullptr;
+    void *hot = nullptr; size_t hot_bytes = 0;      // hot-column plan of the part (mspmv_mg_plan_hot_columns): its own temp, indices, x
 };
 
 struct Replica { int device = 0; void *x = nullptr; };
@@ -178,9 +179,21 @@ int run_spmv(mspmv_mg_plan *plan)
                 MG_HIP(hipStreamWaitEvent(q.stream, o.applied, 0));
         }
         size_t tb = q.temp_bytes;
-        const int st = csrmv_call<V>(q.temp, &tb, static_cast<const V *>(q.values), q.offsets, q.cols,
-                                     static_cast<const V *>(plan->replicas[q.replica].x), static_cast<V *>(q.y), q.local_rows,
-                                     (int32_t) plan->cols, q.local_nnz, (V) 1, (V) 0, false, q.stream, 0, ex);
+        int st;
+        if (q.hot) {
+            // the part's columns renumbered by reference count (mspmv_hotcols.hip): x is permuted into the part's numbering first
+            if (sizeof(V) == 4)
+                st = mspmv_csrmv_hotcols_apply_f32(q.hot, q.hot_bytes, static_cast<const float *>(q.values), q.offsets,
+                                                   static_cast<const float *>(plan->replicas[q.replica].x), static_cast<float *>(q.y), q.local_rows,
+                                                   (int32_t) plan->cols, q.local_nnz, 1.f, 0.f, q.stream, 0);
+            else
+                st = mspmv_csrmv_hotcols_apply_f64(q.hot, q.hot_bytes, static_cast<const double *>(q.values), q.offsets,
+                                                   static_cast<const double *>(plan->replicas[q.replica].x), static_cast<double *>(q.y), q.local_rows,
+                                                   (int32_t) plan->cols, q.local_nnz, 1.0, 0.0, q.stream, 0);
+        } else
+            st = csrmv_call<V>(q.temp, &tb, static_cast<const V *>(q.values), q.offsets, q.cols,
+                               static_cast<const V *>(plan->replicas[q.replica].x), static_cast<V *>(q.y), q.local_rows,
+                               (int32_t) plan->cols, q.local_nnz, (V) 1, (V) 0, false, q.stream, 0, ex);
         if (st != 0) return st;
         MG_HIP(hipEventRecord(q.done, q.stream)); q.done_valid = true;
     }
@@ -261,6 +274,7 @@ int destroy(mspmv_mg_plan *plan)
         if (q.applied) (void) hipEventDestroy(q.applied);
         if (q.pushed) (void) hipEventDestroy(q.pushed);
         (void) hipFree(q.temp); (void) hipFree(q.y); (void) hipFree(q.carries); (void) hipFree(q.src_table); (void) hipFree(q.push_table);
+        (void) hipFree(q.hot);
         if (q.stream) (void) hipStreamDestroy(q.stream);
     }
     for (Replica &r : plan->replicas) { (void) hipSetDevice(r.device); (void) hipFree(r.x); }
@@ -446,6 +460,30 @@ int mspmv_mg_plan_set_part(mspmv_mg_plan_t *plan, int32_t i, const void *d_value
         st = csrmv_call<double>(q.temp, &tb, nullptr, q.offsets, nullptr, nullptr, nullptr, q.local_rows, 0, q.local_nnz, 1.0, 0.0, false, q.stream, 0, ex);
     if (st == 0) st = (int) hipStreamSynchronize(q.stream);
     q.attached = st == 0;
+    (void) hipSetDevice(prev);
+    return st;
+}
+
+int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable)
+{
+    if (!plan) return kErrInvalid;
+    int prev = 0; MG_HIP(hipGetDevice(&prev));
+    int st = 0;
+    for (Part &q : plan->local) {
+        if (!q.attached) { st = kErrInvalid; break; }
+        (void) hipSetDevice(q.device);
+        (void) hipStreamSynchronize(q.stream);
+        if (!enable) { (void) hipFree(q.hot); q.hot = nullptr; q.hot_bytes = 0; continue; }
+        if (q.hot) continue;
+        size_t bytes = 0;
+        st = mspmv_csrmv_hotcols_size(q.local_rows, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, &bytes);
+        if (st != 0) break;
+        if (hipMalloc(&q.hot, bytes) != hipSuccess) { (void) hipGetLastError(); q.hot = nullptr; st = hipErrorOutOfMemory; break; }
+        q.hot_bytes = bytes;
+        st = mspmv_csrmv_hotcols_build(q.hot, bytes, q.offsets, q.cols, q.local_rows, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, q.stream, 0);
+        if (st == 0) st = (int) hipStreamSynchronize(q.stream);
+        if (st != 0) { (void) hipFree(q.hot); q.hot = nullptr; q.hot_bytes = 0; break; }
+    }
     (void) hipSetDevice(prev);
     return st;
 }

@@ -16,6 +16,7 @@
 // Extra method lines of this project (non-quiet only; the CSV keeps the reference's columns):
 //   --prepared   the stateless call with the tile coordinates found once (mspmv_csrmv_prepare)
 //   --plan       the prepared band-major plan (mspmv_csrmv_plan_*): set-up = the plan build
+//   --hotcols    the hot-column plan (mspmv_csrmv_hotcols_*): set-up = ranking the columns by reference count
 //   --band-passes=<n>  column-band passes of the stateless call (mspmv_set_band_passes): 0 automatic (default),
 //                -1 never, n >= 2 always n
 //   --gpus=G     the matrix merge-partitioned over G GPUs of this node through the C multi-GPU operator
@@ -202,6 +203,33 @@ float TestPlan(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &
     return ms;
 }
 
+// the hot-column plan (extension): set-up = mspmv_csrmv_hotcols_build, then the same protocol (x permuted inside every timed call)
+template <typename V>
+float TestHotColumns(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
+                     const std::vector<V> &gold, DeviceProblem<V> &p, int iterations, float &setup_ms)
+{
+    size_t bytes = 0;
+    HIP_OK((hipError_t) mspmv_csrmv_hotcols_size(p.rows, p.cols, p.nnz, (int) sizeof(V), &bytes));
+    void *d_plan = nullptr;
+    HIP_OK(hipMalloc(&d_plan, bytes));
+    auto apply = [&](int debug) {
+        if constexpr (sizeof(V) == 4) return (hipError_t) mspmv_csrmv_hotcols_apply_f32(d_plan, bytes, p.d_values, p.d_row_offsets, p.d_x, p.d_y, p.rows, p.cols, p.nnz, (float) c.alpha, (float) c.beta, nullptr, debug);
+        else return (hipError_t) mspmv_csrmv_hotcols_apply_f64(d_plan, bytes, p.d_values, p.d_row_offsets, p.d_x, p.d_y, p.rows, p.cols, p.nnz, (double) c.alpha, (double) c.beta, nullptr, debug);
+    };
+    GpuTimer setup; setup.Start();
+    HIP_OK((hipError_t) mspmv_csrmv_hotcols_build(d_plan, bytes, p.d_row_offsets, p.d_cols, p.rows, p.cols, p.nnz, (int) sizeof(V), nullptr, 0));
+    setup.Stop(); setup_ms = setup.ElapsedMillis();
+    HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));
+    HIP_OK(apply(!c.quiet));
+    if (!c.quiet) Verify(c, a, x, gold, p.d_y, c.alpha == 1.0f && c.beta == 0.0f);
+    GpuTimer timer; timer.Start();
+    for (int it = 0; it < iterations; ++it) HIP_OK(apply(0));
+    timer.Stop();
+    const float ms = timer.ElapsedMillis() / iterations;
+    HIP_OK(hipFree(d_plan));
+    return ms;
+}
+
 // the matrix cut into G swaths of the merge path, one per GPU (or all on one device), through the C multi-GPU
 // operator: y = A*x per step = every part's CsrMV + one carry exchange, below the C ABI.  Timed on the host
 // clock around N back-to-back steps + a plan-wide synchronise (events of one device cannot bracket G streams).
@@ -335,7 +363,7 @@ float TestRocsparseHybmv(const RunConfig &c, const CsrMatrix<V> &a, const std::v
     return ms;
 }
 
-struct Extras { bool vendor = true, hyb = true, prepared = false, plan = false, mg_one_device = false; int plan_bands = 0, mg_exchange = MSPMV_MG_EXCHANGE_AUTO; std::vector<int> gpus; };
+struct Extras { bool vendor = true, hyb = true, prepared = false, plan = false, hotcols = false, mg_one_device = false; int plan_bands = 0, mg_exchange = MSPMV_MG_EXCHANGE_AUTO; std::vector<int> gpus; };
 
 template <typename V>
 void Run(const RunConfig &c, const Device &dev, const Extras &ex)
@@ -379,6 +407,12 @@ void Run(const RunConfig &c, const Device &dev, const Extras &ex)
         DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
         DisplayRoofline((int) sizeof(V), avg_ms, csr.num_rows, csr.num_cols, csr.num_nonzeros, dev.giga_bandwidth);
     }
+    if (ex.hotcols && !c.quiet) {               // extra method line, never in the CSV
+        printf("\n\nMerge-based CsrMV (hot-column plan: columns renumbered by reference count), "); fflush(stdout);
+        avg_ms = TestHotColumns(c, csr, x, y_in, gold, p, iterations, setup_ms);
+        DisplayPerf(c.quiet, (int) sizeof(V), setup_ms, avg_ms, csr.num_rows, csr.num_nonzeros, dev.giga_bandwidth);
+        DisplayRoofline((int) sizeof(V), avg_ms, csr.num_rows, csr.num_cols, csr.num_nonzeros, dev.giga_bandwidth);
+    }
     if (!c.quiet && c.alpha == 1.0f && c.beta == 0.0f)
         for (int parts : ex.gpus) {
             int used = 0;
@@ -416,7 +450,7 @@ int main(int argc, char **argv)
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
-               "[--no-strict] [--no-vendor] [--no-hyb] [--cache] [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
+               "[--no-strict] [--no-vendor] [--no-hyb] [--cache] [--prepared] [--plan[=<bands>]] [--hotcols] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
                "[--mg-exchange=peer|rccl] [--band-passes=<n>]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
@@ -428,6 +462,7 @@ int main(int argc, char **argv)
     ex.vendor = !args.CheckCmdLineFlag("no-vendor");
     ex.hyb = !args.CheckCmdLineFlag("no-hyb");          // (the CSR -> HYB conversion takes seconds on some small matrices)
     ex.prepared = args.CheckCmdLineFlag("prepared");
+    ex.hotcols = args.CheckCmdLineFlag("hotcols");
     ex.plan = args.CheckCmdLineFlag("plan");
     args.GetCmdLineArgument("plan", ex.plan_bands);
     if (args.CheckCmdLineFlag("band-passes")) {

@@ -151,6 +151,10 @@ class MgPlan:
         _check(load_library().mspmv_mg_plan_info(self._handle, ctypes.byref(info)), "mspmv_mg_plan_info")
         return {name: getattr(info, name) for name, _ in _MgInfo._fields_ if name != "reserved"}
 
+    def hot_columns(self, enable: bool = True):
+        """renumber every local part's columns by reference count (mspmv_mg_plan_hot_columns)"""
+        _check(load_library().mspmv_mg_plan_hot_columns(self._handle, int(bool(enable))), "mspmv_mg_plan_hot_columns")
+
     def csrmv(self):
         _check(load_library().mspmv_mg_csrmv(self._handle), "mspmv_mg_csrmv")
 

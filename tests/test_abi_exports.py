@@ -61,42 +61,43 @@ def test_size_query_two_phase_convention():
 
 
 def test_tuning_rejects_unknown_shapes():
-    M.set_tuning(4, 256, 9)
-    assert M.launch_info(10, 10, 4)["items_per_thread"] == 9
+    M.set_tuning(4, 256, 11)
+    assert M.launch_info(10, 10, 4)["items_per_thread"] == 11
     M.set_tuning(4)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
-    # default shapes: one tile when the problem fits one; the smallest tile that keeps a small problem within 896 tiles,
-    # else the largest if that keeps it within 1280; beyond: 256x11 (fp64 up to 24 M path items: 256x7).  Always ONE launch
-    # of row-snapped tiles (tile_kernel_snap, no fix-up) unless MSPMV_TUNE_TWO_LAUNCH asks for the classic three
+    # default shapes: fp32 256x7 while that keeps the problem within 1024 tiles, 256x11 beyond; fp64 256x7 up to 24 M path
+    # items, 256x11 beyond.  Always ONE launch of row-snapped tiles (tile_kernel_snap, no fix-up) unless MSPMV_TUNE_TWO_LAUNCH
+    # asks for the classic three
     assert M.launch_info(300_000, 1_000_000, 4)["items_per_thread"] == 7         # 1.3M items / 1792 = 726 tiles
-    assert M.launch_info(1_000_000, 3_500_000, 4)["items_per_thread"] == 15      # 4.5M items / 3840 = 1172 tiles
-    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 0 and M.launch_info(1_000_000, 3_500_000, 4)["snap_head_max"] == 192
-    M.set_tuning(4, 0, 0, 0x40000000)                                            # ... unless asked for: one launch of the one-pass kernel
-    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 1
+    assert M.launch_info(300_000, 1_500_000, 4)["items_per_thread"] == 7         # 1005 tiles
+    assert M.launch_info(300_000, 1_600_000, 4)["items_per_thread"] == 11        # 1061 tiles of 256x7: the large-problem shape
+    info = M.launch_info(1_000_000, 3_500_000, 4)
+    assert info["items_per_thread"] == 11 and info["fixup_levels"] == 0 and info["snap_head_max"] == 192
+    M.set_tuning(4, 0, 0, 0x40000000)                                            # the classic three launches: one fix-up launch
+    info = M.launch_info(1_000_000, 3_500_000, 4)
+    assert info["fixup_levels"] == 1 and info["snap_head_max"] == 0
     M.set_tuning(4, 0, 0, 128)                                                   # the chunked multi-level variant
-    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2           # 1172 carries / 512 per block -> 2 launches
-    M.set_tuning(4)
-    assert M.launch_info(1_000_000, 5_000_000, 4)["items_per_thread"] == 11      # 6M items: 1563 tiles even at 256x15 -> the large-problem shape
-    assert M.launch_info(1_000_000, 5_000_000, 4)["fixup_levels"] == 0 and M.launch_info(1_000_000, 5_000_000, 4)["snap_head_max"] == 192
-    M.set_tuning(4, 0, 0, 0x40000000)
-    assert M.launch_info(1_000_000, 5_000_000, 4)["fixup_levels"] == 1 and M.launch_info(1_000_000, 5_000_000, 4)["snap_head_max"] == 0
+    assert M.launch_info(1_000_000, 3_500_000, 4)["fixup_levels"] == 2           # 1599 carries / 512 per block -> 2 launches
+    M.set_tuning(4, 0, 0, 16)                                                    # the large-problem shape whatever the size
+    assert M.launch_info(1000, 5000, 4)["items_per_thread"] == 11
     M.set_tuning(4)
     # the override is per host thread: another thread sees the defaults
     import threading
-    M.set_tuning(4, 256, 9)
+    M.set_tuning(4, 256, 11)
     seen = {}
     th = threading.Thread(target=lambda: seen.update(ipt=M.launch_info(10, 10, 4)["items_per_thread"]))
     th.start(); th.join()
-    assert seen["ipt"] == 7 and M.launch_info(10, 10, 4)["items_per_thread"] == 9
+    assert seen["ipt"] == 7 and M.launch_info(10, 10, 4)["items_per_thread"] == 11
     M.set_tuning(4)
-    assert M.launch_info(1_000_000, 5_000_000, 8)["items_per_thread"] == 7       # fp64 mid-size: 256x7
+    assert M.launch_info(1_000_000, 5_000_000, 8)["items_per_thread"] == 7       # fp64 up to 24 M path items: 256x7
+    assert M.launch_info(1000, 5000, 8)["items_per_thread"] == 7
     assert M.launch_info(4_000_000, 30_000_000, 8)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 4)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 8)["items_per_thread"] == 11
     with pytest.raises(M.MspmvError):
         M.set_tuning(4, 250, 7)
-    # the shapes of the tuning sweeps exist only in the development build
-    for vb, b, i in ((4, 128, 7), (4, 512, 7), (4, 256, 5), (8, 128, 5), (8, 512, 5), (8, 256, 3)):
+    # the other shapes of the tuning sweeps exist only in the development build
+    for vb, b, i in ((4, 128, 7), (4, 512, 7), (4, 256, 5), (4, 256, 9), (4, 256, 15), (8, 128, 5), (8, 512, 5), (8, 256, 3), (8, 256, 5), (8, 256, 9)):
         with pytest.raises(M.MspmvError):
             M.set_tuning(vb, b, i)
     # the product library has no timing-experiment kernels: their flag bits (persistent grid, staging-only
@@ -105,7 +106,7 @@ def test_tuning_rejects_unknown_shapes():
         with pytest.raises(M.MspmvError):
             M.set_tuning(4, 0, 0, dev_bits)
         with pytest.raises(M.MspmvError):
-            M.set_tuning(8, 256, 9, dev_bits | 16)
+            M.set_tuning(8, 256, 11, dev_bits | 16)
     assert not hasattr(M.load_library(), "mspmv_dev_set_trace")
     assert M.launch_info(10, 10, 4)["flags"] == 0
 

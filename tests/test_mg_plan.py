@@ -120,6 +120,14 @@ def test_single_process_plan_peer_exchange(kind, parts, prec):
             plan.csrmv(); plan.synchronize()
             assert np.array_equal(_gather_y(plan, row_split, csr.rows, dtype), y)
         assert plan.info()["steps"] == 4
+        # every part's columns renumbered by reference count (mspmv_mg_plan_hot_columns): the same bits
+        plan.hot_columns(True)
+        for _ in range(2):
+            plan.csrmv(); plan.synchronize()
+            assert np.array_equal(_gather_y(plan, row_split, csr.rows, dtype), y)
+        plan.hot_columns(False)
+        plan.csrmv(); plan.synchronize()
+        assert np.array_equal(_gather_y(plan, row_split, csr.rows, dtype), y)
     finally:
         plan.close()
 
@@ -278,7 +286,7 @@ def test_bench_multi_rank_path_on_one_device():
     reduced scale: (a) 2 ranks sharing the device, carries over gloo through the Python twin; (b) ONE rank forced through
     the N > 1 code path: nccl process group, shipped RCCL id, the C operator's multi-process form with its
     ncclAllGather inside the timed loop, the same-job single-GPU leg."""
-    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000", "--single-gpu-leg")
+    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000")
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo"}, 2, *small)
     assert out["per_rank"]["tile_ms_max"] >= out["per_rank"]["tile_ms_min"] > 0 and out["per_rank"]["nnz_per_rank_max"] > 0
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f64" and out["value"] > 0
@@ -288,3 +296,4 @@ def test_bench_multi_rank_path_on_one_device():
     assert out["n_gpus"] == 1 and "C5 R-MAT scale 18" in out["config"]["workload"]
     assert out["exchange"]["exchange"] == MG.EXCHANGE_RCCL and out["exchange"]["carry_bytes_per_step"] == 8
     assert out["roofline"]["kernel_ms"]["tile"] > 0 and out["single_gpu_same_workload"]["ms_per_step"] > 0
+    assert out["hot_column_plan"]["value"] > 0 and out["hot_column_plan"]["setup_ms_max_over_ranks"] > 0

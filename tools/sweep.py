@@ -10,8 +10,9 @@ import torch
 import merge_spmv_amd as M
 from merge_spmv_amd import generators as G
 
-SHAPES = {4: [(256, 7), (256, 9), (256, 11), (256, 15)],             # product shapes; the dev build (MSPMV_LIB=libmspmv_dev.so) adds 256x5 / 128x7 / 512x7
-          8: [(256, 5), (256, 7), (256, 9), (256, 11)]}
+SHAPES = {4: [(256, 7), (256, 11)], 8: [(256, 7), (256, 11)]}       # product shapes
+if "dev" in os.environ.get("MSPMV_LIB", ""):                         # the dev build (MSPMV_LIB=.../libmspmv_dev.so) has the sweep shapes
+    SHAPES = {4: [(256, 7), (256, 11), (256, 9), (256, 15), (256, 5), (128, 7), (512, 7)], 8: [(256, 7), (256, 11), (256, 5), (256, 9), (256, 3), (128, 5), (512, 5)]}
 
 
 def workloads(names):
