@@ -23,7 +23,9 @@
  *     once per call on entry, and the opt-in event profiler;
  *   - all array pointers are DEVICE pointers; d_row_offsets has rows+1 entries
  *     ([0]=0, [rows]=nnz, non-decreasing), 0-based int32 column indices,
- *     duplicates allowed (sparse_matrix.h:645-650,666-728);
+ *     duplicates allowed (sparse_matrix.h:645-650,666-728); d_x holds cols
+ *     readable entries (a tiny x -- cols * sizeof(value) <= 4 KB -- is copied
+ *     to LDS whole, whether or not every column is referenced);
  *   - y is fully overwritten: y = A*x (alpha=1, beta=0 as
  *     device_spmv.cuh:155-156 forces); rows without entries get exactly 0;
  *   - asynchronous on `stream` unless debug_sync != 0 (then every kernel is

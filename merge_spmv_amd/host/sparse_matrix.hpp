@@ -251,9 +251,9 @@ struct CooMatrix {
                 char *s = l;
                 while (*s == ' ' || *s == '\t') ++s;
                 if (*s >= '1' && *s <= '9') {
-                    int v = 0, digits = 0;
-                    while (*s >= '0' && *s <= '9' && digits < 10) { v = v * 10 + (*s - '0'); ++s; ++digits; }
-                    if (digits <= 9 && !(*s >= '0' && *s <= '9')) { *t = s; return v; }
+                    int v = 0, digits = 0;          // (stops after 9 digits: 999 999 999 fits an int, a tenth digit would not)
+                    while (*s >= '0' && *s <= '9' && digits < 9) { v = v * 10 + (*s - '0'); ++s; ++digits; }
+                    if (!(*s >= '0' && *s <= '9')) { *t = s; return v; }
                 }
                 return (int) strtol(l, t, 0);
             };
