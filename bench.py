@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--no-plan", action="store_true", help="skip the prepared_plan sub-record (N = 1, c2)")
     ap.add_argument("--no-single-gpu-leg", action="store_true",
                     help="N > 1, c5: skip rank 0's run of the WHOLE matrix alone afterwards (about 15 s during which the other ranks idle)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"],
+                    help="N > 1: how the C operator exchanges the boundary-row carries -- one RCCL all-gather per step (default), or the hipIpc "
+                         "peer backend (carries written straight into the owner's mailbox, step tags instead of a collective; never timed over links)")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records (the other single-GPU configurations)")
     ap.add_argument("--configs-budget", type=float, default=150.0, help="seconds the `configs` leg may take before it stops starting new ones")
     ap.add_argument("--dist-timeout", type=int, default=900, help="N > 1: seconds a collective may block before the job aborts")
@@ -348,16 +351,23 @@ def main():
 
         def op_sync():
             torch.cuda.synchronize()
-    elif backend == "nccl" and not one_device:
-        # the C multi-GPU operator, one part per process; RCCL communicator over the ranks
+    elif (backend == "nccl" and not one_device) or args.exchange == "ipc":
+        # the C multi-GPU operator, one part per process
         local_rows, local_nnz = shard.local_rows, shard.local_nnz
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        plan = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
-                         id128=bytes(idt.cpu().numpy().tobytes()))
+        if args.exchange == "ipc":
+            # hipIpc peer backend: no collective library in the step (works with all ranks on one device too)
+            plan = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_IPC)
+        else:
+            # RCCL communicator over the ranks
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            plan = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
+                             id128=bytes(idt.cpu().numpy().tobytes()))
         plan.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
+        if args.exchange == "ipc":
+            plan.ipc_connect()
         plan.x(0).copy_(x)
         torch.cuda.synchronize()
         exchange = plan.info()
@@ -529,7 +539,8 @@ def main():
         if exchange is not None:
             out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
             if isinstance(exchange.get("exchange"), int):
-                out["exchange"]["backend"] = {1: "RCCL ncclAllGather (1 element per rank) below the C ABI", 2: "peer reads"}.get(exchange["exchange"])
+                out["exchange"]["backend"] = {1: "RCCL ncclAllGather (1 element per rank) below the C ABI", 2: "peer reads",
+                                              3: "hipIpc peer writes into the owner's mailbox, step-tagged (no collective)"}.get(exchange["exchange"])
         if per_rank is not None:
             out["per_rank"] = per_rank
         if hot is not None:

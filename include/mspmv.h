@@ -345,6 +345,17 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries,
  *                           that reads the carries straight out of the peers' memory over xGMI;
  *   MSPMV_MG_EXCHANGE_RCCL  one ncclAllGather of a scalar per part (needs distinct devices; librccl is loaded
  *                           on first use, the library has no link-time dependency on it);
+ *   MSPMV_MG_EXCHANGE_IPC   any split of the parts over processes (typically one process per GPU), no collective library:
+ *                           after creating its plan every process calls mspmv_mg_plan_ipc_export, the launcher gathers the
+ *                           blobs (MPI / torch.distributed / a file -- anything), and every process passes ALL of them to
+ *                           mspmv_mg_plan_ipc_import, which opens the peers' x replicas and mailbox blocks through hipIpc.
+ *                           A step is then the SpMV + one tiny kernel writing the carry, tagged with the step number,
+ *                           straight into its owner's mailbox (a peer write) + one tiny kernel on the owner that waits for
+ *                           the tags of its sources, adds them in part order and acknowledges; the row all-gather is the
+ *                           PEER backend's pushes fenced by step-tagged flags.  Nothing on the host, no rendezvous; a
+ *                           producer runs at most two steps ahead of its consumer.  Waits are bounded (seconds):
+ *                           mspmv_mg_synchronize returns hipErrorLaunchFailure if one ran out.  (HSA_ENABLE_IPC_MODE_LEGACY=0
+ *                           where the host driver only supports dmabuf IPC.)
  *   MSPMV_MG_EXCHANGE_AUTO  PEER when the process holds every part, else RCCL.
  * mspmv_mg_allgather_rows (square matrices): x <- y on every replica -- PEER: each part
  * pushes its owned rows into every replica (direct peer writes, unpadded); RCCL: grouped ncclBroadcast.
@@ -355,6 +366,7 @@ typedef struct mspmv_mg_plan mspmv_mg_plan_t;
 #define MSPMV_MG_EXCHANGE_AUTO 0
 #define MSPMV_MG_EXCHANGE_RCCL 1
 #define MSPMV_MG_EXCHANGE_PEER 2
+#define MSPMV_MG_EXCHANGE_IPC  3
 
 typedef struct mspmv_mg_info {
     int32_t parts, local_parts, exchange /* backend in effect */, value_bytes, replicas, reserved;
@@ -368,6 +380,10 @@ int mspmv_mg_unique_id(void *id128);
 int mspmv_mg_plan_create(mspmv_mg_plan_t **plan, int32_t parts, int32_t local_parts, const int32_t *part_ids,
                          const int32_t *device_ids, const int64_t *row_split, const int64_t *nz_split,
                          int64_t cols, int32_t value_bytes, int32_t exchange, const void *id128);
+/* IPC backend: blob == NULL -> *blob_bytes = the size of this process's blob; else the blob is written.  _import takes `count`
+ * blobs laid out `blob_stride` bytes apart (every process's, its own included, in any order), once. */
+int mspmv_mg_plan_ipc_export(mspmv_mg_plan_t *plan, void *blob, size_t *blob_bytes);
+int mspmv_mg_plan_ipc_import(mspmv_mg_plan_t *plan, const void *blobs, int32_t count, size_t blob_stride);
 int mspmv_mg_plan_set_part(mspmv_mg_plan_t *plan, int32_t local_index, const void *d_values,
                            const int32_t *d_local_row_offsets, const int32_t *d_column_indices);
 void *mspmv_mg_plan_x(mspmv_mg_plan_t *plan, int32_t local_index);

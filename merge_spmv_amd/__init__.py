@@ -143,6 +143,10 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_mg_plan_set_part.argtypes = [vp, i32, vp, vp, vp]
     lib.mspmv_mg_plan_hot_columns.restype = ctypes.c_int
     lib.mspmv_mg_plan_hot_columns.argtypes = [vp, i32]
+    lib.mspmv_mg_plan_ipc_export.restype = ctypes.c_int
+    lib.mspmv_mg_plan_ipc_export.argtypes = [vp, vp, sz_p]
+    lib.mspmv_mg_plan_ipc_import.restype = ctypes.c_int
+    lib.mspmv_mg_plan_ipc_import.argtypes = [vp, vp, i32, ctypes.c_size_t]
     for name in ("mspmv_mg_plan_x", "mspmv_mg_plan_y", "mspmv_mg_plan_stream"):
         getattr(lib, name).restype = vp
         getattr(lib, name).argtypes = [vp, i32]

@@ -23,10 +23,19 @@
 //         inside ncclGroupStart/End when the process holds several parts, then the same add kernel
 //         reading the gathered array.  librccl is dlopen'ed on first use, so the single-GPU library has
 //         no link-time dependency on it (inside a torch process that is torch's own librccl.so.1).
+//   IPC   one process per GPU, no collective library: every process exports hipIpc handles of its x replica and of a small
+//         mailbox block (mspmv_mg_plan_ipc_export), the launcher ships the blobs, every process opens its peers'
+//         (mspmv_mg_plan_ipc_import).  A step is then the part's SpMV + ONE tiny kernel that writes the part's carry, tagged
+//         with the step number, straight into the mailbox of the part that owns the row (a peer write over xGMI) + ONE
+//         tiny kernel on the owner that waits for the tags of its sources, adds them in part order and acknowledges.  Step
+//         tags instead of events or collectives: nothing on the host, no rendezvous; a producer may run at most two steps
+//         ahead of its consumer (two slots per source, credit = the consumer's acknowledgement).  Waits are bounded.
 // mspmv_mg_allgather_rows turns the row-sharded y into the replicated x of the next
 // SpMV: PEER = every part pushes its owned rows straight into every replica of x (direct writes over the
 // fully connected xGMI, unpadded, no host loop); RCCL = G grouped ncclBroadcast calls (the all-gather-v
-// idiom), again unpadded and written in place.
+// idiom), again unpadded and written in place; IPC = the same pushes into the peers' opened replicas, fenced by two
+// step-tagged flags per pair ("my SpMV of step s has read x" before anyone overwrites it, "my rows of step s are in your
+// x" before the next SpMV reads it).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -120,6 +129,82 @@ __global__ __launch_bounds__(256) void mg_push_rows_kernel(const V *__restrict__
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = y[i];
 }
 
+// ---- IPC backend: the mailbox block every part shares with its peers (device memory, opened by them through hipIpc) ----
+constexpr int IPC_SLOTS = 2;                         // a producer may run this many steps ahead of its consumer
+struct IpcBlock {
+    unsigned long long carry[MSPMV_MG_MAX_PARTS][IPC_SLOTS][2];   // [source part][step & 1]: the source's carry as a record tagged with the step
+    unsigned long long carry_ack[MSPMV_MG_MAX_PARTS];             // [consumer part]: the last step whose carry OF THIS PART that consumer has taken
+    unsigned long long spmv_done[MSPMV_MG_MAX_PARTS];             // [part]: the last step whose SpMV that part has finished (it no longer reads its x)
+    unsigned long long rows_pushed[MSPMV_MG_MAX_PARTS];           // [part]: the last step whose rows that part has written into THIS part's x
+};
+constexpr long long IPC_MAX_SPINS = 1LL << 24;       // x ~0.3 us: seconds; running out raises the part's error word (mspmv_mg_synchronize reports it)
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ bool spin_until_at_least(const unsigned long long *p, unsigned long long want)
+{
+    for (long long i = 0; i < IPC_MAX_SPINS; ++i) { if (sys_load(p) >= want) return true; __builtin_amdgcn_s_sleep(8); }
+    return false;
+}
+template <typename V> __device__ __forceinline__ unsigned long long value_bits(V v);
+template <> __device__ __forceinline__ unsigned long long value_bits<float>(float v) { return __builtin_bit_cast(unsigned, v); }
+template <> __device__ __forceinline__ unsigned long long value_bits<double>(double v) { return __builtin_bit_cast(unsigned long long, v); }
+template <typename V> __device__ __forceinline__ V bits_value(unsigned long long b);
+template <> __device__ __forceinline__ float bits_value<float>(unsigned long long b) { return __builtin_bit_cast(float, (unsigned) b); }
+template <> __device__ __forceinline__ double bits_value<double>(unsigned long long b) { return __builtin_bit_cast(double, b); }
+
+// producer: this part's carry of step `step` -> the mailboxes of the parts that own the row it belongs to.  slot[k] points at
+// carry[me][step & 1] inside consumer k's block (peer memory), ack[k] at carry_ack[consumer k] inside MY block.
+template <typename V>
+__global__ void ipc_push_carry_kernel(const V *__restrict__ y_last, unsigned long long *const *__restrict__ slot,
+                                      const unsigned long long *const *__restrict__ ack, int n, unsigned long long step, int *error)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long bits = value_bits<V>(*y_last);
+    const unsigned tag = (unsigned) step;
+    for (int k = 0; k < n; ++k) {
+        // credit: the consumer has taken what this slot held two steps ago
+        if (step > IPC_SLOTS && !spin_until_at_least(ack[k], step - IPC_SLOTS)) { *error = 1; return; }
+        unsigned long long *rec = slot[k] + 2 * (step & (IPC_SLOTS - 1));
+        sys_store(rec, ((unsigned long long) tag << 32) | (unsigned) (bits >> 32));
+        sys_store(rec + 1, ((unsigned long long) tag << 32) | (unsigned) bits);
+    }
+}
+// consumer: y_first[0] += the carries of this step from the source parts, in part order; then acknowledge.  rec[k] points at
+// carry[source k] inside MY block, ack[k] at carry_ack[me] inside source k's block (peer memory).
+template <typename V>
+__global__ void ipc_take_carry_kernel(V *__restrict__ y_first, const unsigned long long *const *__restrict__ rec,
+                                      unsigned long long *const *__restrict__ ack, int n, unsigned long long step, int *error)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned tag = (unsigned) step;
+    V acc = *y_first;
+    for (int k = 0; k < n; ++k) {
+        const unsigned long long *r = rec[k] + 2 * (step & (IPC_SLOTS - 1));
+        unsigned long long w0 = 0, w1 = 0; bool ok = false;
+        for (long long i = 0; i < IPC_MAX_SPINS; ++i) {
+            w0 = sys_load(r); w1 = sys_load(r + 1);
+            if ((unsigned) (w0 >> 32) == tag && (unsigned) (w1 >> 32) == tag) { ok = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) { *error = 2; acc = (V) __builtin_nan(""); break; }
+        acc += bits_value<V>(((w0 & 0xffffffffull) << 32) | (w1 & 0xffffffffull));
+        sys_store(ack[k], step);
+    }
+    *y_first = acc;
+}
+// flag[k][me] = step in every peer's block (k = the other parts): "done" / "pushed" announcements
+__global__ void ipc_announce_kernel(unsigned long long *const *__restrict__ flag, int n, unsigned long long step)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) sys_store(flag[k], step);
+}
+// wait until every listed counter of MY block has reached `step`
+__global__ void ipc_wait_kernel(const unsigned long long *const *__restrict__ flag, int n, unsigned long long step, int *error)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && !spin_until_at_least(flag[k], step)) *error = 3;
+}
+
 struct Part {
     int id = 0, device = 0, replica = 0;
     long long row_begin = 0, row_end = 0, nz_begin = 0, nz_end = 0;
@@ -139,13 +224,24 @@ struct Part {
     bool applied_valid = false, pushed_valid = false, done_valid = false;
     ncclComm_t comm = nullptr;
     void *hot = nullptr; size_t hot_bytes = 0;      // hot-column plan of the part (mspmv_mg_plan_hot_columns): its own temp, indices, x
+    // IPC backend
+    IpcBlock *block = nullptr;            // this part's mailbox block (device memory, exported)
+    int *ipc_error = nullptr;             // device word: a bounded wait ran out
+    void **ipc_tables = nullptr;          // device array holding the pointer tables below, filled by mspmv_mg_plan_ipc_import
+    int n_push = 0, n_take = 0, n_peers = 0, n_push_rows = 0;
+    std::vector<int> consumers;           // parts that take this part's carry
 };
 
 struct Replica { int device = 0; void *x = nullptr; };
 
 }  // namespace
 
+struct IpcPeer { int part = -1; IpcBlock *block = nullptr; void *x = nullptr; bool opened = false; };
+
 struct mspmv_mg_plan {
+    std::vector<IpcPeer> peers;           // IPC backend: every part of the job (own parts: local pointers)
+    bool ipc_ready = false;
+    unsigned long long allgather_step = 0;    // IPC: the last step whose rows were pushed (the next SpMV waits for the peers' pushes)
     int parts = 0, value_bytes = 0, exchange = 0;
     long long rows = 0, cols = 0;
     bool whole = false;                   // this process holds every part
@@ -168,9 +264,17 @@ int run_spmv(mspmv_mg_plan *plan)
 {
     CallExtra ex; ex.phase = PHASE_SKIP_COORDS;
     // 1. every part's local SpMV (its last local row is the part's carry)
+    const bool ipc = plan->exchange == MSPMV_MG_EXCHANGE_IPC;
+    if (ipc && !plan->ipc_ready) return kErrInvalid;
+    const unsigned long long step = plan->steps + 1;
     for (Part &q : plan->local) {
         if (!q.attached) return kErrInvalid;
         MG_HIP(hipSetDevice(q.device));
+        if (ipc && q.n_peers > 0 && plan->allgather_step + 1 == step && step > 1) {
+            // the peers' rows of the previous step must be in this part's x before the SpMV reads it
+            hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, q.stream,
+                               reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 7 * MSPMV_MG_MAX_PARTS), q.n_peers, step - 1, q.ipc_error);
+        }
         // x must be complete (a preceding all-gather pushed into this device's replica from every part) and
         // nobody may still be reading what this SpMV overwrites (the carry readers of the previous step)
         for (Part &o : plan->local) {
@@ -196,7 +300,25 @@ int run_spmv(mspmv_mg_plan *plan)
                                (int32_t) plan->cols, q.local_nnz, (V) 1, (V) 0, false, q.stream, 0, ex);
         if (st != 0) return st;
         MG_HIP(hipEventRecord(q.done, q.stream)); q.done_valid = true;
+        if (ipc) {
+            const int vb = (int) sizeof(V);
+            // "my SpMV of this step has read x" -> every peer (a later row all-gather waits for it before overwriting x)
+            if (q.n_peers > 0)
+                hipLaunchKernelGGL(ipc_announce_kernel, dim3(1), dim3(64), 0, q.stream,
+                                   reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 4 * MSPMV_MG_MAX_PARTS), q.n_peers, step);
+            if (q.n_push > 0)
+                hipLaunchKernelGGL((ipc_push_carry_kernel<V>), dim3(1), dim3(64), 0, q.stream,
+                                   reinterpret_cast<const V *>(static_cast<const char *>(q.y) + (size_t) (q.local_rows - 1) * vb),
+                                   reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 0 * MSPMV_MG_MAX_PARTS),
+                                   reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 1 * MSPMV_MG_MAX_PARTS), q.n_push, step, q.ipc_error);
+            if (q.n_take > 0)
+                hipLaunchKernelGGL((ipc_take_carry_kernel<V>), dim3(1), dim3(64), 0, q.stream, static_cast<V *>(q.y),
+                                   reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 2 * MSPMV_MG_MAX_PARTS),
+                                   reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 3 * MSPMV_MG_MAX_PARTS), q.n_take, step, q.ipc_error);
+            MG_HIP(hipGetLastError());
+        }
     }
+    if (ipc) { ++plan->steps; return 0; }
     if (plan->parts == 1 && plan->exchange != MSPMV_MG_EXCHANGE_RCCL) { ++plan->steps; return 0; }
     // 2. the one exchange + the owners' adds (a one-part RCCL plan still issues its all-gather: that is how a
     //    single-GPU box exercises the RCCL path end to end)
@@ -245,6 +367,29 @@ int run_allgather(mspmv_mg_plan *plan)
         MG_NCCL(r.GroupEnd());
         return 0;
     }
+    if (plan->exchange == MSPMV_MG_EXCHANGE_IPC) {
+        if (!plan->ipc_ready || plan->steps == 0) return kErrInvalid;
+        const unsigned long long step = plan->steps;              // the step whose y becomes x
+        for (Part &q : plan->local) {
+            MG_HIP(hipSetDevice(q.device));
+            // nobody may still be reading x: every peer has announced its SpMV of this step
+            if (q.n_peers > 0)
+                hipLaunchKernelGGL(ipc_wait_kernel, dim3(1), dim3(64), 0, q.stream,
+                                   reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 6 * MSPMV_MG_MAX_PARTS), q.n_peers, step, q.ipc_error);
+            if (q.owned > 0) {
+                const unsigned grid = (unsigned) std::min<long long>((q.owned + 255) / 256, 1024);
+                hipLaunchKernelGGL((mg_push_rows_kernel<V>), dim3(grid, (unsigned) q.n_push_rows), dim3(256), 0, q.stream,
+                                   static_cast<const V *>(q.y), reinterpret_cast<V *const *>(q.push_table), q.owned);
+            }
+            // (a kernel boundary on this stream: the rows are written before the announcement goes out)
+            if (q.n_peers > 0)
+                hipLaunchKernelGGL(ipc_announce_kernel, dim3(1), dim3(64), 0, q.stream,
+                                   reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 5 * MSPMV_MG_MAX_PARTS), q.n_peers, step);
+            MG_HIP(hipGetLastError());
+        }
+        plan->allgather_step = step;
+        return 0;
+    }
     // PEER: nobody may still be reading x (every part's SpMV done) before the pushes overwrite it
     for (Part &q : plan->local) {
         MG_HIP(hipSetDevice(q.device));
@@ -274,9 +419,12 @@ int destroy(mspmv_mg_plan *plan)
         if (q.applied) (void) hipEventDestroy(q.applied);
         if (q.pushed) (void) hipEventDestroy(q.pushed);
         (void) hipFree(q.temp); (void) hipFree(q.y); (void) hipFree(q.carries); (void) hipFree(q.src_table); (void) hipFree(q.push_table);
-        (void) hipFree(q.hot);
+        (void) hipFree(q.hot); (void) hipFree(q.block); (void) hipFree(q.ipc_error); (void) hipFree(q.ipc_tables);
         if (q.stream) (void) hipStreamDestroy(q.stream);
     }
+    for (IpcPeer &peer : plan->peers)
+        if (peer.opened) { if (peer.block) (void) hipIpcCloseMemHandle(peer.block); if (peer.x) (void) hipIpcCloseMemHandle(peer.x); }
+    (void) hipGetLastError();
     for (Replica &r : plan->replicas) { (void) hipSetDevice(r.device); (void) hipFree(r.x); }
     delete plan;
     return 0;
@@ -302,7 +450,7 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
 {
     if (!out || parts < 1 || parts > MSPMV_MG_MAX_PARTS || local_parts < 1 || local_parts > parts || !part_ids || !device_ids ||
         !row_split || !nz_split || cols < 0 || cols > 0x7fffffffLL || (value_bytes != 4 && value_bytes != 8) || exchange < 0 ||
-        exchange > MSPMV_MG_EXCHANGE_PEER)
+        exchange > MSPMV_MG_EXCHANGE_IPC)
         return kErrInvalid;
     *out = nullptr;
     int ndev = 0, prev_dev = 0;
@@ -310,7 +458,7 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
     MG_HIP(hipGetDevice(&prev_dev));
     mspmv_mg_plan *plan = new mspmv_mg_plan;
     plan->parts = parts; plan->value_bytes = value_bytes; plan->cols = cols; plan->rows = row_split[parts];
-    plan->whole = local_parts == parts && !id128;     // (an id makes even a 1-rank job take the multi-process path)
+    plan->whole = local_parts == parts && !id128 && exchange != MSPMV_MG_EXCHANGE_IPC;     // (an id / the IPC backend make even a 1-rank job take the multi-process path)
     plan->row_split.assign(row_split, row_split + parts + 1);
     plan->nz_split.assign(nz_split, nz_split + parts + 1);
     auto fail = [&](int code) { destroy(plan); (void) hipSetDevice(prev_dev); return code; };
@@ -347,7 +495,7 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
                     }
                 }
     }
-    if (exchange == MSPMV_MG_EXCHANGE_PEER && local_parts != parts) return fail(kErrInvalid);       // peers live in this process
+    if (exchange == MSPMV_MG_EXCHANGE_PEER && local_parts != parts) return fail(kErrInvalid);       // peers live in this process (other processes: MSPMV_MG_EXCHANGE_IPC)
     if (exchange == MSPMV_MG_EXCHANGE_RCCL && !distinct_devices) return fail(kErrInvalid);  // one RCCL rank per device
     if (exchange == MSPMV_MG_EXCHANGE_RCCL && !plan->whole && !id128) return fail(kErrInvalid);
     if (exchange == MSPMV_MG_EXCHANGE_RCCL && !rccl().ok) return fail(kErrNoRccl);
@@ -388,10 +536,21 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
             if (hipMemsetAsync(q.carries, 0, (size_t) parts * vb, q.stream) != hipSuccess) return fail(kErrInvalid);
         }
     }
+    if (exchange == MSPMV_MG_EXCHANGE_IPC)
+        for (Part &q : plan->local) {
+            if (hipSetDevice(q.device) != hipSuccess) return fail(kErrInvalid);
+            if (hipMalloc(reinterpret_cast<void **>(&q.block), sizeof(IpcBlock)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&q.ipc_error), 256) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&q.ipc_tables), sizeof(void *) * 8 * MSPMV_MG_MAX_PARTS) != hipSuccess)
+                return fail(hipErrorOutOfMemory);
+            if (hipMemset(q.block, 0, sizeof(IpcBlock)) != hipSuccess || hipMemset(q.ipc_error, 0, 256) != hipSuccess) return fail(kErrInvalid);
+            // who takes this part's carry: the first later part that owns a row, if that row is the one this part leaves open
+            for (int c = q.id + 1; c < parts; ++c)
+                if (row_split[c + 1] > row_split[c]) { if (row_split[c] == row_split[q.id + 1]) q.consumers.push_back(c); break; }
+        }
     // address tables (all buffers they point into are plan-owned, so they are fixed for the plan's life)
     for (Part &q : plan->local) {
         if (hipSetDevice(q.device) != hipSuccess) return fail(kErrInvalid);
-        if (q.nsrc > 0) {
+        if (q.nsrc > 0 && exchange != MSPMV_MG_EXCHANGE_IPC) {
             std::vector<const void *> src;
             for (int j : q.sources) {
                 if (exchange == MSPMV_MG_EXCHANGE_PEER) {
@@ -462,6 +621,112 @@ int mspmv_mg_plan_set_part(mspmv_mg_plan_t *plan, int32_t i, const void *d_value
     q.attached = st == 0;
     (void) hipSetDevice(prev);
     return st;
+}
+
+// ---- IPC backend: handle exchange.  A blob = int32 count, then per local part { int32 part, int32 device, 64-byte handle of the
+// mailbox block, 64-byte handle of the x replica }.
+struct IpcEntry { int32_t part, device; hipIpcMemHandle_t block, x; };
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "blob layout");
+
+int mspmv_mg_plan_ipc_export(mspmv_mg_plan_t *plan, void *blob, size_t *blob_bytes)
+{
+    if (!plan || !blob_bytes || plan->exchange != MSPMV_MG_EXCHANGE_IPC) return kErrInvalid;
+    const size_t need = 8 + plan->local.size() * sizeof(IpcEntry);
+    if (!blob) { *blob_bytes = need; return 0; }
+    if (*blob_bytes < need) return kErrInvalid;
+    int prev = 0; MG_HIP(hipGetDevice(&prev));
+    char *out = static_cast<char *>(blob);
+    const int32_t n = (int32_t) plan->local.size();
+    memset(out, 0, need); memcpy(out, &n, 4);
+    for (size_t i = 0; i < plan->local.size(); ++i) {
+        Part &q = plan->local[i];
+        MG_HIP(hipSetDevice(q.device));
+        IpcEntry e; memset(&e, 0, sizeof(e)); e.part = q.id; e.device = q.device;
+        MG_HIP(hipIpcGetMemHandle(&e.block, q.block));
+        MG_HIP(hipIpcGetMemHandle(&e.x, plan->replicas[q.replica].x));
+        memcpy(out + 8 + i * sizeof(IpcEntry), &e, sizeof(e));
+    }
+    (void) hipSetDevice(prev);
+    *blob_bytes = need;
+    return 0;
+}
+
+int mspmv_mg_plan_ipc_import(mspmv_mg_plan_t *plan, const void *blobs, int32_t count, size_t blob_stride)
+{
+    if (!plan || !blobs || count < 1 || plan->exchange != MSPMV_MG_EXCHANGE_IPC || plan->ipc_ready) return kErrInvalid;
+    int prev = 0; MG_HIP(hipGetDevice(&prev));
+    plan->peers.assign((size_t) plan->parts, IpcPeer());
+    for (Part &q : plan->local) { IpcPeer &me = plan->peers[(size_t) q.id]; me.part = q.id; me.block = q.block; me.x = plan->replicas[q.replica].x; }
+    struct Opened { hipIpcMemHandle_t h; void *ptr; };
+    std::vector<Opened> opened;                      // (two parts of one remote process may share an x replica: open each handle once)
+    auto open_handle = [&](const hipIpcMemHandle_t &h, void **out) -> int {
+        for (const Opened &o : opened) if (memcmp(&o.h, &h, sizeof(h)) == 0) { *out = o.ptr; return 0; }
+        void *ptr = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void) hipGetLastError(); return (int) e; }
+        opened.push_back(Opened{h, ptr}); *out = ptr;
+        return 0;
+    };
+    MG_HIP(hipSetDevice(plan->local[0].device));
+    for (int b = 0; b < count; ++b) {
+        const char *in = static_cast<const char *>(blobs) + (size_t) b * blob_stride;
+        int32_t n = 0; memcpy(&n, in, 4);
+        if (n < 0 || 8 + (size_t) n * sizeof(IpcEntry) > blob_stride) { (void) hipSetDevice(prev); return kErrInvalid; }
+        for (int i = 0; i < n; ++i) {
+            IpcEntry e; memcpy(&e, in + 8 + (size_t) i * sizeof(IpcEntry), sizeof(e));
+            if (e.part < 0 || e.part >= plan->parts) { (void) hipSetDevice(prev); return kErrInvalid; }
+            IpcPeer &peer = plan->peers[(size_t) e.part];
+            if (peer.part == e.part) continue;                       // one of this process's own parts
+            void *blk = nullptr, *x = nullptr;
+            int st = open_handle(e.block, &blk);
+            if (st == 0) st = open_handle(e.x, &x);
+            if (st != 0) { (void) hipSetDevice(prev); return st; }
+            peer.part = e.part; peer.block = static_cast<IpcBlock *>(blk); peer.x = x; peer.opened = true;
+        }
+    }
+    for (const IpcPeer &peer : plan->peers) if (peer.part < 0) { (void) hipSetDevice(prev); return kErrInvalid; }     // a part nobody exported
+    // every peer's pointers are known: the tables of the step kernels
+    const size_t vb = (size_t) plan->value_bytes;
+    for (Part &q : plan->local) {
+        MG_HIP(hipSetDevice(q.device));
+        std::vector<void *> t((size_t) 8 * MSPMV_MG_MAX_PARTS, nullptr);
+        auto at = [&](int table, int k) -> void *& { return t[(size_t) table * MSPMV_MG_MAX_PARTS + (size_t) k]; };
+        q.n_push = 0;
+        for (int c : q.consumers) {
+            at(0, q.n_push) = &plan->peers[(size_t) c].block->carry[q.id][0][0];         // where my carry goes
+            at(1, q.n_push) = &q.block->carry_ack[c];                                    // where the consumer acknowledges
+            ++q.n_push;
+        }
+        q.n_take = 0;
+        for (int src : q.sources) {
+            at(2, q.n_take) = &q.block->carry[src][0][0];
+            at(3, q.n_take) = &plan->peers[(size_t) src].block->carry_ack[q.id];
+            ++q.n_take;
+        }
+        q.n_peers = 0;
+        for (int o = 0; o < plan->parts; ++o) {
+            if (o == q.id) continue;
+            at(4, q.n_peers) = &plan->peers[(size_t) o].block->spmv_done[q.id];
+            at(5, q.n_peers) = &plan->peers[(size_t) o].block->rows_pushed[q.id];
+            at(6, q.n_peers) = &q.block->spmv_done[o];
+            at(7, q.n_peers) = &q.block->rows_pushed[o];
+            ++q.n_peers;
+        }
+        MG_HIP(hipMemcpy(q.ipc_tables, t.data(), t.size() * sizeof(void *), hipMemcpyHostToDevice));
+        // row pushes: this part's row range inside every distinct replica of x in the job
+        std::vector<void *> dst;
+        for (const IpcPeer &peer : plan->peers) {
+            void *d = static_cast<char *>(peer.x) + (size_t) q.row_begin * vb;
+            if (std::find(dst.begin(), dst.end(), d) == dst.end()) dst.push_back(d);
+        }
+        q.n_push_rows = (int) dst.size();
+        if (q.push_table) { (void) hipFree(q.push_table); q.push_table = nullptr; }
+        MG_HIP(hipMalloc(reinterpret_cast<void **>(&q.push_table), dst.size() * sizeof(void *)));
+        MG_HIP(hipMemcpy(q.push_table, dst.data(), dst.size() * sizeof(void *), hipMemcpyHostToDevice));
+    }
+    (void) hipSetDevice(prev);
+    plan->ipc_ready = true;
+    return 0;
 }
 
 int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable)
@@ -548,6 +813,13 @@ int mspmv_mg_synchronize(mspmv_mg_plan_t *plan)
         (void) hipSetDevice(q.device);
         const hipError_t e = hipStreamSynchronize(q.stream);
         if (e != hipSuccess && st == 0) st = (int) e;
+        if (q.ipc_error && st == 0) {
+            int h = 0;
+            if (hipMemcpy(&h, q.ipc_error, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h != 0) {
+                fprintf(stderr, "mspmv_mg: part %d gave up waiting for a peer (code %d: 1 carry credit, 2 carry, 3 row all-gather flag)\n", q.id, h);
+                st = hipErrorLaunchFailure;
+            }
+        }
     }
     (void) hipSetDevice(prev);
     return st;

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import load_library, _check, CsrMVWorkspace, DeviceSpmv, csrmv, _stream_handle, _value_bytes, MspmvError
 
-EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_PEER = 0, 1, 2
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_PEER, EXCHANGE_IPC = 0, 1, 2, 3
 
 
 def partition(row_offsets_i64: np.ndarray, parts: int):
@@ -150,6 +150,28 @@ class MgPlan:
         info = _MgInfo()
         _check(load_library().mspmv_mg_plan_info(self._handle, ctypes.byref(info)), "mspmv_mg_plan_info")
         return {name: getattr(info, name) for name, _ in _MgInfo._fields_ if name != "reserved"}
+
+    def ipc_export(self) -> bytes:
+        """this process's hipIpc handles (x replicas, mailbox blocks) as one blob (mspmv_mg_plan_ipc_export)"""
+        size = ctypes.c_size_t(0)
+        _check(load_library().mspmv_mg_plan_ipc_export(self._handle, None, ctypes.byref(size)), "mspmv_mg_plan_ipc_export")
+        buf = ctypes.create_string_buffer(size.value)
+        _check(load_library().mspmv_mg_plan_ipc_export(self._handle, buf, ctypes.byref(size)), "mspmv_mg_plan_ipc_export")
+        return buf.raw[: size.value]
+
+    def ipc_import(self, blobs):
+        """every process's blob (its own included, any order): opens the peers' memory (mspmv_mg_plan_ipc_import)"""
+        stride = max(len(b) for b in blobs)
+        flat = b"".join(b + b"\0" * (stride - len(b)) for b in blobs)
+        _check(load_library().mspmv_mg_plan_ipc_import(self._handle, flat, len(blobs), stride), "mspmv_mg_plan_ipc_import")
+
+    def ipc_connect(self, group=None):
+        """export, all-gather the blobs over torch.distributed (any backend), import: one call per rank"""
+        import torch.distributed as dist
+        mine = self.ipc_export()
+        blobs = [None] * dist.get_world_size(group)
+        dist.all_gather_object(blobs, mine, group=group)
+        self.ipc_import(blobs)
 
     def hot_columns(self, enable: bool = True):
         """renumber every local part's columns by reference count (mspmv_mg_plan_hot_columns)"""

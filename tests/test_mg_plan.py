@@ -281,6 +281,22 @@ def _run_bench(env_extra, nproc, *args, timeout=600):
 
 
 @gpu
+@pytest.mark.parametrize("kind,prec,nproc", [("giant", "f64", 2), ("short", "f32", 2), ("empty_parts", "f64", 4)])
+def test_ipc_backend_two_processes_sharing_the_device(kind, prec, nproc):
+    """The hipIpc peer backend of the one-process-per-GPU form (MSPMV_MG_EXCHANGE_IPC): `nproc` processes, one part each, all on
+    cuda:0 of this box; carries go through hipIpc-opened mailboxes tagged with the step number, rows through the opened x
+    replicas.  The worker checks every row against the oracle for repeated and iterated SpMV (tests/mg_ipc_worker.py)."""
+    import subprocess, sys, socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "mg_ipc_worker.py"), kind, prec]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and f"IPC-OK {kind} {prec} {nproc}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@gpu
 def test_bench_multi_rank_path_on_one_device():
     """bench.py --gpus N (N > 1 runs BASELINE config 5, one R-MAT matrix cut N ways) end to end on this one-GPU box, at a
     reduced scale: (a) 2 ranks sharing the device, carries over gloo through the Python twin; (b) ONE rank forced through
@@ -292,6 +308,10 @@ def test_bench_multi_rank_path_on_one_device():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f64" and out["value"] > 0
     assert "C5 R-MAT scale 18" in out["config"]["workload"] and "merge-path diagonal split over 2 GPUs" in out["config"]["partition"]
     assert out["single_gpu_same_workload"]["n_gpus"] == 1 and out["single_gpu_same_workload"]["value"] > 0
+    # (c) 2 ranks sharing the device through the C operator's hipIpc backend (no collective in the step)
+    out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, 2, *small, "--exchange", "ipc")
+    assert out["n_gpus"] == 2 and out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["value"] > 0
+    assert out["hot_column_plan"]["value"] > 0 and out["per_rank"]["tile_ms_min"] > 0
     out = _run_bench({"MSPMV_BENCH_FORCE_MG": "1"}, 1, *small)
     assert out["n_gpus"] == 1 and "C5 R-MAT scale 18" in out["config"]["workload"]
     assert out["exchange"]["exchange"] == MG.EXCHANGE_RCCL and out["exchange"]["carry_bytes_per_step"] == 8
