@@ -351,32 +351,85 @@ def main():
 
         def op_sync():
             torch.cuda.synchronize()
-    elif (backend == "nccl" and not one_device) or args.exchange == "ipc":
-        # the C multi-GPU operator, one part per process
+    elif (backend == "nccl" and not one_device) or args.exchange == "ipc" or os.environ.get("MSPMV_BENCH_FORCE_C_OPERATOR") == "1":
+        # the C multi-GPU operator, one part per process.  The exchange asked for is tried first; if any rank fails to set it up or
+        # to run two trial steps with it, every rank falls back together (rccl -> ipc -> the Python twin over torch.distributed) and
+        # the record says so: a scaling run on a node this code has never met should still produce its numbers.
         local_rows, local_nnz = shard.local_rows, shard.local_nnz
-        if args.exchange == "ipc":
-            # hipIpc peer backend: no collective library in the step (works with all ranks on one device too)
-            plan = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_IPC)
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        def try_exchange(kind):
+            p, why = None, None
+            try:
+                if kind == "ipc":
+                    # hipIpc peer backend: no collective library in the step (works with all ranks on one device too)
+                    p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_IPC)
+                else:
+                    # RCCL communicator over the ranks
+                    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
+                    dist.broadcast(idt, 0)
+                    p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
+                                  id128=bytes(idt.cpu().numpy().tobytes()))
+                p.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
+                blob = p.ipc_export() if kind == "ipc" else None
+            except Exception as e:  # noqa: BLE001 - any failure means "fall back"
+                why = f"setup: {e}"
+            if not all_ok(why is None):
+                return p, why or "another rank failed during setup"
+            try:
+                if kind == "ipc":
+                    blobs = [None] * world
+                    dist.all_gather_object(blobs, blob)
+                    p.ipc_import(blobs)
+                p.x(0).copy_(x)
+                torch.cuda.synchronize()
+                for _ in range(2):
+                    p.csrmv()
+                p.synchronize(); torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                why = f"trial steps: {e}"
+            if not all_ok(why is None):
+                return p, why or "another rank failed in the trial steps"
+            return p, None
+
+        order = [args.exchange] + [k for k in ("rccl", "ipc") if k != args.exchange]
+        fallbacks = []
+        for kind in order:
+            plan, why = try_exchange(kind)
+            if why is None:
+                break
+            fallbacks.append({"exchange": kind, "failed": why[:300]})
+            if plan is not None:
+                try:
+                    plan.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            plan = None
+        if plan is not None:
+            exchange = plan.info()
+            if fallbacks:
+                exchange["fallbacks"] = fallbacks
+
+            def op():
+                plan.csrmv()
+
+            def op_sync():
+                plan.synchronize(); torch.cuda.synchronize()
         else:
-            # RCCL communicator over the ranks
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            plan = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
-                             id128=bytes(idt.cpu().numpy().tobytes()))
-        plan.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
-        if args.exchange == "ipc":
-            plan.ipc_connect()
-        plan.x(0).copy_(x)
-        torch.cuda.synchronize()
-        exchange = plan.info()
+            sharded = MG.ShardedCsrMV(shard, group=None)
+            exchange = {"exchange": "python twin over " + backend, "carry_bytes_per_step": world * vb, "fallbacks": fallbacks}
 
-        def op():
-            plan.csrmv()
+            def op():
+                sharded(x)
 
-        def op_sync():
-            plan.synchronize(); torch.cuda.synchronize()
+            def op_sync():
+                torch.cuda.synchronize()
     else:
         local_rows, local_nnz = shard.local_rows, shard.local_nnz
         sharded = MG.ShardedCsrMV(shard, group=None)
@@ -440,7 +493,11 @@ def main():
     # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
     single = None
     if mg and workload == "c5" and not args.no_single_gpu_leg:
+        y0 = None
         if plan is not None:
+            if rank == 0:
+                op_sync()
+                y0 = plan.y(0).clone()          # rank 0's owned rows of the last step (rows 0 .. of the whole matrix)
             plan.close()
         plan = None; shard = None; sharded = None
         torch.cuda.empty_cache()
@@ -459,6 +516,13 @@ def main():
             single = {"n_gpus": 1, "steps": k, "ms_per_step": round(sms, 5), "value": round(2.0 * nnz_total / (sms * 1e-3) / 1e9, 3),
                       "unit": "GFLOP/s", "speedup_of_this_job": round(sms / ms_per_step, 3),
                       "parallel_efficiency": round(sms / ms_per_step / world, 4)}
+            if y0 is not None:
+                # rank 0's tiles are the single-GPU call's first tiles, so its rows must match bit for bit (its last row, completed by
+                # the next ranks' carries, to within re-association)
+                ref = wy[:y0.numel()]
+                differ = int((ref != y0).sum().item())
+                single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": differ,
+                                                      "max_abs_diff": float((ref - y0).abs().max().item()) if y0.numel() else 0.0}
             del W, wws, wy
 
     # anything native code left in C stdio buffers (RCCL prints a version banner at communicator creation) goes out on
@@ -514,7 +578,7 @@ def main():
                                      f"{local_rows - 1} rows + {local_nnz} nonzeros on rank 0; one exchange of {world} carries per step")},
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": "tile_kernel_vec", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap (one launch per part)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": b_alg,
                          "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5),

@@ -539,7 +539,19 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
     if (exchange == MSPMV_MG_EXCHANGE_IPC)
         for (Part &q : plan->local) {
             if (hipSetDevice(q.device) != hipSuccess) return fail(kErrInvalid);
-            if (hipMalloc(reinterpret_cast<void **>(&q.block), sizeof(IpcBlock)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&q.ipc_error), 256) != hipSuccess ||
+            // the mailbox is polled by kernels of THIS device while kernels of other devices write it over the links: ordinary
+            // (coarse-grained) device memory is only coherent between agents at kernel boundaries, so the block is allocated
+            // uncached (else fine-grained); the plain allocation is the last resort and is only certain with all parts on one device
+            void *blk = nullptr;
+            if (hipExtMallocWithFlags(&blk, sizeof(IpcBlock), hipDeviceMallocUncached) != hipSuccess) {
+                (void) hipGetLastError(); blk = nullptr;
+                if (hipExtMallocWithFlags(&blk, sizeof(IpcBlock), hipDeviceMallocFinegrained) != hipSuccess) {
+                    (void) hipGetLastError(); blk = nullptr;
+                    if (hipMalloc(&blk, sizeof(IpcBlock)) != hipSuccess) return fail(hipErrorOutOfMemory);
+                }
+            }
+            q.block = static_cast<IpcBlock *>(blk);
+            if (hipMalloc(reinterpret_cast<void **>(&q.ipc_error), 256) != hipSuccess ||
                 hipMalloc(reinterpret_cast<void **>(&q.ipc_tables), sizeof(void *) * 8 * MSPMV_MG_MAX_PARTS) != hipSuccess)
                 return fail(hipErrorOutOfMemory);
             if (hipMemset(q.block, 0, sizeof(IpcBlock)) != hipSuccess || hipMemset(q.ipc_error, 0, 256) != hipSuccess) return fail(kErrInvalid);

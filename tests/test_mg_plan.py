@@ -311,6 +311,12 @@ def test_bench_multi_rank_path_on_one_device():
     # (c) 2 ranks sharing the device through the C operator's hipIpc backend (no collective in the step)
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, 2, *small, "--exchange", "ipc")
     assert out["n_gpus"] == 2 and out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["value"] > 0
+    # rank 0's tiles are the first tiles of the one-GPU call of the same job: its rows agree bit for bit
+    assert out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]["not_bitwise_equal"] <= 1
+    # (d) an exchange that cannot be set up (two RCCL ranks on one device are refused) makes every rank fall back together
+    out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                      "MSPMV_BENCH_FORCE_C_OPERATOR": "1"}, 2, *small, "--exchange", "rccl")
+    assert out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["exchange"]["fallbacks"][0]["exchange"] == "rccl" and out["value"] > 0
     assert out["hot_column_plan"]["value"] > 0 and out["per_rank"]["tile_ms_min"] > 0
     out = _run_bench({"MSPMV_BENCH_FORCE_MG": "1"}, 1, *small)
     assert out["n_gpus"] == 1 and "C5 R-MAT scale 18" in out["config"]["workload"]
