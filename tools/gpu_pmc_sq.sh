@@ -7,7 +7,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/sq_$TAG
 RAW=/tmp/sq_raw_$TAG
 rm -rf $OUT $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs $BARGS"
+# PROFILE_CMD overrides the profiled command (e.g. the gpu_spmv driver); PROFILE_MATCH (regex, default tile_kernel) selects the kernels
+BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs $BARGS"}
 i=0
 PMCS=${PMCS:-full}
 if [ "$PMCS" = "lds" ]; then
@@ -23,16 +24,18 @@ for pmc in "$@"; do
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $RAW/p$i -o bench -- $BENCH > $OUT/p$i.log 2>&1
   CC=$(find $RAW/p$i -name "*counter_collection.csv" | head -1)
   if [ -n "$CC" ]; then
-    python3 - "$CC" <<'PY'
-import csv, sys, collections
+    python3 - "$CC" "${PROFILE_MATCH:-tile_kernel}" <<'PY'
+import csv, sys, collections, re
+match = re.compile(sys.argv[2])
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
     k = r.get("Kernel_Name", "")
-    if "tile_kernel" not in k: continue
-    key = r.get("Counter_Name", "")
+    if not match.search(k): continue
+    short = k.split("(")[0].split("<")[0].split("::")[-1]
+    key = (short, r.get("Counter_Name", ""))
     acc[key][0] += 1; acc[key][1] += float(r.get("Counter_Value", 0) or 0)
-for c, (n, s) in sorted(acc.items()):
-    print(f"{c:36s} avg/dispatch {s / n if n else 0:16.1f}   (n={n})")
+for (k, c), (n, s) in sorted(acc.items()):
+    print(f"{k:26s} {c:28s} avg/dispatch {s / n if n else 0:16.1f}   (n={n})")
 PY
   else echo "no csv for: $pmc"; tail -3 $OUT/p$i.log; fi
 done

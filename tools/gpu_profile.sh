@@ -9,6 +9,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 RAW=/tmp/prof_raw_$TAG
 rm -rf $OUT $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
+# PROFILE_MATCH (a regex, default mspmv) selects the kernels whose counters are summarised (e.g. 'mspmv|rocsparse' for the driver);
 # PROFILE_CMD overrides the profiled command (e.g. tools/plan_bench.py for the prepared plan); the default is the
 # headline bench without its prepared_plan leg (that leg launches the same kernel symbol on another matrix)
 BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-plan --no-configs $*"}
@@ -16,19 +17,20 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o bench -- $
 tail -2 $OUT/bench_trace.log
 for f in $(find $RAW/trace -name "*stats*.csv"); do cp $f $OUT/; done
 KT=$(find $RAW/trace -name "*kernel_trace.csv" | head -1)
-if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_mspmv.csv; grep mspmv $KT | head -400 >> $OUT/kernel_trace_mspmv.csv; fi
+if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_mspmv.csv; grep -E "${PROFILE_MATCH:-mspmv}" $KT | head -400 >> $OUT/kernel_trace_mspmv.csv; fi
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_READ_SECTORS_sum" "TCP_TCC_READ_REQ_sum"; do
   name=$(echo $pmc | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $RAW/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1
   CC=$(find $RAW/pmc_$name -name "*counter_collection.csv" | head -1)
   if [ -n "$CC" ]; then
-    python3 - "$CC" "$OUT/pmc_$name.summary.csv" <<'PY'
-import csv, sys, collections
+    python3 - "$CC" "$OUT/pmc_$name.summary.csv" "${PROFILE_MATCH:-mspmv}" <<'PY'
+import csv, sys, collections, re
+match = re.compile(sys.argv[3])
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     k = r.get("Kernel_Name", "")
-    if "mspmv" not in k: continue
+    if not match.search(k): continue
     short = k.split("(")[0].split("<")[0].split("::")[-1]
     key = (short, r.get("Counter_Name", ""))
     acc[key][0] += 1; acc[key][1] += float(r.get("Counter_Value", 0) or 0)

@@ -118,6 +118,7 @@ def main():
         torch.cuda.synchronize(); tp = (time.perf_counter() - t0) / 30 * 1e3
         print(f"  prepared (tile coordinates found once): total {tp:8.4f} ms | {2*A.nnz/tp/1e6:9.1f} GFLOP/s", flush=True)
         try:
+            if os.environ.get("SWEEP_NO_ROCSPARSE"): raise RuntimeError("skipped (SWEEP_NO_ROCSPARSE)")
             import rocsparse_ref
             ana, avg, yr = rocsparse_ref.time_csrmv(A, x)
             ym = M.csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols)
