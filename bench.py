@@ -219,6 +219,11 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
                 rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
             # cheap sanity on the result: finite, and the row sums of |y| are not all zero (parity proper is tests/ -m gpu)
             rec["y_finite"] = bool(torch.isfinite(y).all().item())
+            rec["gathers_per_s_G"] = round(A.nnz / (ms * 1e-3) / 1e9, 2)
+            if name.startswith("C5"):
+                rec["roofline"]["note"] = ("x (512 MB) is beyond every cache: a gather that misses moves a whole 128-byte line whatever the load's cache "
+                                           "policy, and the chip delivers ~55 G random lines/s (tools/gather_granularity, profiles/r03_gather_granularity.txt); "
+                                           "`gathers_per_s_G` is to be read against that, `frac` counts each x entry once")
             if name.startswith("C5") or "Orkut" in name:
                 # scale-free graphs with an x beyond the caches: the opt-in hot-column plan on the same matrix
                 rec["hot_column_plan"] = M.hotcols_bench_record(A, x, y, steps=k, warmup=2, peak_gbs=HBM_PEAK_GBS)
