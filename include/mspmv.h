@@ -349,8 +349,8 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries,
  *                           after creating its plan every process calls mspmv_mg_plan_ipc_export, the launcher gathers the
  *                           blobs (MPI / torch.distributed / a file -- anything), and every process passes ALL of them to
  *                           mspmv_mg_plan_ipc_import, which opens the peers' x replicas and mailbox blocks through hipIpc.
- *                           A step is then the SpMV + one tiny kernel writing the carry, tagged with the step number,
- *                           straight into its owner's mailbox (a peer write) + one tiny kernel on the owner that waits for
+ *                           A step is then the SpMV + one tiny kernel that writes the carry, tagged with the step number,
+ *                           straight into its owner's mailbox (a peer write) and, on the owner, waits for
  *                           the tags of its sources, adds them in part order and acknowledges; the row all-gather is the
  *                           PEER backend's pushes fenced by step-tagged flags.  Nothing on the host, no rendezvous; a
  *                           producer runs at most two steps ahead of its consumer.  Waits are bounded (seconds):

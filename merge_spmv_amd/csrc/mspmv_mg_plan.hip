@@ -152,45 +152,50 @@ template <typename V> __device__ __forceinline__ V bits_value(unsigned long long
 template <> __device__ __forceinline__ float bits_value<float>(unsigned long long b) { return __builtin_bit_cast(float, (unsigned) b); }
 template <> __device__ __forceinline__ double bits_value<double>(unsigned long long b) { return __builtin_bit_cast(double, b); }
 
-// producer: this part's carry of step `step` -> the mailboxes of the parts that own the row it belongs to.  slot[k] points at
-// carry[me][step & 1] inside consumer k's block (peer memory), ack[k] at carry_ack[consumer k] inside MY block.
+// What follows a part's SpMV in an IPC step, as ONE launch (three dependent tiny launches cost ~15 us of kernel boundaries
+// per step): lanes 0..n_peers-1 announce "my SpMV of this step has read x" (done_flag[k]: spmv_done[me] in peer k's block);
+// lane 0 then writes this part's carry of the step, as a record tagged with the step, into the mailboxes of the parts that
+// own the row it belongs to (slot[k]: carry[me][step & 1] inside consumer k's block, peer memory; push_ack[k]: carry_ack[consumer k]
+// inside MY block -- the credit: the consumer has taken what the slot held two steps ago) and, last, adds the carries of its
+// sources to y_first[0] in part order and acknowledges them (rec[k]: carry[source k] inside MY block; take_ack[k]: carry_ack[me]
+// inside source k's block).  Every part pushes before it waits: no cycle.
 template <typename V>
-__global__ void ipc_push_carry_kernel(const V *__restrict__ y_last, unsigned long long *const *__restrict__ slot,
-                                      const unsigned long long *const *__restrict__ ack, int n, unsigned long long step, int *error)
+__global__ __launch_bounds__(64) void ipc_step_tail_kernel(unsigned long long *const *__restrict__ done_flag, int n_peers,
+                                                           const V *__restrict__ y_last, unsigned long long *const *__restrict__ slot,
+                                                           const unsigned long long *const *__restrict__ push_ack, int n_push,
+                                                           V *__restrict__ y_first, const unsigned long long *const *__restrict__ rec,
+                                                           unsigned long long *const *__restrict__ take_ack, int n_take,
+                                                           unsigned long long step, int *error)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const unsigned long long bits = value_bits<V>(*y_last);
+    const int lane = threadIdx.x;
+    for (int k = lane; k < n_peers; k += 64) sys_store(done_flag[k], step);
+    if (lane != 0) return;
     const unsigned tag = (unsigned) step;
-    for (int k = 0; k < n; ++k) {
-        // credit: the consumer has taken what this slot held two steps ago
-        if (step > IPC_SLOTS && !spin_until_at_least(ack[k], step - IPC_SLOTS)) { *error = 1; return; }
-        unsigned long long *rec = slot[k] + 2 * (step & (IPC_SLOTS - 1));
-        sys_store(rec, ((unsigned long long) tag << 32) | (unsigned) (bits >> 32));
-        sys_store(rec + 1, ((unsigned long long) tag << 32) | (unsigned) bits);
-    }
-}
-// consumer: y_first[0] += the carries of this step from the source parts, in part order; then acknowledge.  rec[k] points at
-// carry[source k] inside MY block, ack[k] at carry_ack[me] inside source k's block (peer memory).
-template <typename V>
-__global__ void ipc_take_carry_kernel(V *__restrict__ y_first, const unsigned long long *const *__restrict__ rec,
-                                      unsigned long long *const *__restrict__ ack, int n, unsigned long long step, int *error)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const unsigned tag = (unsigned) step;
-    V acc = *y_first;
-    for (int k = 0; k < n; ++k) {
-        const unsigned long long *r = rec[k] + 2 * (step & (IPC_SLOTS - 1));
-        unsigned long long w0 = 0, w1 = 0; bool ok = false;
-        for (long long i = 0; i < IPC_MAX_SPINS; ++i) {
-            w0 = sys_load(r); w1 = sys_load(r + 1);
-            if ((unsigned) (w0 >> 32) == tag && (unsigned) (w1 >> 32) == tag) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(8);
+    if (n_push > 0) {
+        const unsigned long long bits = value_bits<V>(*y_last);
+        for (int k = 0; k < n_push; ++k) {
+            if (step > IPC_SLOTS && !spin_until_at_least(push_ack[k], step - IPC_SLOTS)) { *error = 1; return; }
+            unsigned long long *r = slot[k] + 2 * (step & (IPC_SLOTS - 1));
+            sys_store(r, ((unsigned long long) tag << 32) | (unsigned) (bits >> 32));
+            sys_store(r + 1, ((unsigned long long) tag << 32) | (unsigned) bits);
         }
-        if (!ok) { *error = 2; acc = (V) __builtin_nan(""); break; }
-        acc += bits_value<V>(((w0 & 0xffffffffull) << 32) | (w1 & 0xffffffffull));
-        sys_store(ack[k], step);
     }
-    *y_first = acc;
+    if (n_take > 0) {
+        V acc = *y_first;
+        for (int k = 0; k < n_take; ++k) {
+            const unsigned long long *r = rec[k] + 2 * (step & (IPC_SLOTS - 1));
+            unsigned long long w0 = 0, w1 = 0; bool ok = false;
+            for (long long i = 0; i < IPC_MAX_SPINS; ++i) {
+                w0 = sys_load(r); w1 = sys_load(r + 1);
+                if ((unsigned) (w0 >> 32) == tag && (unsigned) (w1 >> 32) == tag) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) { *error = 2; acc = (V) __builtin_nan(""); break; }
+            acc += bits_value<V>(((w0 & 0xffffffffull) << 32) | (w1 & 0xffffffffull));
+            sys_store(take_ack[k], step);
+        }
+        *y_first = acc;
+    }
 }
 // flag[k][me] = step in every peer's block (k = the other parts): "done" / "pushed" announcements
 __global__ void ipc_announce_kernel(unsigned long long *const *__restrict__ flag, int n, unsigned long long step)
@@ -302,17 +307,15 @@ int run_spmv(mspmv_mg_plan *plan)
         MG_HIP(hipEventRecord(q.done, q.stream)); q.done_valid = true;
         if (ipc) {
             const int vb = (int) sizeof(V);
-            // "my SpMV of this step has read x" -> every peer (a later row all-gather waits for it before overwriting x)
-            if (q.n_peers > 0)
-                hipLaunchKernelGGL(ipc_announce_kernel, dim3(1), dim3(64), 0, q.stream,
-                                   reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 4 * MSPMV_MG_MAX_PARTS), q.n_peers, step);
-            if (q.n_push > 0)
-                hipLaunchKernelGGL((ipc_push_carry_kernel<V>), dim3(1), dim3(64), 0, q.stream,
+            // "my SpMV of this step has read x" -> every peer (a later row all-gather waits for it before overwriting x); this
+            // part's carry -> its consumers' mailboxes; the carries of its sources -> y[0]: one launch
+            if (q.n_peers > 0 || q.n_push > 0 || q.n_take > 0)
+                hipLaunchKernelGGL((ipc_step_tail_kernel<V>), dim3(1), dim3(64), 0, q.stream,
+                                   reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 4 * MSPMV_MG_MAX_PARTS), q.n_peers,
                                    reinterpret_cast<const V *>(static_cast<const char *>(q.y) + (size_t) (q.local_rows - 1) * vb),
                                    reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 0 * MSPMV_MG_MAX_PARTS),
-                                   reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 1 * MSPMV_MG_MAX_PARTS), q.n_push, step, q.ipc_error);
-            if (q.n_take > 0)
-                hipLaunchKernelGGL((ipc_take_carry_kernel<V>), dim3(1), dim3(64), 0, q.stream, static_cast<V *>(q.y),
+                                   reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 1 * MSPMV_MG_MAX_PARTS), q.n_push,
+                                   static_cast<V *>(q.y),
                                    reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 2 * MSPMV_MG_MAX_PARTS),
                                    reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 3 * MSPMV_MG_MAX_PARTS), q.n_take, step, q.ipc_error);
             MG_HIP(hipGetLastError());
