@@ -1912,22 +1912,39 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
 
     const int tid = threadIdx.x;
     const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
+    // the hints: the tile's two boundaries (x, y) and their row starts.  The large-problem shapes read them THROUGH THE SCALAR
+    // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
+    // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
+    // same-box A/B in profiles/r03_scalar_hints.txt).  Matrices that live in the Infinity Cache and take the small shape gain
+    // nothing (dense5 loses 3 %), so that shape keeps the two-lane vector load + LDS broadcast.  (The hints were written by
+    // vector stores of an earlier launch; the scalar cache is invalidated at every kernel start.  Were the compiler ever to
+    // copy the destination registers between request and wait, the hints would be garbage -- which the verification below
+    // turns into a search, never into a wrong result.)
+    constexpr bool SCALAR_HINTS = IPT > 7;
+    int4v hint_c; int2v hint_r;
+    if constexpr (SCALAR_HINTS)
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0"
+                     : "=&s"(hint_c), "=&s"(hint_r) : "s"(coords + tile), "s"(rstart + tile) : "memory");
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     const V *const s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
     const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
-    if (tid < 2) {
-        Coord h = coords[tile + tid]; int rs = rstart[tile + tid];                                       // the hints
-        if (single) { h.x = tid ? p.rows : 0; h.y = tid ? p.nnz : 0; rs = h.y; }
+    if constexpr (SCALAR_HINTS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hint_c), "+s"(hint_r) : : "memory");
+    } else if (tid < 2) {
+        const Coord h = coords[tile + tid]; const int rs = rstart[tile + tid];
         s_bnd[3 * tid] = h.x; s_bnd[3 * tid + 1] = rs; s_bnd[3 * tid + 2] = h.y;
     }
-    __syncthreads();
+    __syncthreads();                                                // (s_flag cleared, the LDS copy of x complete, s_bnd written)
+    if constexpr (!SCALAR_HINTS) {
+        hint_c.x = s_bnd[0]; hint_r.x = s_bnd[1]; hint_c.y = s_bnd[2]; hint_c.z = s_bnd[3]; hint_r.y = s_bnd[4]; hint_c.w = s_bnd[5];
+    }
     const int total = p.rows + p.nnz;                               // < 2^31
     const long long d0l = (long long) tile * TILE, d1l = d0l + TILE;
     const int d0 = (int) (d0l < total ? d0l : total), d1 = (int) (d1l < total ? d1l : total);
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
-    int x0 = s_bnd[0], rs0 = s_bnd[1], x1 = s_bnd[3], rs1 = s_bnd[4];
-    const int hint_y0 = s_bnd[2], hint_y1 = s_bnd[5];
+    int x0 = single ? 0 : hint_c.x, rs0 = single ? 0 : hint_r.x, x1 = single ? p.rows : hint_c.z, rs1 = single ? p.nnz : hint_r.y;
+    const int hint_y0 = single ? 0 : hint_c.y, hint_y1 = single ? p.nnz : hint_c.w;
     int y0 = d0 - x0, y1 = d1 - x1;
     bool snap0 = y0 - rs0 <= HEAD_MAX, snap1 = y1 - rs1 <= HEAD_MAX;
     Coord c0, c1;
