@@ -1,11 +1,8 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
+echo "# dense5_f64 grid2d_2000_f64 grid2d_4096_f64 grid3d_200_f64 dense32_f32 dense32_f64 band5_f32 rmat22_f64 c4_f32 | c2 f32 f64"
+for rep in 1 2 3; do
 for v in old new; do
   if [ $v = new ]; then unset MSPMV_LIB; else export MSPMV_LIB=$GRAFT_REPO_ROOT/merge_spmv_amd/libmspmv_old.so; fi
-  for dt in f32 f64; do
-  python bench.py --no-configs --no-cpu-baseline --no-plan --dtype $dt 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v $dt', d['ms_per_step'], d['roofline']['kernel_ms'])"
-  done
+  echo -n "$v (round $rep): "
+  SWEEP_DEFAULT_SHAPE=1 SWEEP_NO_ROCSPARSE=1 timeout 600 python tools/sweep.py dense5d grid2d grid2d4096 grid3d dense32 dense32d band rmat c4 c2 c2d 2>&1 | grep -E "DEFAULT" | awk '{print $4}' | tr '\n' ' '; echo
 done; done
-unset MSPMV_LIB
-python tools/band_passes_bench.py u8MB_f32 2>&1 | grep -v amdgpu | head -3
-timeout 900 python -m pytest tests/test_band_passes.py -m gpu -x -q 2>&1 | tail -2
