@@ -1404,10 +1404,12 @@ __device__ __forceinline__ int xcd_chunked_tile(int b, int num_tiles, int chunk_
         return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     if (chunk_log2 > 0) {
-        const int G = 1 << chunk_log2, span = 8 * G;
-        if (b < (num_tiles / span) * span) {
-            const int q = b / span, r = b % span;
-            return (q * 8 + (r & 7)) * G + (r >> 3);
+        // groups of span = 8 * 2^chunk_log2 blocks; shifts, not divisions (the compiler does not see that span is a power of
+        // two, and this sits at the very head of every block, before its first load can be requested); b, num_tiles >= 0
+        const int sh = chunk_log2 + 3;
+        if (b < ((num_tiles >> sh) << sh)) {
+            const int q = b >> sh, r = b & ((1 << sh) - 1);
+            return (((q << 3) | (r & 7)) << chunk_log2) + (r >> 3);
         }
     }
     return b;
