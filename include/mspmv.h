@@ -246,7 +246,7 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
 #define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by a 64-ary wave search per boundary */
 #define MSPMV_TUNE_SCATTER_COORDS 0x10000000 /* ... always by one coalesced pass over all row offsets (the default below 10 M rows) */
 #define MSPMV_TUNE_INTERP_COORDS  0x20000000 /* ... always by one thread per boundary, interpolation search (the default from 10 M rows up) */
-#define MSPMV_TUNE_NO_FUSED   16  /* small problems take the large-problem tile shape too (256x11; fp64 up to 24 M path items: 256x7) */
+#define MSPMV_TUNE_NO_FUSED   16  /* small problems take the large-problem tile shape too (256x11; fp64 up to 8 M path items: 256x7) */
 #define MSPMV_TUNE_TWO_LAUNCH 0x40000000 /* the classic three launches (coordinate pass, tile_kernel_vec with one carry per tile, fix-up) instead of ONE launch of
                                            row-snapped tiles on verified coordinate hints (tile_kernel_snap) */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */

@@ -63,19 +63,20 @@ static inline const Tune &thread_tune(int value_bytes) { return t_tune[value_byt
 //  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (1024) tiles -- more, smaller tiles keep more CUs
 //    busy on a small matrix: 4.4-5.6 us per call up to 1.4 M nonzeros where 256x11 takes 4.9-5.9 --, 256x11 beyond (the
 //    fastest or within 1 % of the fastest shape on every larger workload tried);
-//  * fp64: 256x7 (7 resident blocks per CU instead of 5) up to 24 M path items, 256x11 beyond;
+//  * fp64: 256x7 (7 resident blocks per CU instead of 5) up to 8 M path items, 256x11 beyond (24 M until the large shape
+//    began to read its hints through the scalar cache: 5-point grids of 10-20 M items 3-6 % faster in 256x11 since);
 //  * MSPMV_TUNE_NO_FUSED / _NO_VEC: the large-problem choice whatever the size (tests).
 static Shape pick_shape(int value_bytes, long long items, const Tune &t)
 {
     if (t.block > 0) return Shape{t.block, t.ipt};
     const bool small_ok = !(t.flags & (MSPMV_TUNE_NO_VEC | MSPMV_TUNE_NO_FUSED));
-    if (value_bytes == 8) return items <= 24000000LL ? Shape{256, 7} : Shape{256, 11};
+    if (value_bytes == 8) return items <= 8000000LL ? Shape{256, 7} : Shape{256, 11};
     if (small_ok && (items + 256LL * 7 - 1) / (256LL * 7) <= SMALL_MAX_TILES) return Shape{256, 7};
     return Shape{256, 11};
 }
 
 // tile shapes whose vectorised kernel is also compiled with the column-band passes: the large-problem shape, and the fp64
-// shape of problems of up to 24 M path items
+// shape of smaller problems (forced band passes, and what the policy offered while that shape went up to 24 M path items)
 static constexpr bool band_shape(int block, int ipt, int value_bytes) { return block == 256 && (ipt == 11 || (value_bytes == 8 && ipt == 7)); }
 
 // room the row-snapped tiles have for the nonzeros they adopt (kernels: snap_head_max)

@@ -65,7 +65,7 @@ def test_tuning_rejects_unknown_shapes():
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 11
     M.set_tuning(4)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
-    # default shapes: fp32 256x7 while that keeps the problem within 1024 tiles, 256x11 beyond; fp64 256x7 up to 24 M path
+    # default shapes: fp32 256x7 while that keeps the problem within 1024 tiles, 256x11 beyond; fp64 256x7 up to 8 M path
     # items, 256x11 beyond.  Always ONE launch of row-snapped tiles (tile_kernel_snap, no fix-up) unless MSPMV_TUNE_TWO_LAUNCH
     # asks for the classic three
     assert M.launch_info(300_000, 1_000_000, 4)["items_per_thread"] == 7         # 1.3M items / 1792 = 726 tiles
@@ -89,7 +89,7 @@ def test_tuning_rejects_unknown_shapes():
     th.start(); th.join()
     assert seen["ipt"] == 7 and M.launch_info(10, 10, 4)["items_per_thread"] == 11
     M.set_tuning(4)
-    assert M.launch_info(1_000_000, 5_000_000, 8)["items_per_thread"] == 7       # fp64 up to 24 M path items: 256x7
+    assert M.launch_info(1_000_000, 5_000_000, 8)["items_per_thread"] == 7       # fp64 up to 8 M path items: 256x7
     assert M.launch_info(1000, 5000, 8)["items_per_thread"] == 7
     assert M.launch_info(4_000_000, 30_000_000, 8)["items_per_thread"] == 11
     assert M.launch_info(3_125_000, 100_000_000, 4)["items_per_thread"] == 11

@@ -194,7 +194,7 @@ def test_forced_passes_on_the_reference_golden_matrices(forced_shape, case, prec
 @pytest.mark.parametrize("shape", ["short_rows", "power_law", "giant_row", "mostly_empty"])
 @pytest.mark.parametrize("passes", [2, 5])
 def test_forced_passes_on_the_fp64_mid_size_tile(shape, passes):
-    """fp64 problems of up to 24 M path items run 256x7 tiles: that kernel carries the passes too"""
+    """the fp64 256x7 tile (problems of up to 8 M path items; forced here) carries the passes too"""
     rng = np.random.default_rng(len(shape) * 13 + passes)
     rows, cols, lens = SHAPES[shape](rng)
     csr = _random(rng, rows, cols, np.asarray(lens, np.int64), np.float64)
