@@ -1909,7 +1909,6 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
     __shared__ int s_bnd[6];
-    __shared__ int s_ok;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
 
     const int tid = threadIdx.x;
@@ -1963,9 +1962,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     if (good) {
         // the four row offsets that decide whether (x0, rs0) and (x1, rs1) are the points of diagonals d0 and d1: requested
         // BEFORE the tile's streams, so they are back first
+        // (by four lanes of EVERY wave: each wave then decides for itself -- all from the same four words, so all alike --
+        //  and the verdict needs neither an LDS word nor a barrier of its own)
         int vre = 0;
-        if (tid < 4) {
-            int idx = (tid < 2 ? x0 : x1) - 1 + (tid & 1);          // x0 - 1, x0, x1 - 1, x1
+        const int lane = tid & (WAVE - 1);
+        if (lane < 4) {
+            int idx = (lane < 2 ? x0 : x1) - 1 + (lane & 1);        // x0 - 1, x0, x1 - 1, x1
             idx = idx < 0 ? 0 : idx >= p.rows ? p.rows - 1 : idx;   // (rows >= 3 on this path)
             vre = p.row_end[idx];
         }
@@ -1975,15 +1977,14 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
         // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
         // memory latency; a barrier is cheap)
-        if (tid < WAVE) {
+        {
             const int before0 = __shfl(vre, 0, WAVE), at0 = __shfl(vre, 1, WAVE), before1 = __shfl(vre, 2, WAVE), at1 = __shfl(vre, 3, WAVE);
             // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
             const bool ok0 = (x0 > 0 ? before0 == rs0 : rs0 == 0) && (x0 < p.rows ? y0 <= at0 : d0 == total);
             const bool ok1 = (x1 > 0 ? before1 == rs1 : rs1 == 0) && (x1 < p.rows ? y1 <= at1 : d1 == total);
-            if (tid == 0) s_ok = (single || (ok0 && ok1)) ? 1 : 0;
+            good = single || (ok0 && ok1);
         }
-        __syncthreads();
-        good = s_ok != 0;
+        // (a failed check: every wave is past the staging barrier, and the search below starts with a barrier of its own)
         if (!good && tid < SLOTS / 32 + 1) s_flag[tid] = 0u;       // (the staging above touched nothing but LDS)
     }
     if (!good) {
