@@ -14,7 +14,9 @@
  *   - two-phase temp storage: d_temp == NULL -> *temp_bytes receives the size
  *     needed, no work is done, returns 0 (dispatch_spmv_orig.cuh:651-655);
  *     otherwise *temp_bytes < needed -> hipErrorInvalidValue
- *     (util_device.cuh:90-93);
+ *     (util_device.cuh:90-93); d_temp (and a plan's storage) must be 16-byte
+ *     aligned, as every device allocation is -- it holds 64-bit records that
+ *     are updated atomically -- else hipErrorInvalidValue;
  *   - the caller owns every buffer including temp; the callee allocates
  *     nothing and keeps no state between calls (what a call leaves in temp
  *     storage is scratch, except for mspmv_csrmv_prepare); the only library

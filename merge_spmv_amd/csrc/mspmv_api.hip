@@ -580,6 +580,9 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
         return hipSuccess;
     }
     if (*temp_bytes < L.total) return hipErrorInvalidValue;   // util_device.cuh:90-93
+    // (the temp storage holds 64-bit records updated atomically and is read with scalar loads: 16-byte alignment, which any
+    //  device allocation has, is required rather than silently compensated for)
+    if (reinterpret_cast<uintptr_t>(d_temp) & 15) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;             // nothing to write
     if (ex.phase == PHASE_COORDS_ONLY) { if (!d_row_offsets) return hipErrorInvalidValue; }
     else if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
@@ -732,7 +735,7 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
     const bool wide = (unsigned long long) cols * (unsigned long long) ldx * sizeof(T) > (1ull << 20);
     const MMLayout L = make_mm_layout<T>(rows, nnz, k, wide);
     if (d_temp == nullptr) { *temp_bytes = (size_t) L.total; return hipSuccess; }
-    if (*temp_bytes < L.total) return hipErrorInvalidValue;
+    if (*temp_bytes < L.total || (reinterpret_cast<uintptr_t>(d_temp) & 15)) return hipErrorInvalidValue;
     if (rows == 0 || k == 0) return hipSuccess;
     if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

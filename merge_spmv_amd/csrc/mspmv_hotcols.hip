@@ -150,7 +150,7 @@ int hot_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets, con
 {
     if (!d_plan || rows < 0 || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8) || !d_row_offsets || (nnz > 0 && !d_cols)) return hipErrorInvalidValue;
     HotLayout L;
-    if (!make_layout(rows, cols, nnz, value_bytes, L) || plan_bytes < L.total) return hipErrorInvalidValue;
+    if (!make_layout(rows, cols, nnz, value_bytes, L) || plan_bytes < L.total || (reinterpret_cast<uintptr_t>(d_plan) & 15)) return hipErrorInvalidValue;
     char *base = static_cast<char *>(d_plan);
     unsigned *counts = reinterpret_cast<unsigned *>(base + L.counts_off);
     unsigned *cls = reinterpret_cast<unsigned *>(base + L.class_off);
@@ -189,7 +189,7 @@ int hot_apply(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t 
 {
     if (!d_plan || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
     HotLayout L;
-    if (!make_layout(rows, cols, nnz, (int) sizeof(V), L) || plan_bytes < L.total) return hipErrorInvalidValue;
+    if (!make_layout(rows, cols, nnz, (int) sizeof(V), L) || plan_bytes < L.total || (reinterpret_cast<uintptr_t>(d_plan) & 15)) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     if (!d_y || !d_row_offsets || (nnz > 0 && (!d_x || !d_values))) return hipErrorInvalidValue;
     char *base = static_cast<char *>(d_plan);

@@ -247,7 +247,7 @@ int plan_build(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t
 {
     if (!d_plan || rows < 0 || cols < 0 || nnz < 0 || !d_row_offsets || (nnz > 0 && (!d_values || !d_cols))) return hipErrorInvalidValue;
     PlanLayout L;
-    if (!make_layout(rows, cols, nnz, (int) sizeof(V), bands, L) || plan_bytes < L.total) return hipErrorInvalidValue;
+    if (!make_layout(rows, cols, nnz, (int) sizeof(V), bands, L) || plan_bytes < L.total || (reinterpret_cast<uintptr_t>(d_plan) & 15)) return hipErrorInvalidValue;
     char *base = static_cast<char *>(d_plan);
     PlanHeader *hdr = reinterpret_cast<PlanHeader *>(base + L.header_off);
     int *soff = reinterpret_cast<int *>(base + L.offsets_off);
@@ -292,7 +292,7 @@ int plan_apply(void *d_plan, size_t plan_bytes, const V *d_x, V *d_y, int32_t ro
 {
     if (!d_plan || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
     PlanLayout L;
-    if (!make_layout(rows, cols, nnz, (int) sizeof(V), bands, L) || plan_bytes < L.total) return hipErrorInvalidValue;
+    if (!make_layout(rows, cols, nnz, (int) sizeof(V), bands, L) || plan_bytes < L.total || (reinterpret_cast<uintptr_t>(d_plan) & 15)) return hipErrorInvalidValue;
     if (rows == 0) return hipSuccess;
     if (!d_y || (nnz > 0 && !d_x)) return hipErrorInvalidValue;
     char *base = static_cast<char *>(d_plan);

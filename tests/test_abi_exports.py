@@ -50,6 +50,12 @@ def test_size_query_two_phase_convention():
         small = ctypes.c_size_t(size.value - 1)
         st = fn(ctypes.c_void_p(256), ctypes.byref(small), None, None, None, None, None, 1000, 1000, 50000, None, 0)
         assert st == 1  # hipErrorInvalidValue
+        # temp storage must be 16-byte aligned (64-bit atomic records, scalar loads): refused before anything is touched
+        big = ctypes.c_size_t(size.value + 64)
+        fake = ctypes.c_void_p(4096)
+        for misaligned in (4096 + 1, 4096 + 4, 4096 + 8):
+            st = fn(ctypes.c_void_p(misaligned), ctypes.byref(big), fake, fake, fake, fake, fake, 1000, 1000, 50000, None, 0)
+            assert st == 1
         st = fn(None, ctypes.byref(size), None, None, None, None, None, -1, 5, 5, None, 0)
         assert st == 1
         st = fn(None, ctypes.byref(size), None, None, None, None, None, 2**30, 5, 2**30 + 5, None, 0)
