@@ -1916,8 +1916,8 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // the hints: the tile's two boundaries (x, y) and their row starts.  The large-problem shapes read them THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
-    // same-box A/B in profiles/r03_scalar_hints.txt).  Matrices that live in the Infinity Cache and take the small shape gain
-    // nothing (dense5 loses 3 %), so that shape keeps the two-lane vector load + LDS broadcast.  (The hints were written by
+    // same-box A/B in profiles/r03_scalar_hints.txt).  In the small shape nothing was gained (small grids the same, a 20 M-item
+    // matrix that then still took it 3 % slower), so that shape keeps the two-lane vector load + LDS broadcast.  (The hints were written by
     // vector stores of an earlier launch; the scalar cache is invalidated at every kernel start.  Were the compiler ever to
     // copy the destination registers between request and wait, the hints would be garbage -- which the verification below
     // turns into a search, never into a wrong result.)
