@@ -312,7 +312,8 @@ def test_bench_multi_rank_path_on_one_device():
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, 2, *small, "--exchange", "ipc")
     assert out["n_gpus"] == 2 and out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["value"] > 0
     # rank 0's tiles are the first tiles of the one-GPU call of the same job: its rows agree bit for bit
-    assert out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]["not_bitwise_equal"] <= 1
+    cmp = out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]
+    assert cmp["same_tiling"] and cmp["not_bitwise_equal"] <= 1
     # (d) an exchange that cannot be set up (two RCCL ranks on one device are refused) makes every rank fall back together
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                       "MSPMV_BENCH_FORCE_C_OPERATOR": "1"}, 2, *small, "--exchange", "rccl")
