@@ -97,6 +97,37 @@ def uniform_csr(rows: int, cols: int, nnz_per_row: int, dtype=torch.float32, dev
     return DeviceCsr(n_rows, cols, offsets, cols_out, vals)
 
 
+def _grid_csr(n: int, me: torch.Tensor, cand, dtype, device) -> DeviceCsr:
+    """CSR of a lattice: for vertex `me` the neighbours of `cand` (ascending column order) whose guard holds; values 1."""
+    mask = torch.stack([m for m, _ in cand], dim=1)
+    nbr = torch.stack([v for _, v in cand], dim=1)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(mask.sum(dim=1), 0, out=offsets[1:])
+    cols = nbr[mask].to(torch.int32)
+    return DeviceCsr(n, n, offsets.to(torch.int32), cols, torch.ones(cols.numel(), dtype=dtype, device=device))
+
+
+def grid2d_csr(width: int, dtype=torch.float64, device="cuda") -> DeviceCsr:
+    """The reference's --grid2d=W input as CSR (InitGrid2d without self loops, sparse_matrix.h:461-526, after its COO -> CSR
+    conversion: columns ascending within a row): W*W vertices, 4-neighbour lattice, every value 1."""
+    j = torch.arange(width, dtype=torch.int64, device=device).repeat_interleave(width)
+    k = torch.arange(width, dtype=torch.int64, device=device).repeat(width)
+    me = j * width + k
+    cand = [(j - 1 >= 0, me - width), (k - 1 >= 0, me - 1), (k + 1 < width, me + 1), (j + 1 < width, me + width)]
+    return _grid_csr(width * width, me, cand, dtype, device)
+
+
+def grid3d_csr(width: int, dtype=torch.float64, device="cuda") -> DeviceCsr:
+    """The reference's --grid3d=W input as CSR (InitGrid3d without self loops, sparse_matrix.h:533-617): W^3 vertices,
+    6-neighbour lattice, columns ascending within a row, every value 1."""
+    w = width
+    a = torch.arange(w, dtype=torch.int64, device=device)
+    i = a.repeat_interleave(w * w); j = a.repeat_interleave(w).repeat(w); k = a.repeat(w * w)
+    me = i * w * w + j * w + k
+    cand = [(i - 1 >= 0, me - w * w), (j - 1 >= 0, me - w), (k - 1 >= 0, me - 1), (k + 1 < w, me + 1), (j + 1 < w, me + w), (i + 1 < w, me + w * w)]
+    return _grid_csr(w * w * w, me, cand, dtype, device)
+
+
 def dense_csr(rows: int, cols: int, dtype=torch.float32, device="cuda", ones: bool = True,
               seed: int = SEED_C2) -> DeviceCsr:
     """The reference's --dense=<cols> matrix (InitDense, sparse_matrix.h:386-413)

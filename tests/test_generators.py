@@ -2,6 +2,7 @@
 they can be built in HBM) against an independent numpy splitmix64: same integers, same
 values, valid CSR.  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from merge_spmv_amd import generators as G
@@ -80,3 +81,16 @@ def test_tools_and_entry_points_compile():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
         py_compile.compile(f, doraise=True)
+
+
+@pytest.mark.parametrize("kind,width", [("grid2d", 1), ("grid2d", 2), ("grid2d", 9), ("grid2d", 40), ("grid3d", 1), ("grid3d", 2), ("grid3d", 7)])
+def test_lattice_generators_are_the_reference_inputs(kind, width):
+    """grid2d_csr / grid3d_csr (what the measuring tools feed the GPU) are array for array the CSR the oracle's restatement of
+    InitGrid2d / InitGrid3d + the COO -> CSR conversion gives (sparse_matrix.h:461-617,666-728)."""
+    from oracle import oracle as O
+    c = O.make(kind, width, dtype=np.float64)
+    d = (G.grid2d_csr if kind == "grid2d" else G.grid3d_csr)(width, torch.float64, "cpu")
+    assert (c.rows, c.cols) == (d.rows, d.cols)
+    assert np.array_equal(c.row_offsets, d.row_offsets.numpy())
+    assert np.array_equal(c.column_indices, d.column_indices.numpy())
+    assert np.array_equal(c.values, d.values.numpy())

@@ -6,14 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import merge_spmv_amd as M
 from merge_spmv_amd import generators as G
-from oracle import oracle as O
 
 f32 = os.environ.get("SMALL_F32") == "1"
 npdt, tdt, vb = (np.float32, torch.float32, 4) if f32 else (np.float64, torch.float64, 8)
 widths = [int(a) for a in sys.argv[1:]] or [100, 300, 500, 600, 700, 800, 1000, 1400]
 for w in widths:
-    c = O.make("grid2d", w, dtype=npdt)
-    A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+    A = G.grid2d_csr(w, tdt)
     x = torch.ones(A.cols, dtype=tdt, device="cuda"); y = torch.empty(A.rows, dtype=tdt, device="cuda")
     line = f"grid2d_{w} {'fp32' if f32 else 'fp64'} ({A.nnz} nnz):"
     dev = "dev" in os.environ.get("MSPMV_LIB", "")        # MSPMV_LIB=merge_spmv_amd/libmspmv_dev.so: every sweep shape

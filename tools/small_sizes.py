@@ -7,7 +7,6 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import merge_spmv_amd as M
 from merge_spmv_amd import generators as G
-from oracle import oracle as O
 import rocsparse_ref
 def t(fn, iters=300):
     for _ in range(10): fn()
@@ -16,8 +15,7 @@ def t(fn, iters=300):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / iters * 1e6
 for w in (30, 100, 200, 300, 400, 500, 600, 700, 1200):
-    c = O.make("grid2d", w, dtype=np.float64)
-    A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+    A = G.grid2d_csr(w, torch.float64)
     x = torch.ones(A.cols, dtype=torch.float64, device="cuda")
     ws = M.CsrMVWorkspace(A.rows, A.nnz, torch.float64); y = torch.empty(A.rows, dtype=torch.float64, device="cuda")
     us = t(lambda: M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, workspace=ws))

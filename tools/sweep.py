@@ -42,23 +42,13 @@ def workloads(names):
             A = G.dense_csr((1 << 24) // 5, 5, dtype=torch.float64, ones=False)
             yield "dense5_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "grid2d4096":
-            import numpy as np
-            from oracle import oracle as O
-            c = O.make("grid2d", 4096, dtype=np.float64)
-            A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+            A = G.grid2d_csr(4096, torch.float64)
             yield "grid2d_4096_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "grid2d":
-            import numpy as np
-            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-            from oracle import oracle as O
-            c = O.make("grid2d", 2000, dtype=np.float64)
-            A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+            A = G.grid2d_csr(2000, torch.float64)
             yield "grid2d_2000_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "grid3d":
-            import numpy as np
-            from oracle import oracle as O
-            c = O.make("grid3d", 200, dtype=np.float64)
-            A = G.DeviceCsr(c.rows, c.cols, torch.from_numpy(c.row_offsets).cuda(), torch.from_numpy(c.column_indices).cuda(), torch.from_numpy(c.values).cuda())
+            A = G.grid3d_csr(200, torch.float64)
             yield "grid3d_200_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "band":
             # banded: 5 nnz/row near the diagonal (grid-like locality)
