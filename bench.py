@@ -166,6 +166,21 @@ def time_stateless(M, torch, A, x, steps, warmup):
     return ms, M.profile_end(), ws, y
 
 
+def replayed_traffic(workload, dtype_name):
+    """HBM-side bytes per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same command
+    (profiles/*/pmc_latest.json, written by tools/gpu_profile.sh): replayed constants, labelled as such."""
+    for rel in ("pmc_latest.json", os.path.join("r03_dense32", "pmc_latest.json"), os.path.join("r03_c2_f64", "pmc_latest.json")):
+        path = os.path.join(ROOT, "profiles", rel)
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
+        if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and pmc.get("tile_kernel_hbm_bytes_per_launch"):
+            return pmc["tile_kernel_hbm_bytes_per_launch"], (f"profiles/{rel} (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
+                                                              "from separate rocprofv3 --pmc passes over this command, " + str(pmc.get("collected", "see profiles/README.md")))
+    return None, None
+
+
 def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
     """The `configs` array: every single-GPU configuration of BASELINE.json that the headline does not cover, through the
     same stateless call.  Generation is on the GPU and not timed; a configuration that would start after `budget_s` of
@@ -218,6 +233,9 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
                 spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
                 rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
             # cheap sanity on the result: finite, and the row sums of |y| are not all zero (parity proper is tests/ -m gpu)
+            tr, src = replayed_traffic({"C2 fp64": "c2", "dense32 fp32": "dense32"}.get(name, ""), "f32" if vb == 4 else "f64")
+            if tr is not None:
+                rec["roofline"]["traffic"] = tr; rec["roofline"]["traffic_source"] = src
             rec["y_finite"] = bool(torch.isfinite(y).all().item())
             rec["gathers_per_s_G"] = round(A.nnz / (ms * 1e-3) / 1e9, 2)
             if name.startswith("C5"):
@@ -568,16 +586,10 @@ def main():
         achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
         traffic = None
         traffic_source = "not measured: hardware counters need rocprofv3 --pmc passes (tools/gpu_profile.sh), which bench.py does not run"
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
-            try:
-                pmc = json.load(open(pmc_path))
-                if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and not mg:
-                    traffic = pmc.get("tile_kernel_hbm_bytes_per_launch")
-                    traffic_source = ("profiles/pmc_latest.json (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
-                                      "from separate rocprofv3 --pmc passes over this command, " + str(pmc.get("collected", "see profiles/README.md")))
-            except Exception:
-                traffic = None
+        if not mg:
+            traffic, src = replayed_traffic(workload, dtype_name)
+            if traffic is not None:
+                traffic_source = src
         out = {
             "metric": "CsrMV GFLOP/s", "value": round(gflops, 3), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
