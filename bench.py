@@ -2,7 +2,8 @@
 """bench.py -- CsrMV throughput of the MI355X-native merge-based SpMV.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... -- or
+     plainly, in which case bench.py starts that launcher itself: self_launch)
 
 A "step" is one y = A*x through the C ABI (include/mspmv.h); inputs are resident in HBM before timing.
 
@@ -253,6 +254,44 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one rank per
+    GPU, what the launcher form of the contract does) and hand its output through -- everything the ranks wrote to stdout
+    first, rank 0's JSON line LAST.  Returns the exit code.  With MSPMV_BENCH_ONE_DEVICE=1 (a one-GPU box: every rank on
+    cuda:0) the process group defaults to gloo -- RCCL admits one rank per device -- and the ranks still go through the C
+    operator (its exchange falls back rccl -> hipIpc together on every rank)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")       # (torch.distributed.run would set 1 and say so on stderr)
+    if env.get("MSPMV_BENCH_ONE_DEVICE") == "1":
+        env.setdefault("MSPMV_BENCH_BACKEND", "gloo")
+        env.setdefault("MSPMV_BENCH_FORCE_C_OPERATOR", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)       # stderr passes straight through
+    lines = r.stdout.splitlines()
+    last_json = max((i for i, l in enumerate(lines) if l.startswith("{") and l.rstrip().endswith("}")), default=None)
+    for i, l in enumerate(lines):
+        if i != last_json:
+            print(l)
+    if last_json is not None:
+        rec = lines[last_json]
+        try:
+            d = json.loads(rec)
+            d["launched_by"] = f"bench.py itself (no WORLD_SIZE in the environment): torch.distributed.run --nproc-per-node {n}"
+            rec = json.dumps(d)
+        except ValueError:
+            pass
+        print(rec, flush=True)
+    return r.returncode if (r.returncode != 0 or last_json is not None) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,6 +316,9 @@ def main():
     ap.add_argument("--band-passes", type=int, default=0,
                     help="A/B: mspmv_set_band_passes (0 automatic = the product default, -1 never, >= 2 always that many)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (below) -- the same job the launcher form runs
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import merge_spmv_amd as M
@@ -287,7 +329,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher that started {world} ranks (WORLD_SIZE={world}): the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP merge-path kernels have no CPU fallback)")
     # MSPMV_BENCH_ONE_DEVICE=1 + MSPMV_BENCH_BACKEND=gloo: exercise the multi-rank path on a

@@ -546,6 +546,16 @@ def launch_info(num_rows: int, num_nonzeros: int, value_bytes: int) -> dict:
     return {name: getattr(info, name) for name, _ in _LaunchInfo._fields_}
 
 
+def serial_sum_depth(num_rows: int, num_cols: int, num_nonzeros: int, value_bytes: int, extra: int = 0) -> int:
+    """How many products one thread of the tile kernel adds up serially before the scan tree takes over, for a call of these
+    sizes -- the compiled tile's items per thread rounded up to whole 4-element chunks -- plus one re-association per
+    column-band pass the call may run, plus `extra` (parts of a multi-GPU split, bands of a prepared plan).  It is the
+    `items_per_thread` term of the stated error bound |y - g| <= 2 (ceil(log2(len + 1)) + items_per_thread + 8) eps s
+    (DESIGN.md 3): derived from the compiled shape, so the bound follows the library when a shape changes."""
+    ipt = launch_info(num_rows, num_nonzeros, value_bytes)["items_per_thread"]
+    return 4 * (ipt // 4 + 1) + max(band_passes(num_rows, num_cols, num_nonzeros, value_bytes), 0) + int(extra)
+
+
 def set_tuning(value_bytes: int, block_threads: int = 0, items_per_thread: int = 0, flags: int = 0) -> None:
     _check(load_library().mspmv_set_tuning(int(value_bytes), int(block_threads), int(items_per_thread), int(flags)),
            "mspmv_set_tuning")

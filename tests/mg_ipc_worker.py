@@ -56,7 +56,7 @@ for step in range(6):                                   # same x: nothing but th
     if step % 2 == 1:
         plan.synchronize()
         y = gather_y()
-        ok, worst = O.strict_check(csr, y, g, s, items_per_thread=16 + world)
+        ok, worst = O.strict_check(csr, y, g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=world))
         assert ok, (kind, prec, step, worst)
         first = y if first is None else first
         assert np.array_equal(y, first)                 # bitwise repeatable
@@ -68,7 +68,7 @@ for step in range(3):
     dist.barrier()                                      # (only so that rank 0 reads x after every rank's pushes of this step; the plan itself needs no barrier)
     got = plan.x(0).cpu().numpy()
     gg, ss = O.spmv_gold_acc64(csr, xh)
-    ok, worst = O.strict_check(csr, got, gg, ss, items_per_thread=16 + world)
+    ok, worst = O.strict_check(csr, got, gg, ss, M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=world))
     assert ok, ("iterated", kind, prec, step, worst)
     xh = got
     dist.barrier()

@@ -111,7 +111,7 @@ def test_forced_passes_match_oracle(forced_shape, shape, passes, prec):
     M.csrmv(val, off, col, dx, y=y, num_cols=cols, workspace=ws)
     torch.cuda.synchronize()
     g, s = O.spmv_gold_acc64(csr, x)
-    ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=16 + passes)
+    ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=passes))
     assert ok, (shape, passes, prec, worst)
     # rows without nonzeros are exact zeros, whatever the passes add
     empty = np.diff(csr.row_offsets) == 0
@@ -178,7 +178,7 @@ def test_forced_passes_on_the_reference_golden_matrices(forced_shape, case, prec
     if case["kind"] != "mtx":
         assert np.array_equal(yh, gold)
     g, s = O.spmv_gold_acc64(csr, x)
-    ok, worst = O.strict_check(csr, yh, g, s, items_per_thread=16 + 3)
+    ok, worst = O.strict_check(csr, yh, g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=3))
     assert ok, worst
     coords, keys, vals = M.debug_read_tiles(ws.buffer, csr.rows, csr.nnz, vb)
     want = O.tile_coords(csr, info["tile_items"])
@@ -212,7 +212,7 @@ def test_forced_passes_on_the_fp64_mid_size_tile(shape, passes):
         M.csrmv(val, off, col, dx, y=y2, num_cols=cols, workspace=ws)
         torch.cuda.synchronize()
         g, s = O.spmv_gold_acc64(csr, x)
-        ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=16 + passes)
+        ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=passes))
         assert ok, (shape, passes, worst)
         assert torch.equal(y, y2)
         M.set_band_passes(8, -1)

@@ -62,8 +62,7 @@ def bound_ipt(M, rows, cols, nnz, vb):
     """The `items_per_thread` term of the strict bound for a call of these sizes: the nonzeros a thread sums serially
     (the compiled tile's items per thread, rounded up to whole 4-element chunks) plus one re-association per column-band
     pass the call may run (include/mspmv.h: mspmv_get_band_passes)."""
-    ipt = M.launch_info(rows, nnz, vb)["items_per_thread"]
-    return 4 * (ipt // 4 + 1) + max(M.band_passes(rows, cols, nnz, vb), 0)
+    return M.serial_sum_depth(rows, cols, nnz, vb)
 
 
 def snapped_carries(csr, x, coords, tile_items, head_max):

@@ -114,7 +114,7 @@ def test_single_process_plan_peer_exchange(kind, parts, prec):
         plan.csrmv(); plan.synchronize()
         y = _gather_y(plan, row_split, csr.rows, dtype)
         g, s = O.spmv_gold_acc64(csr, x)
-        ok, worst = O.strict_check(csr, y, g, s, items_per_thread=16 + parts)
+        ok, worst = O.strict_check(csr, y, g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=parts))
         assert ok, (kind, parts, prec, worst)
         for _ in range(3):
             plan.csrmv(); plan.synchronize()
@@ -153,7 +153,7 @@ def test_plan_iterated_spmv_with_row_allgather(parts):
             plan.synchronize()
             g, s = O.spmv_gold_acc64(csr, xh)
             got = plan.x(0).cpu().numpy()
-            ok, worst = O.strict_check(csr, got, g, s, items_per_thread=16 + parts)
+            ok, worst = O.strict_check(csr, got, g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=parts))
             assert ok, (step, worst)
             xh = got                                       # follow the device iterate (errors do not compound in the check)
     finally:
@@ -176,7 +176,7 @@ def test_plan_rccl_backend_one_rank():
         plan.csrmv(); plan.synchronize()
         y = plan.y(0).cpu().numpy()
         g, s = O.spmv_gold_acc64(csr, x)
-        ok, worst = O.strict_check(csr, y, g, s, items_per_thread=16)
+        ok, worst = O.strict_check(csr, y, g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, 8))
         assert ok, worst
         plan.allgather_rows(); plan.synchronize()
         assert np.array_equal(plan.x(0).cpu().numpy(), y)
@@ -204,7 +204,7 @@ def test_plan_multi_process_form_single_rank():
             plan.csrmv()
         plan.synchronize()
         g, s = O.spmv_gold_acc64(csr, x)
-        ok, worst = O.strict_check(csr, plan.y(0).cpu().numpy(), g, s, items_per_thread=16)
+        ok, worst = O.strict_check(csr, plan.y(0).cpu().numpy(), g, s, items_per_thread=M.serial_sum_depth(csr.rows, csr.cols, csr.nnz, 4))
         assert ok, worst
     finally:
         plan.close()
@@ -259,9 +259,9 @@ def test_c5_full_size_eight_parts_every_row():
     finally:
         plan.close()
     whole = O.Csr(n, n, off.astype(np.int32), np.zeros(0, np.int32), np.zeros(0, np.float64))   # row lengths for the bound
-    ok, worst = O.strict_check(whole, y, gold[:n], sabs[:n], items_per_thread=16 + parts)
+    ok, worst = O.strict_check(whole, y, gold[:n], sabs[:n], items_per_thread=M.serial_sum_depth(n, n, edges, 8, extra=parts))
     assert ok, worst
-    ok, worst_whole = O.strict_check(whole, y_whole, gold[:n], sabs[:n], items_per_thread=16)
+    ok, worst_whole = O.strict_check(whole, y_whole, gold[:n], sabs[:n], items_per_thread=M.serial_sum_depth(n, n, edges, 8))
     assert ok, worst_whole
     print(f"\nC5 scale {scale}, {edges} edges, {parts} parts: worst |error|/bound = {worst:.3g} (8 parts), {worst_whole:.3g} (one GPU)")
 
@@ -324,3 +324,41 @@ def test_bench_multi_rank_path_on_one_device():
     assert out["exchange"]["exchange"] == MG.EXCHANGE_RCCL and out["exchange"]["carry_bytes_per_step"] == 8
     assert out["roofline"]["kernel_ms"]["tile"] > 0 and out["single_gpu_same_workload"]["ms_per_step"] > 0
     assert out["hot_column_plan"]["value"] > 0 and out["hot_column_plan"]["setup_ms_max_over_ranks"] > 0
+
+
+def _run_bench_plain(env_extra, *args, timeout=900):
+    """`python bench.py --gpus N ...` with NO launcher and no WORLD_SIZE in the environment: bench.py starts its ranks itself."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@gpu
+def test_bench_gpus_n_starts_its_own_ranks():
+    """the driver's plain `python bench.py --gpus N --steps K --warmup W` must produce the line by itself.  Here
+    N = 2 on this one-GPU box (MSPMV_BENCH_ONE_DEVICE=1: both ranks on cuda:0, gloo process group, the C operator with its
+    exchange falling back rccl -> hipIpc on every rank together); the JSON line is the last line of stdout."""
+    import json
+    r = _run_bench_plain({"MSPMV_BENCH_ONE_DEVICE": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), lines[-3:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "strong" and out["value"] > 0
+    assert "torch.distributed.run --nproc-per-node 2" in out["launched_by"]
+    assert out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["exchange"]["fallbacks"][0]["exchange"] == "rccl"
+    assert out["per_rank"]["nnz_per_rank_max"] > 0 and out["single_gpu_same_workload"]["value"] > 0
+    assert out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]["not_bitwise_equal"] <= 1
+
+
+def test_bench_gpus_n_self_launch_reports_failure_of_its_ranks():
+    """The same entry on a box without a GPU: the launcher is started, both ranks refuse ("needs a GPU"), and the plain command
+    returns their failure instead of a line -- no SystemExit about WORLD_SIZE any more."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = _run_bench_plain({}, "--gpus", "2", "--steps", "1", "--warmup", "0", timeout=300)
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and "needs torch.distributed.run" not in r.stderr + r.stdout
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())

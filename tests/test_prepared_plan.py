@@ -73,7 +73,7 @@ def test_plan_matches_oracle(shape, bands, prec):
     y = plan(d(x))
     torch.cuda.synchronize()
     g, s = O.spmv_gold_acc64(csr, x)
-    ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=16 + plan.bands)
+    ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=M.serial_sum_depth(csr.rows * plan.bands, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=plan.bands))
     assert ok, (shape, bands, prec, worst)
     # bitwise reproducible; alpha / beta; beta == 0 never reads y
     y2 = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
@@ -99,7 +99,7 @@ def test_plan_with_unsorted_rows(prec):
     plan = M.CsrMVPlan(d(csr.values), d(csr.row_offsets), d(csr.column_indices), 40000, bands=8)
     y = plan(d(x)).cpu().numpy()
     g, s = O.spmv_gold_acc64(csr, x)
-    ok, worst = O.strict_check(csr, y, g, s, items_per_thread=24)
+    ok, worst = O.strict_check(csr, y, g, s, items_per_thread=M.serial_sum_depth(csr.rows * 8, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=8))
     assert ok, worst
     assert np.array_equal(plan(d(x)).cpu().numpy(), y)
 
@@ -117,6 +117,6 @@ def test_plan_large_uniform_matrix_every_band_count():
     for bands in (8, 16, 32):
         plan = M.CsrMVPlan(A.values, A.row_offsets, A.column_indices, A.cols, bands=bands)
         y = plan(x)
-        ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=16 + bands)
+        ok, worst = O.strict_check(csr, y.cpu().numpy(), g, s, items_per_thread=M.serial_sum_depth(csr.rows * bands, csr.cols, csr.nnz, csr.values.dtype.itemsize, extra=bands))
         assert ok, (bands, worst)
         assert float((y - y_plain).abs().max()) < 1e-4
