@@ -590,11 +590,16 @@ def main():
                 whole_info = M.launch_info(W.rows, W.nnz, vb)
                 same = (part_info["items_per_thread"] == whole_info["items_per_thread"]
                         and M.band_passes(W.rows, W.cols, W.nnz, vb) <= 1 and M.band_passes(local_rows, cols, local_nnz, vb) <= 1)
+                neq = (ref != y0).nonzero()
                 single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": differ,
+                                                      "first_differing_row": int(neq[0].item()) if differ else None,
+                                                      "tile_items": int(part_info["tile_items"]),
                                                       "max_abs_diff": float((ref - y0).abs().max().item()) if y0.numel() else 0.0,
                                                       "same_tiling": bool(same),
                                                       "note": "bit for bit when rank 0's part and the whole matrix run the same tile shape through the same "
-                                                              "path (`same_tiling`: true at BASELINE's size); otherwise the same sums in another association"}
+                                                              "path (`same_tiling`: true at BASELINE's size), except inside rank 0's LAST tile, which ends where the part "
+                                                              "ends (another extent, possibly the other in-tile reduction): rows from `first_differing_row` on; "
+                                                              "otherwise the same sums in another association"}
             del W, wws, wy
 
     # anything native code left in C stdio buffers (RCCL prints a version banner at communicator creation) goes out on

@@ -253,6 +253,8 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
                                            row-snapped tiles on verified coordinate hints (tile_kernel_snap) */
 #define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
 #define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
+#define MSPMV_TUNE_NO_LEAN ((int32_t) 0x80000000u) /* one-launch kernel: closed tiles of short rows take the general flag/segmented-scan reduction too (default: the
+                                           row-by-row reduction, consume_tile_rows) */
 #define MSPMV_TUNE_MULTILEVEL_FIX 128 /* carry fix-up in two/three chunked levels (one launch each) instead of the one-launch owner-computes kernel */
 /* bits 24..27: block -> tile mapping of the tile kernel: 0 = default (runs of 64 consecutive tiles per XCD),
  * 15 = plain round-robin, else log2 of the run length. */

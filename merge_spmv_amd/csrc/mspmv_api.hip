@@ -38,6 +38,14 @@ static int small_max_tiles()
     return v;
 }
 #define SMALL_MAX_TILES (small_max_tiles())
+// Closed tiles of the one-launch kernel whose rows average at most this many nonzeros take the lean row-by-row reduction
+// (mspmv_kernels.hpp: consume_tile_rows); MSPMV_LEAN_AVG in the environment overrides it (read once: a re-tuning aid), 0 = never
+constexpr int LEAN_AVG_DEFAULT = 8;
+static int lean_avg_default()
+{
+    static const int v = [] { const char *e = getenv("MSPMV_LEAN_AVG"); const int n = e ? atoi(e) : -1; return n >= 0 ? n : LEAN_AVG_DEFAULT; }();
+    return v;
+}
 
 static_assert(TILE_MAP_CONTIGUOUS_CODE == TILE_MAP_CONTIGUOUS, "mapping code shared with the kernels");
 
@@ -361,7 +369,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (256ull << 20));
         const unsigned grid = (unsigned) L.num_tiles;
         const size_t xl = (size_t) p.x_lds * sizeof(V);
-#define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, rstart, carries, L.num_tiles, chunk_log2, lb)
+        const int lean_avg = (L.flags & MSPMV_TUNE_NO_LEAN) ? 0 : lean_avg_default();
+#define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, rstart, carries, L.num_tiles, chunk_log2, lb, lean_avg)
         if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
         else if (nt) MSPMV_LAUNCH_SNAP(false, true);
         else MSPMV_LAUNCH_SNAP(false, false);
@@ -922,7 +931,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_p
     const Shape *tab = value_bytes == 8 ? kShapesF64 : kShapesF32;
     const int count = value_bytes == 8 ? int(sizeof(kShapesF64) / sizeof(Shape)) : int(sizeof(kShapesF32) / sizeof(Shape));
     int allowed = MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_SCATTER_COORDS | MSPMV_TUNE_INTERP_COORDS | MSPMV_TUNE_NO_XLDS | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | MSPMV_TUNE_NO_FUSED |
-                  MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | 0xf000000;
+                  MSPMV_TUNE_FORCE_NT | MSPMV_TUNE_FORCE_TEMPORAL | MSPMV_TUNE_MULTILEVEL_FIX | MSPMV_TUNE_NO_LEAN | 0xf000000;
 #ifdef MSPMV_DEV
     allowed |= MSPMV_DEV_FLAG_BITS;        // development kernels (mspmv_dev.hpp): never in the product library
 #endif

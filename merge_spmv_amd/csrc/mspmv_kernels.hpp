@@ -867,17 +867,22 @@ __device__ __forceinline__ int prod_slot(int e)      // element index (>= 0) in 
     constexpr int EPU = 16 / (int) sizeof(V);
     return prod_unit<V, CPT>(e / EPU) * EPU + (e % EPU);
 }
+// (plain: the lean row phase of short-row tiles, consume_tile_rows, reads the products of a row at consecutive addresses)
+template <typename V, int CPT>
+__device__ __forceinline__ int prod_unit(int u, bool plain) { return plain ? u : prod_unit<V, CPT>(u); }
+template <typename V, int CPT>
+__device__ __forceinline__ int prod_slot(int e, bool plain) { return plain ? e : prod_slot<V, CPT>(e); }
 template <int CPT>
-__device__ __forceinline__ void st_prod_chunk(float *s_prod_raw, int chunk, const float (&v)[4])
+__device__ __forceinline__ void st_prod_chunk(float *s_prod_raw, int chunk, const float (&v)[4], bool plain = false)
 {
-    st_lds4(&s_prod_raw[4 * prod_unit<float, CPT>(chunk)], v);
+    st_lds4(&s_prod_raw[4 * prod_unit<float, CPT>(chunk, plain)], v);
 }
 template <int CPT>
-__device__ __forceinline__ void st_prod_chunk(double *s_prod_raw, int chunk, const double (&v)[4])
+__device__ __forceinline__ void st_prod_chunk(double *s_prod_raw, int chunk, const double (&v)[4], bool plain = false)
 {
     double2v a, b; a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
-    *reinterpret_cast<double2v *>(&s_prod_raw[2 * prod_unit<double, CPT>(2 * chunk)]) = a;
-    *reinterpret_cast<double2v *>(&s_prod_raw[2 * prod_unit<double, CPT>(2 * chunk + 1)]) = b;
+    *reinterpret_cast<double2v *>(&s_prod_raw[2 * prod_unit<double, CPT>(2 * chunk, plain)]) = a;
+    *reinterpret_cast<double2v *>(&s_prod_raw[2 * prod_unit<double, CPT>(2 * chunk + 1, plain)]) = b;
 }
 __device__ __forceinline__ void ld_unit(const float *p, float *out)
 { const float4v w = *reinterpret_cast<const float4v *>(p); out[0] = w.x; out[1] = w.y; out[2] = w.z; out[3] = w.w; }
@@ -1010,6 +1015,90 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         if (r == 0) sum += first_row_carry;
         if (AXPBY) y[r] = p.alpha * sum + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
         else y[r] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LEAN in-tile reduction for tiles of short rows (tile_kernel_snap): when a row-snapped tile is CLOSED -- it starts at the
+// first nonzero of a row and ends with the last nonzero of a row: nothing flows in, nothing is left open -- and its rows
+// are short on average, the flag bits, the per-thread running sums, the block-wide segmented scan, the write-back of the
+// running sums and two of the three barriers of consume_tile_flags buy nothing: a thread takes a whole row and adds
+// up its products straight from LDS.  What bounds a matrix of 4-7 nonzeros per row that lives in the Infinity Cache (the
+// reference's --dense=5, the 5/7-point grids) is VALU issue, not bytes (profiles/r03_short_rows/): the general reduction
+// costs ~290 vector instructions per wave and tile, this one ~60 on such a tile.
+//   * products were staged at their RAW positions (prod_unit(u, plain = true)), so row r's products are the consecutive
+//     LDS elements [pshift + e0, pshift + e1), read with immediate offsets from one address per row;
+//   * summation order: strictly left to right from +0.0 -- for every row of at most LEAN_SERIAL nonzeros that IS the order of
+//     the reference's SpmvGold (gpu_spmv.cu:262-278: partial = 0; partial += v * x, one product at a time), so such rows
+//     are bit for bit the sequential definition's; longer rows (rare in a tile that qualifies) are summed by the 16 lanes
+//     of a DPP row, strided, then folded: another fixed order;
+//   * which reduction a tile takes depends only on its boundaries (closed, nonzeros <= lean_avg * rows), i.e. on the
+//     matrix and the tile shape -- never on hints, timing or the device.
+// ---------------------------------------------------------------------------
+constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one thread
+template <typename V, int BLOCK, int IPT, bool AXPBY>
+__device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coord c0, int tile_rows, const end16_t *s_end,
+                                                  const V *s_prod_raw, int pshift, Carry<V> *__restrict__ carry_out)
+{
+    const int tid = threadIdx.x;
+    if (tid == BLOCK - 1) { Carry<V> c; c.key = c0.x + tile_rows; c.value = (V) 0; *carry_out = c; }     // (nothing open: what mspmv_debug_read_tiles reports)
+    V *__restrict__ y = p.y + c0.x;
+    for (int r0 = 0; r0 < tile_rows; r0 += BLOCK) {           // block-uniform trip count
+        const int r = r0 + tid;
+        const bool valid = r < tile_rows;
+        int e0 = 0, e1 = 0;
+        if (valid) { e1 = s_end[r]; e0 = r > 0 ? s_end[r - 1] : 0; }
+        const int len = e1 - e0;
+        const V *src = s_prod_raw + (pshift + e0);
+        V acc = (V) 0;
+#pragma unroll
+        for (int k0 = 0; k0 < LEAN_SERIAL; k0 += 4) {
+            if (__ballot(k0 < len) == 0ull) break;                // wave-uniform
+            V v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = src[k0 + j];       // (in the LDS arrays for any lane: pshift + e0 + 15 < SLOTS)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = k0 + j < len ? acc + v[j] : acc;
+        }
+        // rows longer than that: four at a time, each by the 16 lanes of one DPP row -- lane j adds products j, j + 16, ... from
+        // +0.0, the 16 partial sums are folded left to right (row_shr 1, 2, 4, 8) -- and the total replaces what the owner has
+        unsigned long long pending = __ballot(len > LEAN_SERIAL);
+        while (pending != 0ull) {                                 // wave-uniform
+            int owner[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
+                pending &= pending - 1ull;                        // (0 stays 0)
+            }
+            const int lane = tid & (WAVE - 1), grp = lane >> 4, j = lane & 15;
+            const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
+            // (both shuffles by ALL lanes, the selection afterwards: a lane switched off by a branch cannot be read from)
+            const int g_e0 = __shfl(e0, own < 0 ? 0 : own, WAVE);
+            const int g_len_any = __shfl(len, own < 0 ? 0 : own, WAVE);
+            const int g_len = own < 0 ? 0 : g_len_any;
+            const V *gsrc = s_prod_raw + (pshift + g_e0);
+            V part = (V) 0;
+            for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
+                V v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) part += v[u];
+            }
+            part += dpp_move<0x111, 0xf>((V) 0, part);           // row_shr:1
+            part += dpp_move<0x112, 0xf>((V) 0, part);           // row_shr:2
+            part += dpp_move<0x114, 0xf>((V) 0, part);           // row_shr:4
+            part += dpp_move<0x118, 0xf>((V) 0, part);           // row_shr:8  -> lane 15 of every row holds its total
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const V total = __shfl(part, 16 * g + 15, WAVE);
+                if (lane == owner[g]) acc = total;
+            }
+        }
+        if (valid) {
+            if (AXPBY) y[r] = p.alpha * acc + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
+            else y[r] = acc;
+        }
     }
 }
 
@@ -1149,8 +1238,10 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false>
 __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw, V *s_prod_raw,
-                                           int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1)
+                                           int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1,
+                                           bool lean = false)
 {
+    // lean (block-uniform; FL only): the tile will be reduced row by row (consume_tile_rows) -- no row-start bits, products at their raw positions
     constexpr int CPT = IPT / 4 + 1;
     const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
     const int *__restrict__ row_offsets = p.row_end - 1;
@@ -1203,14 +1294,14 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
             const int r = 4 * q - eshift + j;
             const bool in = r >= 0 && r < tile_rows && i <= last_full_ro;
             v[j] = in ? ro[k].get(j) - c0.y : 0x3fffffff;
-            if (FL && (unsigned) v[j] < (unsigned) tile_nnz) {
+            if (FL && !lean && (unsigned) v[j] < (unsigned) tile_nnz) {
                 const int b = (c0.y - a0) + v[j];
                 atomicOr(&s_flag[b >> 5], 1u << (b & 31));
             }
         }
         st_lds4(&s_end_raw[4 * q], v);
     }
-    if (FL && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - a0));
+    if (FL && !lean && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - a0));
     // ---- stage products
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -1224,7 +1315,7 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
             if constexpr (LAZY) prod[i] = in ? bval[k].get(i) * xv[k][i] : (V) 0;
             else prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
         }
-        if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
+        if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod, lean);
         else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
     }
     // ---- ragged array tails (at most 3 elements each; only the tile that reaches the array
@@ -1238,14 +1329,14 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
         if (nz_tail && j < c1.y && j >= c0.y) {
             const int c = ld_stream<NT>(p.cols + j);
             const bool inb = !BAND || (unsigned) (c - p.band_lo) < (unsigned) p.band_len;
-            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0) : swz_prod(j - a0)] = inb ? ld_stream<NT>(p.values + j) * (XL ? s_x[c] : p.x[c]) : (V) 0;
+            s_prod_raw[FL ? prod_slot<V, CPT>(j - a0, lean) : swz_prod(j - a0)] = inb ? ld_stream<NT>(p.values + j) * (XL ? s_x[c] : p.x[c]) : (V) 0;
         }
         const int i = last_full_ro + 4 + tid;                       // absolute d_row_offsets index
         const int r = i - first;
         if (ro_tail && r >= 0 && r < tile_rows) {
             const int v = ld_stream<NT>(row_offsets + i) - c0.y;
             s_end_raw[r + eshift] = (typename EndType<FL>::type) v;
-            if (FL && (unsigned) v < (unsigned) tile_nnz) atomicOr(&s_flag[((c0.y - a0) + v) >> 5], 1u << (((c0.y - a0) + v) & 31));
+            if (FL && !lean && (unsigned) v < (unsigned) tile_nnz) atomicOr(&s_flag[((c0.y - a0) + v) >> 5], 1u << (((c0.y - a0) + v) & 31));
         }
     }
     __syncthreads();
@@ -1267,7 +1358,7 @@ template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, boo
 __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
                                                     const TileRegs<V, BLOCK, IPT> &regs,
                                                     typename EndType<FL>::type *s_end_raw, V *s_prod_raw, unsigned *s_flag,
-                                                    const V *s_x = nullptr, int tid_in = -1)
+                                                    const V *s_x = nullptr, int tid_in = -1, bool lean = false)
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
@@ -1321,7 +1412,7 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ro[k].get(j) - c0.y;
             st_lds4(&s_end_raw[4 * q], v);
-            if (FL) {
+            if (FL && !lean) {
                 // row starts inside the tile (rows before the tile give v <= 0, rows after it
                 // v >= tile_nnz; v == 0 is the tile's first nonzero, flagged anyway)
                 const int tile_nnz = c1.y - c0.y, pshift = c0.y - (c0.y & ~3);
@@ -1331,7 +1422,7 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
             }
         }
     }
-    if (FL && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - (c0.y & ~3)));
+    if (FL && !lean && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - (c0.y & ~3)));
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
@@ -1342,7 +1433,7 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
             else if constexpr (BAND) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? regs.val[k].get(i) * xv[k][i] : (V) 0;
             else prod[i] = regs.val[k].get(i) * xv[k][i];
         }
-        if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod);
+        if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod, lean);
         else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
     }
     __syncthreads();
@@ -1362,19 +1453,20 @@ __device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1,
 template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool BAND = false>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw,
-                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1)
+                                           V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1,
+                                           bool lean = false)
 {
     const bool interior = tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro);      // block-uniform
     if constexpr (BAND) {              // (a banded pass is for an x beyond L2: never the LDS copy)
         if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, false, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, tid_in);
         else stage_tile_careful<V, BLOCK, IPT, NT, FL, false, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, tid_in);
     } else if (s_x != nullptr) {              // block-uniform: x lives in LDS (tiny x only)
-        if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x);
-        else stage_tile_careful<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+        if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x, -1, lean);
+        else stage_tile_careful<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
     } else if (interior)
-        stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag);
+        stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, -1, lean);
     else
-        stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag);
+        stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, -1, lean);
 }
 
 // x -> LDS (dynamic shared memory, p.x_lds entries) at block start; nullptr when the call does not use it.
@@ -1895,7 +1987,7 @@ constexpr int snap_head_max()
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Params<V> p, Coord *__restrict__ coords,
                                                            int *__restrict__ rstart, Carry<V> *__restrict__ carries, int num_tiles,
-                                                           int xcd_chunk_log2, LookBack lb)
+                                                           int xcd_chunk_log2, LookBack lb, int lean_avg)
 {
     constexpr int TILE = BLOCK * IPT;
     constexpr int NW = BLOCK / WAVE;
@@ -1955,6 +2047,8 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     Coord c0, c1;
     c0.x = x0; c0.y = snap0 ? rs0 : y0;
     c1.x = x1; c1.y = snap1 ? rs1 : y1;
+    // closed tile of short rows (block-uniform; consume_tile_rows): no row-start bits, raw product positions, one LDS phase
+    bool lean = snap0 && snap1 && (long long) (c1.y - c0.y) <= (long long) lean_avg * (c1.x - c0.x);
     // hints: anything may be in there.  Only values that keep every speculative access inside the arrays and the LDS tile
     // are tried at all (block-uniform)
     bool good = x0 >= 0 && x0 <= x1 && x1 <= p.rows && y0 >= 0 && y1 >= y0 && y1 <= p.nnz && rs0 >= 0 && rs0 <= y0 &&
@@ -1974,7 +2068,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         if (late_barrier) __syncthreads();
-        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
         // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
         // memory latency; a barrier is cheap)
         {
@@ -2002,9 +2096,10 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         snap0 = y0 - rs0 <= HEAD_MAX; snap1 = y1 - rs1 <= HEAD_MAX;
         c0.x = x0; c0.y = snap0 ? rs0 : y0;
         c1.x = x1; c1.y = snap1 ? rs1 : y1;
+        lean = snap0 && snap1 && (long long) (c1.y - c0.y) <= (long long) lean_avg * (c1.x - c0.x);
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
-        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x);
+        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
     }
     if (tid == 0) {
         // the hints of the next call on this temp storage (and what mspmv_debug_read_tiles returns): stored when they were not there
@@ -2023,8 +2118,9 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     }
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
-    consume_tile_flags<V, BLOCK, IPT, AXPBY, 4>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                                s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lb, tile, !snap1, first_piece);
+    if (lean) consume_tile_rows<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, s_end_raw + eshift, s_prod_raw, pshift, carries + tile);
+    else consume_tile_flags<V, BLOCK, IPT, AXPBY, 4>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
+                                                     s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lb, tile, !snap1, first_piece);
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

@@ -313,7 +313,8 @@ def test_bench_multi_rank_path_on_one_device():
     assert out["n_gpus"] == 2 and out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["value"] > 0
     # rank 0's tiles are the first tiles of the one-GPU call of the same job: its rows agree bit for bit
     cmp = out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]
-    assert cmp["same_tiling"] and cmp["not_bitwise_equal"] <= 1
+    # ... except inside rank 0's last tile, which ends where the part ends instead of a tile_items further on
+    assert cmp["same_tiling"] and (cmp["not_bitwise_equal"] == 0 or cmp["rows"] - cmp["first_differing_row"] <= cmp["tile_items"])
     # (d) an exchange that cannot be set up (two RCCL ranks on one device are refused) makes every rank fall back together
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                       "MSPMV_BENCH_FORCE_C_OPERATOR": "1"}, 2, *small, "--exchange", "rccl")
@@ -349,7 +350,8 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert "torch.distributed.run --nproc-per-node 2" in out["launched_by"]
     assert out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["exchange"]["fallbacks"][0]["exchange"] == "rccl"
     assert out["per_rank"]["nnz_per_rank_max"] > 0 and out["single_gpu_same_workload"]["value"] > 0
-    assert out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]["not_bitwise_equal"] <= 1
+    cmp = out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]
+    assert cmp["not_bitwise_equal"] == 0 or cmp["rows"] - cmp["first_differing_row"] <= cmp["tile_items"]
 
 
 def test_bench_gpus_n_self_launch_reports_failure_of_its_ranks():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/band_passes_bench.py [case ...] -- the column-band passes of the stateless call (mspmv_set_band_passes):
-never / automatic / forced 2, 3, 4 passes on uniformly spread matrices of growing x (what the policy table in
+never / automatic / forced 2, 3, 4 passes (BAND_FORCE=2,3,4,5,6,8 in the environment: other counts) on uniformly spread matrices of growing x (what the policy table in
 csrc/mspmv_api.hip: band_passes_for was read from), on the headline C2 in both precisions, and on matrices the
 device-side windows must refuse (R-MAT, banded, streaming) -- where `overhead` re-times never vs automatic,
 interleaved, 5 x 300 calls.  Every result is checked (strict bound, reproducibility) before it is timed.
@@ -81,7 +81,8 @@ def sweep(only):
         eps = 2.0 ** -24 if vb == 4 else 2.0 ** -53
         tol = 2.0 * (torch.ceil(torch.log2(lens.double() + 1)) + 32) * eps * s
         out = []
-        for label, passes in (("never", -1), ("auto", 0), ("force2", 2), ("force3", 3), ("force4", 4)):
+        forced = [int(v) for v in os.environ.get("BAND_FORCE", "2,3,4").split(",") if v]
+        for label, passes in [("never", -1), ("auto", 0)] + [(f"force{b}", b) for b in forced]:
             M.set_band_passes(vb, passes)
             y.fill_(float("nan")); call(); torch.cuda.synchronize()
             bad = int(((y.double() - g).abs() > tol).sum()) + int(torch.isnan(y).sum())
