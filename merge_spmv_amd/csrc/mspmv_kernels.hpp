@@ -1210,6 +1210,34 @@ struct TileRegs {
     Vec4<V> val[CPT];
 };
 
+// fp64 values of a 4-element chunk are 32 bytes: fetched as two 16-byte loads per lane, each load instruction of a wave would
+// touch every 128-byte line of the wave's 2 KB twice, half a line at a time -- and the second touch of a line read with a
+// non-temporal load is another request to L2 (measured: making the second half an ordinary load, which then hits the CU's
+// cache, is worth 5-9 % on dense32 / 7-point-grid streams, but gives the lines ordinary retention and costs the
+// gather-bound matrices 2-3 % of their x hits).  Instead the two loads are laid out line by line: in the first, lanes 0-31
+// fetch the first half of their own chunk and lanes 32-63 the SECOND half of the chunk of lane - 32 (8 whole lines); in the
+// second, lanes 0-31 fetch the first half of the chunk of lane + 32 and lanes 32-63 their own second half; four
+// v_permlane32_swap (gfx950) then hand every lane its own 32 bytes.  Wave-uniform control flow required.
+template <bool NT>
+__device__ __forceinline__ Vec4<double> ld_stream4_linewise(const double *base, int e_own, int e_partner, int tid)
+{
+    const bool hi = (tid & 32) != 0;
+    const double2v *pa = reinterpret_cast<const double2v *>(base + (hi ? e_partner + 2 : e_own));
+    const double2v *pb = reinterpret_cast<const double2v *>(base + (hi ? e_own + 2 : e_partner));
+    const double2v a = NT ? __builtin_nontemporal_load(pa) : *pa;
+    const double2v b = NT ? __builtin_nontemporal_load(pb) : *pb;
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    uint4v ua = __builtin_bit_cast(uint4v, a), ub = __builtin_bit_cast(uint4v, b);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        // lanes 32-63 of the first operand <-> lanes 0-31 of the second
+        const auto sw = __builtin_amdgcn_permlane32_swap(ua[d], ub[d], false, false);
+        ua[d] = sw[0]; ub[d] = sw[1];
+    }
+    Vec4<double> r; r.a = __builtin_bit_cast(double2v, ua); r.b = __builtin_bit_cast(double2v, ub);
+    return r;
+}
+
 template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
                                                     TileRegs<V, BLOCK, IPT> &r, int tid_in = -1)
@@ -1227,7 +1255,11 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
         // cached address), so no byte of HBM traffic is spent on data this tile does not use
         e0 = (e0 < c1.y && e0 <= last_full) ? e0 : safe;
         r.col[k] = ld_stream4<NT>(p.cols + e0);
-        if (VALS) r.val[k] = ld_stream4<NT>(p.values + e0);      // (!VALS: column-band passes fetch the values later, by band)
+        if constexpr (VALS && sizeof(V) == 8 && NT) {             // (ordinary loads: the second half hits the CU's cache anyway, and the swaps cost 3 % on dense5)
+            int e1 = a0 + 4 * ((tid ^ 32) + k * BLOCK);          // the chunk of the lane 32 away, by the same rule
+            e1 = (e1 < c1.y && e1 <= last_full) ? e1 : safe;
+            r.val[k] = ld_stream4_linewise<NT>(p.values, e0, e1, tid);
+        } else if constexpr (VALS) r.val[k] = ld_stream4<NT>(p.values + e0);      // (!VALS: column-band passes fetch the values later, by band)
     }
 }
 
@@ -2004,6 +2036,15 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
 
     const int tid = threadIdx.x;
+#ifdef MSPMV_DEV
+    // development (tools/trace_snap.py): 100 MHz wall-clock stamps of this block's phases, 8 words per block
+    unsigned long long *const snap_tr = g_mspmv_trace ? g_mspmv_trace + (size_t) blockIdx.x * 8 : nullptr;
+#define MSPMV_SNAP_TR(i) do { if (snap_tr && tid == 0) snap_tr[i] = wall_clock64(); } while (0)
+    if (snap_tr && tid == 0) { snap_tr[6] = __builtin_amdgcn_s_getreg(63492); snap_tr[7] = __builtin_amdgcn_s_getreg(6164); }
+#else
+#define MSPMV_SNAP_TR(i) do { } while (0)
+#endif
+    MSPMV_SNAP_TR(0);
     const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     // the hints: the tile's two boundaries (x, y) and their row starts.  The large-problem shapes read them THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
@@ -2035,6 +2076,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     if constexpr (!SCALAR_HINTS) {
         hint_c.x = s_bnd[0]; hint_r.x = s_bnd[1]; hint_c.y = s_bnd[2]; hint_c.z = s_bnd[3]; hint_r.y = s_bnd[4]; hint_c.w = s_bnd[5];
     }
+    MSPMV_SNAP_TR(1);
     const int total = p.rows + p.nnz;                               // < 2^31
     const long long d0l = (long long) tile * TILE, d1l = d0l + TILE;
     const int d0 = (int) (d0l < total ? d0l : total), d1 = (int) (d1l < total ? d1l : total);
@@ -2067,8 +2109,10 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         }
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
+        MSPMV_SNAP_TR(2);
         if (late_barrier) __syncthreads();
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
+        MSPMV_SNAP_TR(3);
         // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
         // memory latency; a barrier is cheap)
         {
@@ -2121,6 +2165,11 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     if (lean) consume_tile_rows<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, s_end_raw + eshift, s_prod_raw, pshift, carries + tile);
     else consume_tile_flags<V, BLOCK, IPT, AXPBY, 4>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
                                                      s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lb, tile, !snap1, first_piece);
+    MSPMV_SNAP_TR(4);
+#ifdef MSPMV_DEV
+    if (snap_tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MSPMV_SNAP_TR(5); }      // (y stores acknowledged)
+#endif
+#undef MSPMV_SNAP_TR
 }
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

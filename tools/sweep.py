@@ -35,6 +35,12 @@ def workloads(names):
         elif n == "rmat":
             A = G.rmat_csr(22, 60_000_000, dtype=torch.float64, seed=G.SEED_C3)
             yield "rmat22_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "rmat24":
+            A = G.rmat_csr(24, 250_000_000, dtype=torch.float64, seed=G.SEED_C5)
+            yield "rmat24_250M_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "orkut":
+            A = G.rmat_symmetric_csr(G.C3_ORKUT_SCALE, G.C3_ORKUT_EDGES, dtype=torch.float64, seed=G.SEED_C3)
+            yield "orkut_sized_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "web":
             A = G.rmat_csr(20, 3_105_536, dtype=torch.float64, seed=G.SEED_C3)
             yield "rmat20_webbase_like_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
