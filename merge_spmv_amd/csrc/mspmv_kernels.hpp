@@ -1036,6 +1036,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
 //     matrix and the tile shape -- never on hints, timing or the device.
 // ---------------------------------------------------------------------------
 constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one thread
+constexpr int LEAN_BATCH = 8;          // products of a row requested before any is looked at
 template <typename V, int BLOCK, int IPT, bool AXPBY>
 __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coord c0, int tile_rows, const end16_t *s_end,
                                                   const V *s_prod_raw, int pshift, Carry<V> *__restrict__ carry_out)
@@ -1043,61 +1044,81 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
     const int tid = threadIdx.x;
     if (tid == BLOCK - 1) { Carry<V> c; c.key = c0.x + tile_rows; c.value = (V) 0; *carry_out = c; }     // (nothing open: what mspmv_debug_read_tiles reports)
     V *__restrict__ y = p.y + c0.x;
-    for (int r0 = 0; r0 < tile_rows; r0 += BLOCK) {           // block-uniform trip count
-        const int r = r0 + tid;
-        const bool valid = r < tile_rows;
-        int e0 = 0, e1 = 0;
-        if (valid) { e1 = s_end[r]; e0 = r > 0 ? s_end[r - 1] : 0; }
-        const int len = e1 - e0;
-        const V *src = s_prod_raw + (pshift + e0);
-        V acc = (V) 0;
+    // Two rows per thread and iteration (r, r + BLOCK), and every LDS read of a step requested before the first is waited for:
+    // the row ends of both rows, then the first LEAN_BATCH products of both (read whether the row has them or not: they lie
+    // inside the LDS arrays for any lane, pshift + e0 + 15 < SLOTS) -- two LDS round trips per pair of rows instead of six.
+    for (int r0 = 0; r0 < tile_rows; r0 += 2 * BLOCK) {           // block-uniform trip count
+        int e0[2], len[2]; bool valid[2];
 #pragma unroll
-        for (int k0 = 0; k0 < LEAN_SERIAL; k0 += 4) {
-            if (__ballot(k0 < len) == 0ull) break;                // wave-uniform
-            V v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = src[k0 + j];       // (in the LDS arrays for any lane: pshift + e0 + 15 < SLOTS)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = k0 + j < len ? acc + v[j] : acc;
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + h * BLOCK + tid;
+            valid[h] = r < tile_rows;
+            const int rr = valid[h] ? r : 0;                       // (row 0 exists: tile_rows > 0 here)
+            const int e1 = s_end[rr];
+            e0[h] = rr > 0 ? s_end[rr - 1] : 0;
+            len[h] = valid[h] ? e1 - e0[h] : 0;
         }
-        // rows longer than that: four at a time, each by the 16 lanes of one DPP row -- lane j adds products j, j + 16, ... from
-        // +0.0, the 16 partial sums are folded left to right (row_shr 1, 2, 4, 8) -- and the total replaces what the owner has
-        unsigned long long pending = __ballot(len > LEAN_SERIAL);
-        while (pending != 0ull) {                                 // wave-uniform
-            int owner[4];
+        V v[2][LEAN_BATCH];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
-                pending &= pending - 1ull;                        // (0 stays 0)
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < LEAN_BATCH; ++j) v[h][j] = s_prod_raw[pshift + e0[h] + j];
+        V acc[2] = {(V) 0, (V) 0};
+#pragma unroll
+        for (int j = 0; j < LEAN_BATCH; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[h] = j < len[h] ? acc[h] + v[h][j] : acc[h];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const V *src = s_prod_raw + (pshift + e0[h]);
+            // rows of LEAN_BATCH + 1 ... LEAN_SERIAL nonzeros: the same left-to-right order, continued
+            if (__ballot(len[h] > LEAN_BATCH) != 0ull) {
+                V w[LEAN_SERIAL - LEAN_BATCH];
+#pragma unroll
+                for (int j = 0; j < LEAN_SERIAL - LEAN_BATCH; ++j) w[j] = src[LEAN_BATCH + j];
+#pragma unroll
+                for (int j = 0; j < LEAN_SERIAL - LEAN_BATCH; ++j) acc[h] = LEAN_BATCH + j < len[h] ? acc[h] + w[j] : acc[h];
             }
-            const int lane = tid & (WAVE - 1), grp = lane >> 4, j = lane & 15;
-            const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
-            // (both shuffles by ALL lanes, the selection afterwards: a lane switched off by a branch cannot be read from)
-            const int g_e0 = __shfl(e0, own < 0 ? 0 : own, WAVE);
-            const int g_len_any = __shfl(len, own < 0 ? 0 : own, WAVE);
-            const int g_len = own < 0 ? 0 : g_len_any;
-            const V *gsrc = s_prod_raw + (pshift + g_e0);
-            V part = (V) 0;
-            for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
-                V v[4];
+            // rows longer than that: four at a time, each by the 16 lanes of one DPP row -- lane j adds products j, j + 16, ... from
+            // +0.0, the 16 partial sums are folded left to right (row_shr 1, 2, 4, 8) -- and the total replaces what the owner has
+            unsigned long long pending = __ballot(len[h] > LEAN_SERIAL);
+            while (pending != 0ull) {                                 // wave-uniform
+                int owner[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
+                for (int g = 0; g < 4; ++g) {
+                    owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
+                    pending &= pending - 1ull;                        // (0 stays 0)
+                }
+                const int lane = tid & (WAVE - 1), grp = lane >> 4, j = lane & 15;
+                const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
+                // (both shuffles by ALL lanes, the selection afterwards: a lane switched off by a branch cannot be read from)
+                const int g_e0 = __shfl(e0[h], own < 0 ? 0 : own, WAVE);
+                const int g_len_any = __shfl(len[h], own < 0 ? 0 : own, WAVE);
+                const int g_len = own < 0 ? 0 : g_len_any;
+                const V *gsrc = s_prod_raw + (pshift + g_e0);
+                V part = (V) 0;
+                for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
+                    V u4[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) part += v[u];
+                    for (int u = 0; u < 4; ++u) u4[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) part += u4[u];
+                }
+                part += dpp_move<0x111, 0xf>((V) 0, part);           // row_shr:1
+                part += dpp_move<0x112, 0xf>((V) 0, part);           // row_shr:2
+                part += dpp_move<0x114, 0xf>((V) 0, part);           // row_shr:4
+                part += dpp_move<0x118, 0xf>((V) 0, part);           // row_shr:8  -> lane 15 of every row holds its total
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const V total = __shfl(part, 16 * g + 15, WAVE);
+                    if (lane == owner[g]) acc[h] = total;
+                }
             }
-            part += dpp_move<0x111, 0xf>((V) 0, part);           // row_shr:1
-            part += dpp_move<0x112, 0xf>((V) 0, part);           // row_shr:2
-            part += dpp_move<0x114, 0xf>((V) 0, part);           // row_shr:4
-            part += dpp_move<0x118, 0xf>((V) 0, part);           // row_shr:8  -> lane 15 of every row holds its total
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const V total = __shfl(part, 16 * g + 15, WAVE);
-                if (lane == owner[g]) acc = total;
+            if (valid[h]) {
+                const int r = r0 + h * BLOCK + tid;
+                if (AXPBY) y[r] = p.alpha * acc[h] + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
+                else y[r] = acc[h];
             }
-        }
-        if (valid) {
-            if (AXPBY) y[r] = p.alpha * acc + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
-            else y[r] = acc;
         }
     }
 }
@@ -1218,16 +1239,24 @@ struct TileRegs {
 // fetch the first half of their own chunk and lanes 32-63 the SECOND half of the chunk of lane - 32 (8 whole lines); in the
 // second, lanes 0-31 fetch the first half of the chunk of lane + 32 and lanes 32-63 their own second half; four
 // v_permlane32_swap (gfx950) then hand every lane its own 32 bytes.  Wave-uniform control flow required.
+// (The swaps are a separate step, linewise_own, done by the staging right before the products: next to the loads the compiler
+//  waits for each pair before it requests the next one.)
 template <bool NT>
 __device__ __forceinline__ Vec4<double> ld_stream4_linewise(const double *base, int e_own, int e_partner, int tid)
 {
     const bool hi = (tid & 32) != 0;
     const double2v *pa = reinterpret_cast<const double2v *>(base + (hi ? e_partner + 2 : e_own));
     const double2v *pb = reinterpret_cast<const double2v *>(base + (hi ? e_own + 2 : e_partner));
-    const double2v a = NT ? __builtin_nontemporal_load(pa) : *pa;
-    const double2v b = NT ? __builtin_nontemporal_load(pb) : *pb;
+    Vec4<double> r;
+    r.a = NT ? __builtin_nontemporal_load(pa) : *pa;
+    r.b = NT ? __builtin_nontemporal_load(pb) : *pb;
+    return r;
+}
+// what ld_stream4_linewise fetched -> every lane's own four values.  Wave-uniform control flow required.
+__device__ __forceinline__ Vec4<double> linewise_own(const Vec4<double> &w)
+{
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-    uint4v ua = __builtin_bit_cast(uint4v, a), ub = __builtin_bit_cast(uint4v, b);
+    uint4v ua = __builtin_bit_cast(uint4v, w.a), ub = __builtin_bit_cast(uint4v, w.b);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         // lanes 32-63 of the first operand <-> lanes 0-31 of the second
@@ -1237,6 +1266,10 @@ __device__ __forceinline__ Vec4<double> ld_stream4_linewise(const double *base, 
     Vec4<double> r; r.a = __builtin_bit_cast(double2v, ua); r.b = __builtin_bit_cast(double2v, ub);
     return r;
 }
+__device__ __forceinline__ Vec4<float> linewise_own(const Vec4<float> &w) { return w; }
+// values as issue_nonzero_loads left them in the tile's registers -> the values of the lane's own chunk k
+template <typename V, bool NT, bool LAZY>
+constexpr bool vals_linewise() { return sizeof(V) == 8 && NT && !LAZY; }
 
 template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
@@ -1255,7 +1288,7 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
         // cached address), so no byte of HBM traffic is spent on data this tile does not use
         e0 = (e0 < c1.y && e0 <= last_full) ? e0 : safe;
         r.col[k] = ld_stream4<NT>(p.cols + e0);
-        if constexpr (VALS && sizeof(V) == 8 && NT) {             // (ordinary loads: the second half hits the CU's cache anyway, and the swaps cost 3 % on dense5)
+        if constexpr (VALS && vals_linewise<V, NT, false>()) {     // (ordinary loads: the second half hits the CU's cache anyway, and the swaps cost 3 % on dense5)
             int e1 = a0 + 4 * ((tid ^ 32) + k * BLOCK);          // the chunk of the lane 32 away, by the same rule
             e1 = (e1 < c1.y && e1 <= last_full) ? e1 : safe;
             r.val[k] = ld_stream4_linewise<NT>(p.values, e0, e1, tid);
@@ -1335,6 +1368,11 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     }
     if (FL && !lean && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - a0));
     // ---- stage products
+    Vec4<V> own_val[LAZY ? 1 : CPT];
+    if constexpr (!LAZY) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) own_val[k] = vals_linewise<V, NT, LAZY>() ? linewise_own(regs.val[k]) : regs.val[k];
+    }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
@@ -1345,7 +1383,7 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
             const bool in = BAND ? ((in_band >> (4 * k + i)) & 1u) != 0u
                                  : (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
             if constexpr (LAZY) prod[i] = in ? bval[k].get(i) * xv[k][i] : (V) 0;
-            else prod[i] = in ? regs.val[k].get(i) * xv[k][i] : (V) 0;
+            else prod[i] = in ? own_val[k].get(i) * xv[k][i] : (V) 0;
         }
         if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod, lean);
         else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
@@ -1455,6 +1493,11 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
         }
     }
     if (FL && !lean && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - (c0.y & ~3)));
+    Vec4<V> own_val[LAZY ? 1 : CPT];
+    if constexpr (!LAZY) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) own_val[k] = vals_linewise<V, NT, LAZY>() ? linewise_own(regs.val[k]) : regs.val[k];
+    }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
@@ -1462,8 +1505,8 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if constexpr (LAZY) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? bval[k].get(i) * xv[k][i] : (V) 0;
-            else if constexpr (BAND) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? regs.val[k].get(i) * xv[k][i] : (V) 0;
-            else prod[i] = regs.val[k].get(i) * xv[k][i];
+            else if constexpr (BAND) prod[i] = ((in_band >> (4 * k + i)) & 1u) ? own_val[k].get(i) * xv[k][i] : (V) 0;
+            else prod[i] = own_val[k].get(i) * xv[k][i];
         }
         if (FL) st_prod_chunk<CPT>(s_prod_raw, chunk, prod, lean);
         else st_lds4(&s_prod_raw[swz_prod(4 * chunk)], prod);
@@ -1510,6 +1553,32 @@ __device__ __forceinline__ const V *stage_x_in_lds(const Params<V> &p, unsigned 
     V *s_x = reinterpret_cast<V *>(s_dyn);
     for (int i = threadIdx.x; i < p.x_lds; i += block) s_x[i] = p.x[i];
     return s_x;
+}
+
+// The same copy in two steps (tile_kernel_snap, scalar-hint shapes): the loads are REQUESTED at the very head of the block --
+// before the hints are waited for, before the tile's streams -- and WRITTEN to LDS after the streams have been requested
+// (vector loads return in order: waiting for the oldest does not wait for the streams).  In one step the block sat through
+// hint latency + x latency with nothing else in flight: 0.5 us of a 5.7 us block life on the reference's --dense inputs.
+template <typename V, int BLOCK> struct XRegs { static constexpr int N = X_LDS_MAX_BYTES / (int) sizeof(V) / BLOCK; V v[N]; };
+template <typename V, int BLOCK>
+__device__ __forceinline__ void request_x_for_lds(const Params<V> &p, XRegs<V, BLOCK> &xr)
+{
+    static_assert(XRegs<V, BLOCK>::N >= 1, "x_lds entries per thread");
+#pragma unroll
+    for (int j = 0; j < XRegs<V, BLOCK>::N; ++j) {
+        const int i = (int) threadIdx.x + j * BLOCK;
+        xr.v[j] = i < p.x_lds ? p.x[i] : (V) 0;
+    }
+}
+template <typename V, int BLOCK>
+__device__ __forceinline__ void commit_x_to_lds(const Params<V> &p, const XRegs<V, BLOCK> &xr, unsigned char *s_dyn)
+{
+    V *s_x = reinterpret_cast<V *>(s_dyn);
+#pragma unroll
+    for (int j = 0; j < XRegs<V, BLOCK>::N; ++j) {
+        const int i = (int) threadIdx.x + j * BLOCK;
+        if (i < p.x_lds) s_x[i] = xr.v[j];
+    }
 }
 
 // Block -> tile mapping of the one-tile-per-block launches.  Blocks are dealt round-robin to the 8
@@ -2038,13 +2107,16 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     const int tid = threadIdx.x;
 #ifdef MSPMV_DEV
     // development (tools/trace_snap.py): 100 MHz wall-clock stamps of this block's phases, 8 words per block
+    const unsigned long long t_entry = wall_clock64();           // (before the load of the trace pointer: that is a memory round trip)
     unsigned long long *const snap_tr = g_mspmv_trace ? g_mspmv_trace + (size_t) blockIdx.x * 8 : nullptr;
 #define MSPMV_SNAP_TR(i) do { if (snap_tr && tid == 0) snap_tr[i] = wall_clock64(); } while (0)
     if (snap_tr && tid == 0) { snap_tr[6] = __builtin_amdgcn_s_getreg(63492); snap_tr[7] = __builtin_amdgcn_s_getreg(6164); }
 #else
 #define MSPMV_SNAP_TR(i) do { } while (0)
 #endif
-    MSPMV_SNAP_TR(0);
+#ifdef MSPMV_DEV
+    if (snap_tr && tid == 0) snap_tr[0] = t_entry;
+#endif
     const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     // the hints: the tile's two boundaries (x, y) and their row starts.  The large-problem shapes read them THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
@@ -2060,7 +2132,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0"
                      : "=&s"(hint_c), "=&s"(hint_r) : "s"(coords + tile), "s"(rstart + tile) : "memory");
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
-    const V *const s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
+    // a tiny x goes to LDS: scalar-hint shapes request it now and write it after the streams have been requested
+    XRegs<V, BLOCK> xr;
+    const V *s_x = nullptr;
+    if constexpr (SCALAR_HINTS) {
+        if (p.x_lds > 0) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
+    } else s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
     const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
     if constexpr (SCALAR_HINTS) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hint_c), "+s"(hint_r) : : "memory");
@@ -2110,6 +2187,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         MSPMV_SNAP_TR(2);
+        if constexpr (SCALAR_HINTS) { if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); }
         if (late_barrier) __syncthreads();
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
         MSPMV_SNAP_TR(3);
@@ -2127,6 +2205,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     }
     if (!good) {
         // no usable hints (the first call on this temp storage, or another matrix since): find the two boundaries, stage (again)
+        if constexpr (SCALAR_HINTS) { if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); }      // (again, or for the first time: same values)
         __syncthreads();
         const int wave = tid / WAVE;
         if (wave < 2) {

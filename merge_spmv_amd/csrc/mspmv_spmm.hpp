@@ -245,6 +245,11 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
     const end16_t *s_end = s_end_raw + eshift;
     const int base = tid * NPT;
     const bool nz_tail = c1.y > last_full_nz + 4;
+    // (fp64 values read non-temporally arrive laid out line by line over the wave, mspmv_kernels.hpp: ld_stream4_linewise)
+    if constexpr (vals_linewise<T, NT, false>()) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) regs.val[k] = linewise_own(regs.val[k]);
+    }
 
     // ---- one pass of the LDS phases per group of K right-hand sides: the tile's (col, val) stay in
     //      registers, its row structure (row ends, flags) in LDS; only the gathered X packs change
