@@ -218,6 +218,9 @@ typedef struct mspmv_launch_info {
     uint64_t temp_bytes;       /* what the size query returns                 */
     uint64_t coords_offset;    /* byte offsets of regions inside temp         */
     uint64_t carries_offset;
+    uint64_t diag_offset;      /* two int32: [0] = tag of the last one-launch call in which a tile gave up waiting for another
+                                  workgroup's record and computed the sum itself (debug_sync reports it), [1] = the epoch such
+                                  a tile moves on (mixed into the record tags); neither is ever needed for a result */
 } mspmv_launch_info_t;
 
 /* value_bytes = 4 (float) or 8 (double). */
@@ -272,6 +275,12 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
  *   passes < 0  never
  *   passes >= 2 always that many passes, on any call that takes the 256x11 tile or, in fp64, the 256x7 tile (tests, tuning). */
 int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
+/* Testing aid (per HOST THREAD, like mspmv_set_tuning): how often a tile of the one-launch kernel in which a long row ENDS
+ * looks for the partial sum another workgroup publishes before it computes that sum itself from the matrix (0 = the
+ * library default, ~0.1 s of polling; 1 = one look; < 0 = never look, which sends every such tile down the recomputing path).  The
+ * result is correct for any value: nothing in a call depends on another workgroup making progress; only the time and, by a
+ * re-association, the last bits of such a row do. */
+int mspmv_set_record_polls(int32_t polls);
 /* *passes = how many passes a call of these sizes is offered under the current setting (0: none; the aligned,
  * vectorised path is assumed); with the automatic setting the device-side verdicts still have the last word. */
 int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes);

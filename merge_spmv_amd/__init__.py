@@ -45,7 +45,7 @@ class _LaunchInfo(ctypes.Structure):
                 ("fixup_chunk", ctypes.c_int32), ("fixup_levels", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("snap_head_max", ctypes.c_int32),
                 ("temp_bytes", ctypes.c_uint64), ("coords_offset", ctypes.c_uint64),
-                ("carries_offset", ctypes.c_uint64)]
+                ("carries_offset", ctypes.c_uint64), ("diag_offset", ctypes.c_uint64)]
 
 
 def load_library() -> ctypes.CDLL:
@@ -103,6 +103,8 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_profile_end.argtypes = [ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(ctypes.c_float)] * 3
     lib.mspmv_set_band_passes.restype = ctypes.c_int
     lib.mspmv_set_band_passes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.mspmv_set_record_polls.restype = ctypes.c_int
+    lib.mspmv_set_record_polls.argtypes = [ctypes.c_int32]
     lib.mspmv_get_band_passes.restype = ctypes.c_int
     lib.mspmv_get_band_passes.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
     lib.mspmv_debug_band_windows.restype = ctypes.c_int
@@ -577,6 +579,12 @@ def profile_end() -> dict:
 def set_band_passes(value_bytes: int, passes: int = 0) -> None:
     """Column-band passes (mspmv_set_band_passes): 0 automatic, < 0 never, >= 2 always that many."""
     _check(load_library().mspmv_set_band_passes(int(value_bytes), int(passes)), "mspmv_set_band_passes")
+
+
+def set_record_polls(polls: int = 0) -> None:
+    """Testing aid (mspmv_set_record_polls): 0 = library default, 1 = one look, -1 = never look: tiles in which a long row ends
+    compute the pieces held by other workgroups themselves instead of taking the published records."""
+    _check(load_library().mspmv_set_record_polls(int(polls)), "mspmv_set_record_polls")
 
 
 def band_passes(rows: int, cols: int, nnz: int, value_bytes: int) -> int:

@@ -82,20 +82,25 @@ struct Params {
 // atomics (visible across the XCDs' L2s without a cache flush).  A word is valid when its tag half matches, so no ordering
 // between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits, and the ONE consumer every
 // record has clears it -- none outlives the call, which also makes a captured call replayable with the same tags, even
-// after the matrix changed.  Polling is bounded (~seconds): running out writes the call's tag into the error word of its temp
-// storage (reported by the next debug_sync call) instead of hanging; it is never seen in practice, because the awaited
-// block is always one that was dispatched earlier or fits beside the waiting one (mspmv_api.hip: safe_chunk_log2).
+// after the matrix changed.
+// NOTHING DEPENDS ON A RECORD ARRIVING.  Polling is bounded; a consumer whose poll runs out -- the awaited block has not
+// been dispatched: possible only when far fewer blocks are resident than mspmv_api.hip assumed (a CU-masked stream, a
+// long kernel beside this one, several processes on the device) AND the resident ones are all waiting -- computes the
+// missing sum itself from the matrix (recompute_row_head) and bumps the EPOCH word of the temp storage, which is mixed into
+// the tags: records that may then arrive late and stay uncleared can never look valid to a later launch that replays the
+// same call tag (a captured graph).  The reference's fp64 fix-up spins without bound on the same assumption
+// (single_pass_scan_operators.cuh:620-639); here a broken assumption costs time, never the result.
 // ---------------------------------------------------------------------------
-constexpr int REC_MAX_POLLS = 1 << 21;      // x ~1 us
+constexpr int REC_MAX_POLLS = 1 << 17;      // x ~1 us: ~0.1 s before a consumer gives up on a record and computes the sum itself
 __device__ __forceinline__ void rec_store(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned p0, unsigned p1)
 {
     __hip_atomic_store(rec, ((unsigned long long) tag_a << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(rec + 1, ((unsigned long long) tag_b << 32) | p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // waits (bounded) until both words carry this call's tag, clears the record; false = timed out (payload undefined)
-__device__ __forceinline__ bool rec_take(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned &p0, unsigned &p1)
+__device__ __forceinline__ bool rec_take(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned &p0, unsigned &p1, int max_polls)
 {
-    for (int polls = 0; polls < REC_MAX_POLLS; ++polls) {
+    for (int polls = 0; polls < max_polls; ++polls) {
         const unsigned long long w0 = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long w1 = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned) (w0 >> 32) == tag_a && (unsigned) (w1 >> 32) == tag_b) {
@@ -740,8 +745,18 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 struct LookBack {
     unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
     unsigned tag_a, tag_b;        // tag_a is never 0 (a cleared word is never valid)
-    int *error;                   // error word of the call's temp storage: receives tag_a when a poll runs out
+    int *error;                   // two words of the call's temp storage: [0] receives call_tag when a poll ran out and the consumer computed the
+                                  // sum itself (a diagnostic: debug_sync reports it), [1] is the epoch mixed into the tags
+    unsigned call_tag;            // what the host compares word [0] with
+    int max_polls;                // how often a consumer looks for a record before it computes the sum itself (REC_MAX_POLLS; tests: 1, or 0 = never looks)
 };
+// the tags of this launch: the call's tag and the epoch word as the block found it
+__device__ __forceinline__ LookBack with_epoch(LookBack lb, unsigned epoch)
+{
+    lb.tag_a = (lb.tag_a ^ (epoch * 0x9E3779B9u)) | 1u;
+    lb.tag_b = lb.tag_b + epoch * 0x85EBCA6Bu;
+    return lb;
+}
 template <typename V> struct LbBits;
 template <> struct LbBits<float> {
     static __device__ __forceinline__ void split(float v, unsigned &p0, unsigned &p1) { p0 = __builtin_bit_cast(unsigned, v); p1 = 0u; }
@@ -761,20 +776,20 @@ __device__ __forceinline__ void lb_publish(const LookBack &lb, int tile, V value
 }
 // the carry tile s published: waits (bounded) until both words carry this call's tag, then clears the record
 template <typename V>
-__device__ __forceinline__ V lb_take(const LookBack &lb, int s)
+__device__ __forceinline__ V lb_take(const LookBack &lb, int s, bool &ok)
 {
     unsigned p0, p1;
-    if (rec_take(lb.rec + 2 * (size_t) s, lb.tag_a, lb.tag_b, p0, p1)) return LbBits<V>::join(p0, p1);
-    if (lb.error) __hip_atomic_store(lb.error, (int) lb.tag_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (this call's tag: temp storage is not initialised)
-    return (V) __builtin_nan("");           // never seen in practice: loud, not a hang
+    if (rec_take(lb.rec + 2 * (size_t) s, lb.tag_a, lb.tag_b, p0, p1, lb.max_polls)) return LbBits<V>::join(p0, p1);
+    ok = false;                             // the caller computes the sum itself (recompute_row_head)
+    return (V) 0;
 }
 // Sum of the carries of tiles [tile - count, tile) -- the pieces of this tile's first row held by earlier tiles --
 // taken by the lanes of ONE wave (count <= 64), nearest tile on lane 0; fixed butterfly order; wave-uniform result.
 template <typename V>
-__device__ __forceinline__ V lb_take_wave(const LookBack &lb, int tile, int count)
+__device__ __forceinline__ V lb_take_wave(const LookBack &lb, int tile, int count, bool &ok)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    V part = lane < count ? lb_take<V>(lb, tile - 1 - lane) : (V) 0;
+    V part = lane < count ? lb_take<V>(lb, tile - 1 - lane, ok) : (V) 0;
     if (count > 1) {
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
@@ -785,7 +800,7 @@ __device__ __forceinline__ V lb_take_wave(const LookBack &lb, int tile, int coun
 // tile-1-j-BLOCK, ... in that order; wave butterflies; the wave partials in wave order.  Block-uniform call (it has a
 // barrier); the result is valid on thread 0.
 template <typename V, int BLOCK, int U>
-__device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int count, V *s_wave_val)
+__device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int count, V *s_wave_val, bool &ok)
 {
     // U records per thread and round are requested before any is looked at (a round costs one memory latency whatever its
     // width: with U = 4 a row spanning 37 000 tiles is 37 rounds); one that is not there yet -- only ever among the nearest
@@ -808,17 +823,36 @@ __device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int cou
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * BLOCK;
             if (i < count) {
-                if ((unsigned) (w0[u] >> 32) == lb.tag_a && (unsigned) (w1[u] >> 32) == lb.tag_b) {
+                if (lb.max_polls > 0 && (unsigned) (w0[u] >> 32) == lb.tag_a && (unsigned) (w1[u] >> 32) == lb.tag_b) {
                     unsigned long long *r = lb.rec + 2 * (size_t) (tile - 1 - i);
                     __hip_atomic_store(r, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(r + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     part += LbBits<V>::join((unsigned) w0[u], (unsigned) w1[u]);
-                } else part += lb_take<V>(lb, tile - 1 - i);
+                } else part += lb_take<V>(lb, tile - 1 - i, ok);
             }
         }
     }
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_wave_val[threadIdx.x / WAVE] = part;
+    __syncthreads();
+    V total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / WAVE; ++w) total += s_wave_val[w];
+    return total;
+}
+
+// What the records of tiles [first piece, this tile) add up to, computed from the matrix instead: the products of the
+// nonzeros [j0, j1) of the row that ends in this tile (from the row's first nonzero to the tile's first) -- the path of a
+// consumer whose poll ran out.  Whole block (barriers inside); fixed order; the result on every thread.
+template <typename V, int BLOCK>
+__device__ __forceinline__ V recompute_row_head(const Params<V> &p, int j0, int j1, V *s_wave_val)
+{
+    V part = 0;
+    for (int j = j0 + (int) threadIdx.x; j < j1; j += BLOCK) part += p.values[j] * p.x[p.cols[j]];
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) part += __shfl_xor(part, d, WAVE);
+    __syncthreads();                                   // (s_wave_val may still be read by a take that preceded)
     if ((threadIdx.x & (WAVE - 1)) == 0) s_wave_val[threadIdx.x / WAVE] = part;
     __syncthreads();
     V total = 0;
@@ -936,7 +970,8 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
                                                    const end16_t *s_end, V *s_prod_raw, unsigned *s_flag,
                                                    int *s_wave_flag, V *s_wave_val, Carry<V> *__restrict__ carry_out,
                                                    int pshift, unsigned long long *tr = nullptr, const LookBack *lb = nullptr,
-                                                   int tile = 0, bool publish = false, int first_row_tile = 0, int tid_in = -1)
+                                                   int tile = 0, bool publish = false, int first_row_tile = 0, int tid_in = -1,
+                                                   int first_row_start = 0)
 {
     constexpr int TAKE_BATCH = LB_BATCH;
     constexpr int CPT = IPT / 4 + 1;
@@ -1002,8 +1037,20 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
     V first_row_carry = 0;
     if (lb) {
         const int pieces = tile - first_row_tile;            // block-uniform
-        if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, tile, pieces, s_wave_val);
-        else if (pieces > 0 && tid < WAVE) first_row_carry = lb_take_wave<V>(*lb, tile, pieces);
+        if (pieces > 0) {
+            bool ok = true;
+            if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, tile, pieces, s_wave_val, ok);
+            else if (tid < WAVE) first_row_carry = lb_take_wave<V>(*lb, tile, pieces, ok);
+            // a poll ran out (see "NOTHING DEPENDS ON A RECORD ARRIVING" above): the whole block computes the sum from the
+            // matrix -- the row's nonzeros before this tile -- and moves the epoch on
+            if (__syncthreads_or(ok ? 0 : 1)) {
+                first_row_carry = recompute_row_head<V, BLOCK>(p, first_row_start, c0.y, s_wave_val);
+                if (tid == 0 && lb->error) {
+                    __hip_atomic_store(lb->error, (int) lb->call_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(lb->error + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 
     // ---- row phase
@@ -2101,7 +2148,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
-    __shared__ int s_bnd[6];
+    __shared__ int s_bnd[7];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
 
     const int tid = threadIdx.x;
@@ -2123,14 +2170,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
     // same-box A/B in profiles/r03_scalar_hints.txt).  In the small shape nothing was gained (small grids the same, a 20 M-item
     // matrix that then still took it 3 % slower), so that shape keeps the two-lane vector load + LDS broadcast.  (The hints were written by
-    // vector stores of an earlier launch; the scalar cache is invalidated at every kernel start.  Were the compiler ever to
-    // copy the destination registers between request and wait, the hints would be garbage -- which the verification below
-    // turns into a search, never into a wrong result.)
+    // vector stores of an earlier launch; the scalar cache is invalidated at every kernel start.)  Request and wait are ONE asm
+    // statement: the compiler never sees destination registers whose load is still in flight, so it cannot copy, spill or
+    // re-assign them under the load (a later, separate s_waitcnt left exactly that open).  What used to sit between the two --
+    // clearing the flag words, requesting a tiny x -- now comes first; the block has nothing else to do until its hints are
+    // there anyway.
     constexpr bool SCALAR_HINTS = IPT > 7;
-    int4v hint_c; int2v hint_r;
-    if constexpr (SCALAR_HINTS)
-        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0"
-                     : "=&s"(hint_c), "=&s"(hint_r) : "s"(coords + tile), "s"(rstart + tile) : "memory");
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     // a tiny x goes to LDS: scalar-hint shapes request it now and write it after the streams have been requested
     XRegs<V, BLOCK> xr;
@@ -2139,12 +2184,15 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         if (p.x_lds > 0) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
     } else s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
     const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
+    int4v hint_c; int2v hint_r;
+    unsigned epoch = 0u;                                            // (mixed into the record tags: "NOTHING DEPENDS ON A RECORD ARRIVING")
     if constexpr (SCALAR_HINTS) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hint_c), "+s"(hint_r) : : "memory");
+        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(hint_c), "=&s"(hint_r), "=&s"(epoch) : "s"(coords + tile), "s"(rstart + tile), "s"(lb.error) : "memory");
     } else if (tid < 2) {
         const Coord h = coords[tile + tid]; const int rs = rstart[tile + tid];
         s_bnd[3 * tid] = h.x; s_bnd[3 * tid + 1] = rs; s_bnd[3 * tid + 2] = h.y;
-    }
+    } else if (tid == 2) s_bnd[6] = __hip_atomic_load(lb.error + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (s_flag cleared, the LDS copy of x complete, s_bnd written.  With scalar hints and a tiny x being copied into LDS, every
     //  wave requests its share of the streams first and the barrier -- which waits for that copy -- comes after the requests:
     //  dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier is the better place, by 1-2 %)
@@ -2152,7 +2200,9 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     if (!late_barrier) __syncthreads();
     if constexpr (!SCALAR_HINTS) {
         hint_c.x = s_bnd[0]; hint_r.x = s_bnd[1]; hint_c.y = s_bnd[2]; hint_c.z = s_bnd[3]; hint_r.y = s_bnd[4]; hint_c.w = s_bnd[5];
+        epoch = (unsigned) s_bnd[6];
     }
+    const LookBack lbe = with_epoch(lb, epoch);
     MSPMV_SNAP_TR(1);
     const int total = p.rows + p.nnz;                               // < 2^31
     const long long d0l = (long long) tile * TILE, d1l = d0l + TILE;
@@ -2243,7 +2293,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
     if (lean) consume_tile_rows<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, s_end_raw + eshift, s_prod_raw, pshift, carries + tile);
     else consume_tile_flags<V, BLOCK, IPT, AXPBY, 4>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                                     s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lb, tile, !snap1, first_piece);
+                                                     s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lbe, tile, !snap1, first_piece, -1, rs0);
     MSPMV_SNAP_TR(4);
 #ifdef MSPMV_DEV
     if (snap_tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MSPMV_SNAP_TR(5); }      // (y stores acknowledged)
