@@ -178,7 +178,9 @@ int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_
  * and runs the ordinary stateless CsrMV on the renumbered indices:
  *     y = alpha * A * x + beta * y        (beta == 0: y is never read).
  * A column permutation only changes where x is read -- every row still sums the same products in the same order -- so y
- * is BIT FOR BIT the result of mspmv_csrmv_* / _axpby_*.  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
+ * is BIT FOR BIT the result of mspmv_csrmv_* / _axpby_* in its one-sweep form (the plan never takes the column-band passes;
+ * a stateless call that does -- x of 5.5-40 MiB under uniformly spread columns -- re-associates the row sums, so compare
+ * with mspmv_set_band_passes(vb, -1) there).  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
  * the band-major plan below (caller-owned storage of mspmv_csrmv_hotcols_size bytes, the same rows / cols / nnz /
  * value_bytes to every call, asynchronous on `stream`); d_values / d_row_offsets passed to _apply must be the arrays
  * the plan was built for.  No reference counterpart (its HYB column is the precedent for set-up timed apart,
@@ -368,7 +370,9 @@ int mspmv_mg_apply_carries(void *d_y_local, const void *d_carries,
  *                           PEER backend's pushes fenced by step-tagged flags.  Nothing on the host, no rendezvous; a
  *                           producer runs at most two steps ahead of its consumer.  Waits are bounded (seconds):
  *                           mspmv_mg_synchronize returns hipErrorLaunchFailure if one ran out.  (HSA_ENABLE_IPC_MODE_LEGACY=0
- *                           where the host driver only supports dmabuf IPC.)
+ *                           where the host driver only supports dmabuf IPC.)  EXPERIMENTAL: exercised with several processes
+ *                           sharing ONE device only (no multi-GPU node has run it); a process's local parts must sit on one
+ *                           device; the mailboxes need uncached or fine-grained device memory (hipErrorNotSupported otherwise).
  *   MSPMV_MG_EXCHANGE_AUTO  PEER when the process holds every part, else RCCL.
  * mspmv_mg_allgather_rows (square matrices): x <- y on every replica -- PEER: each part
  * pushes its owned rows into every replica (direct peer writes, unpadded); RCCL: grouped ncclBroadcast.
@@ -406,7 +410,8 @@ int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info);
 /* enable != 0: every local part's columns are renumbered by reference count (the hot-column plan above, built once per
  * part in plan-owned storage of 4 * local_nnz + 16 * cols bytes; every part must be attached) and mspmv_mg_csrmv permutes
  * x into the part's numbering before its SpMV -- for a scale-free matrix with an x far beyond the caches (config 5).
- * Results are bit for bit the ones without it.  enable == 0 releases the storage. */
+ * Results are bit for bit the ones without it (parts that would take the column-band passes excepted, as above).
+ * enable == 0 releases the storage. */
 int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable);
 int mspmv_mg_csrmv(mspmv_mg_plan_t *plan);
 int mspmv_mg_allgather_rows(mspmv_mg_plan_t *plan);

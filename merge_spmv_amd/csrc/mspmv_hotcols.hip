@@ -176,7 +176,7 @@ int hot_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets, con
         if (int e = launched(stream, debug_sync, "hot_relabel_kernel", ngrid)) return e;
     }
     // the hints of the inner call's tiles (they depend on the row offsets alone)
-    CallExtra ex; ex.phase = PHASE_COORDS_ONLY;
+    CallExtra ex; ex.phase = PHASE_COORDS_ONLY; ex.no_bands = true;
     size_t tb = (size_t) L.temp_bytes;
     if (value_bytes == 4)
         return csrmv_call<float>(base + L.temp_off, &tb, nullptr, d_row_offsets, nullptr, nullptr, nullptr, rows, 0, nnz, 1.f, 0.f, false, stream, debug_sync, ex);
@@ -200,6 +200,9 @@ int hot_apply(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t 
         if (int e = launched(stream, debug_sync, "hot_permute_x_kernel", grid)) return e;
     }
     CallExtra ex; ex.phase = PHASE_ALL;            // (hints from the build; verified by the tiles as always)
+    ex.no_bands = true;                            // the hot columns are contiguous now: column bands of x have nothing to add, and their verdict is
+                                                   // sampled from the column indices -- which the renumbering changed -- so taking them would make the
+                                                   // plan's rounding differ from the one-sweep stateless call's
     size_t tb = (size_t) L.temp_bytes;
     return csrmv_call<V>(base + L.temp_off, &tb, d_values, d_row_offsets, reinterpret_cast<const int *>(base + L.cols_off), xp, d_y, rows, cols, nnz,
                          alpha, beta, !(alpha == (V) 1 && beta == (V) 0), stream, debug_sync, ex);

@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void mg_push_rows_kernel(const V *__restrict__
     const long long stride = (long long) gridDim.x * blockDim.x;
     V *__restrict__ out = dst[blockIdx.y];
     for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = y[i];
+    // the replicas may belong to other devices (and, in the hipIpc form, the "rows are there" flag is written by the NEXT
+    // kernel of this stream and polled by a kernel of the owner's device): make the stores visible system-wide before this
+    // kernel ends, rather than rely on what scope the end-of-kernel release of back-to-back launches has
+    __threadfence_system();
 }
 
 // ---- IPC backend: the mailbox block every part shares with its peers (device memory, opened by them through hipIpc) ----
@@ -544,13 +548,14 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
             if (hipSetDevice(q.device) != hipSuccess) return fail(kErrInvalid);
             // the mailbox is polled by kernels of THIS device while kernels of other devices write it over the links: ordinary
             // (coarse-grained) device memory is only coherent between agents at kernel boundaries, so the block is allocated
-            // uncached (else fine-grained); the plain allocation is the last resort and is only certain with all parts on one device
+            // uncached (else fine-grained).  No plain allocation as a last resort: it would only be right with every part on one
+            // device, which a plan that sees its own parts alone cannot know
             void *blk = nullptr;
             if (hipExtMallocWithFlags(&blk, sizeof(IpcBlock), hipDeviceMallocUncached) != hipSuccess) {
                 (void) hipGetLastError(); blk = nullptr;
                 if (hipExtMallocWithFlags(&blk, sizeof(IpcBlock), hipDeviceMallocFinegrained) != hipSuccess) {
-                    (void) hipGetLastError(); blk = nullptr;
-                    if (hipMalloc(&blk, sizeof(IpcBlock)) != hipSuccess) return fail(hipErrorOutOfMemory);
+                    (void) hipGetLastError();
+                    return fail(hipErrorNotSupported);
                 }
             }
             q.block = static_cast<IpcBlock *>(blk);
@@ -682,24 +687,34 @@ int mspmv_mg_plan_ipc_import(mspmv_mg_plan_t *plan, const void *blobs, int32_t c
         opened.push_back(Opened{h, ptr}); *out = ptr;
         return 0;
     };
+    // the handles are opened with ONE device current (peer access is enabled for that device): a process whose local parts sit on
+    // several devices would leave the others without access to the imported memory -- refused rather than half-working
+    for (const Part &q : plan->local) if (q.device != plan->local[0].device) return kErrInvalid;
     MG_HIP(hipSetDevice(plan->local[0].device));
+    // on any failure: whatever was opened so far is closed again and the plan is left as it was (a retry starts clean)
+    auto give_up = [&](int st) -> int {
+        for (const Opened &o : opened) (void) hipIpcCloseMemHandle(o.ptr);
+        plan->peers.clear();
+        (void) hipSetDevice(prev);
+        return st;
+    };
     for (int b = 0; b < count; ++b) {
         const char *in = static_cast<const char *>(blobs) + (size_t) b * blob_stride;
         int32_t n = 0; memcpy(&n, in, 4);
-        if (n < 0 || 8 + (size_t) n * sizeof(IpcEntry) > blob_stride) { (void) hipSetDevice(prev); return kErrInvalid; }
+        if (n < 0 || 8 + (size_t) n * sizeof(IpcEntry) > blob_stride) return give_up(kErrInvalid);
         for (int i = 0; i < n; ++i) {
             IpcEntry e; memcpy(&e, in + 8 + (size_t) i * sizeof(IpcEntry), sizeof(e));
-            if (e.part < 0 || e.part >= plan->parts) { (void) hipSetDevice(prev); return kErrInvalid; }
+            if (e.part < 0 || e.part >= plan->parts) return give_up(kErrInvalid);
             IpcPeer &peer = plan->peers[(size_t) e.part];
             if (peer.part == e.part) continue;                       // one of this process's own parts
             void *blk = nullptr, *x = nullptr;
             int st = open_handle(e.block, &blk);
             if (st == 0) st = open_handle(e.x, &x);
-            if (st != 0) { (void) hipSetDevice(prev); return st; }
+            if (st != 0) return give_up(st);
             peer.part = e.part; peer.block = static_cast<IpcBlock *>(blk); peer.x = x; peer.opened = true;
         }
     }
-    for (const IpcPeer &peer : plan->peers) if (peer.part < 0) { (void) hipSetDevice(prev); return kErrInvalid; }     // a part nobody exported
+    for (const IpcPeer &peer : plan->peers) if (peer.part < 0) return give_up(kErrInvalid);     // a part nobody exported
     // every peer's pointers are known: the tables of the step kernels
     const size_t vb = (size_t) plan->value_bytes;
     for (Part &q : plan->local) {

@@ -116,3 +116,29 @@ def test_hotcols_pays_on_a_scale_free_matrix_with_a_large_x():
     t_plain, t_plan = timed(call), timed(lambda: plan(x, yp))
     assert torch.equal(y, yp)
     assert t_plan < 0.85 * t_plain, (t_plain, t_plan)
+
+
+@gpu
+def test_plan_in_the_band_policy_size_range_equals_the_one_sweep_call():
+    """Advisor (r03, low): for x of 5.5-40 MiB under spread columns the STATELESS call may take the column-band passes (a
+    re-association), and their verdict is sampled from the column indices, which the plan renumbers.  The plan never takes
+    them: it is bit for bit the stateless call with the passes off, and within the bound of the automatic call."""
+    from merge_spmv_amd import generators as G
+    A = G.uniform_csr(2_000_000, 2_000_000, 12, dtype=torch.float32)          # x = 7.6 MiB, 24 M nonzeros = 192 MiB of stream
+    assert M.band_passes(A.rows, A.cols, A.nnz, 4) >= 2                       # (the stateless call is a candidate)
+    x = G.uniform_pm1(9, A.cols, torch.float32, "cuda")
+    plan = M.CsrMVHotColumns(A.values, A.row_offsets, A.column_indices, A.cols)
+    y_plan = plan(x).clone()
+    y_auto = M.csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols).clone()
+    try:
+        M.set_band_passes(4, -1)
+        y_one = M.csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols).clone()
+    finally:
+        M.set_band_passes(4, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(y_plan, y_one)
+    lens = (A.row_offsets[1:] - A.row_offsets[:-1]).double()
+    prod = A.values.double() * x.double()[A.column_indices.long()]
+    s = torch.segment_reduce(prod.abs(), "sum", lengths=(A.row_offsets[1:] - A.row_offsets[:-1]).long(), unsafe=True)
+    tol = 2.0 * (torch.ceil(torch.log2(lens + 1)) + M.serial_sum_depth(A.rows, A.cols, A.nnz, 4) + 8) * 2.0 ** -24 * s
+    assert bool(((y_auto.double() - y_plan.double()).abs() <= 2 * tol).all())
