@@ -32,10 +32,13 @@ roofline        = algorithmic (compulsory) bytes of one tile_kernel launch / its
                   hipEvents recorded on the launch stream (mspmv_profile_begin/_end), against the 8 TB/s
                   HBM3E peak
 configs         = (N = 1, default workload) one sub-record per remaining single-GPU configuration of BASELINE.json, each
-                  timed the same way on its own synthetic matrix -- C2 in fp64 (the reference's default precision,
-                  gpu_spmv.cu:727-735), config 3's two matrices as size-matched R-MAT stand-ins (the SuiteSparse files cannot
-                  be fetched offline), config 4, config 5 on ONE GPU, and the reference's own --dense=32 streaming
-                  input -- with ms_per_step, GFLOP/s and the tile kernel's roofline fraction from hipEvents.
+                  timed the same way on its own synthetic matrix -- config 1's --dense=5 matrix in fp64 with the product's
+                  cpu_spmv kernel on the host cores beside it (`cpu`), C2 in fp64 (the reference's default precision,
+                  gpu_spmv.cu:727-735), a circuit5M-SHAPED stand-in (the matrix of the reference's one published number),
+                  config 3's two matrices as size-matched R-MAT stand-ins (the SuiteSparse files cannot be fetched
+                  offline), config 4, config 5 on ONE GPU, and the reference's own --dense=32 streaming input -- with
+                  ms_per_step, GFLOP/s, the reference's effective-bandwidth share of peak (gpu_spmv.cu:452-465), the tile
+                  kernel's roofline fraction, replayed counter traffic, and rocSPARSE csrmv on the same arrays (`vendor`).
 cpu_baseline    = the PRODUCT's OpenMP merge-path kernel (merge_spmv_amd/host/merge_csrmv.hpp, what cpu_spmv
                   runs; pinned bit for bit against the oracle by tests/test_cpu_product_parity.py) on the
                   same matrix on this box's host cores: private first-touched arrays, threads = the cgroup
@@ -168,45 +171,92 @@ def time_stateless(M, torch, A, x, steps, warmup):
 
 
 def replayed_traffic(workload, dtype_name):
-    """HBM-side bytes per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same command
-    (profiles/*/pmc_latest.json, written by tools/gpu_profile.sh): replayed constants, labelled as such."""
-    for rel in ("pmc_latest.json", os.path.join("r03_dense32", "pmc_latest.json"), os.path.join("r03_c2_f64", "pmc_latest.json")):
-        path = os.path.join(ROOT, "profiles", rel)
+    """HBM-side bytes per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same workload
+    (profiles/*/pmc_latest.json, written by tools/gpu_profile.sh): replayed constants, labelled as such.  The newest
+    round's file wins."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_latest.json")) + [os.path.join(ROOT, "profiles", "pmc_latest.json")]):
         try:
             pmc = json.load(open(path))
         except Exception:
             continue
         if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and pmc.get("tile_kernel_hbm_bytes_per_launch"):
-            return pmc["tile_kernel_hbm_bytes_per_launch"], (f"profiles/{rel} (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
-                                                              "from separate rocprofv3 --pmc passes over this command, " + str(pmc.get("collected", "see profiles/README.md")))
-    return None, None
+            best = (pmc, os.path.relpath(path, ROOT))
+    if best is None:
+        return None, None
+    pmc, rel = best
+    return pmc["tile_kernel_hbm_bytes_per_launch"], (f"{rel} (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
+                                                      "from separate rocprofv3 --pmc passes over this workload, " + str(pmc.get("collected", "see profiles/README.md")))
 
 
-def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
-    """The `configs` array: every single-GPU configuration of BASELINE.json that the headline does not cover, through the
-    same stateless call.  Generation is on the GPU and not timed; a configuration that would start after `budget_s` of
-    this function's wall time is reported as skipped rather than run."""
+REFERENCE_PUBLISHED_PCT = 62.96      # circuit5M fp64 on a K40: 181.6 effective GB/s of 288.4 (README.md:116,137-138)
+
+
+def effective_record(rows, nnz, vb, ms):
+    """the reference's own headline figure for one method (gpu_spmv.cu:452-465): bytes of its model / time, as a share of the
+    device's peak memory bandwidth"""
+    gbs = effective_bytes(rows, nnz, vb) / (ms * 1e-3) / 1e9
+    return {"effective_GBs": round(gbs, 2), "effective_pct_of_peak": round(100.0 * gbs / HBM_PEAK_GBS, 2)}
+
+
+def vendor_record(torch, A, x, y_ours, iters):
+    """rocSPARSE csrmv on the same device arrays -- the column the reference always prints beside its own (cuSPARSE there,
+    gpu_spmv.cu:262-364,565-578): analysis time apart, average SpMV time, and ours / theirs."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import rocsparse_ref
+        ana, avg, yr = rocsparse_ref.time_csrmv(A, x, iters=iters)
+        rec = {"library": "rocSPARSE csrmv (rocsparse_[sd]csrmv after rocsparse_[sd]csrmv_analysis), via tools/rocsparse_ref.py",
+               "analysis_ms": round(ana, 3), "ms_per_step": round(avg, 5), "steps": iters, "value": round(2.0 * A.nnz / (avg * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
+        if y_ours is not None:
+            rec["max_abs_diff_vs_ours"] = float((yr.double() - y_ours.double()).abs().max().item())
+        del yr
+        return rec
+    except Exception as e:  # noqa: BLE001 - the comparison column must never cost the headline
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def config_specs(torch, G, dev, steps):
+    """(name, pmc label, description, dtype, steps, make) of every single-GPU configuration besides the headline -- shared with
+    tools/run_config.py, which profiles one of them under rocprofv3."""
     f32, f64 = torch.float32, torch.float64
-    specs = [
-        ("C2 fp64", "BASELINE config 2's matrix in the reference's default precision (gpu_spmv.cu:727-735)", f64, steps,
+    return [
+        ("C1 dense5 fp64", "dense5", "BASELINE config 1's matrix: the reference's --dense=5 (cpu_spmv.cpp:581-587: (1 << 24) / 5 rows x 5 columns, every entry 1.0), fp64 -- "
+         "the GPU beside the product's OpenMP merge-path kernel on this box's host cores (`cpu`)", f64, max(steps, 100),
+         lambda: (G.dense_csr((1 << 24) // 5, 5, dtype=f64, device=dev, ones=True), G.SEED_C2 + 2)),
+        ("C2 fp64", "c2", "BASELINE config 2's matrix in the reference's default precision (gpu_spmv.cu:727-735)", f64, steps,
          lambda: (G.uniform_csr(C2_ROWS_PER_GPU, C2_ROWS_PER_GPU, C2_NPR, dtype=f64, device=dev), G.SEED_C2 + 2)),
-        ("C3 webbase-1M-sized stand-in", f"BASELINE config 3: R-MAT scale {G.C3_WEBBASE_SCALE}, {G.C3_WEBBASE_EDGES} edges (webbase-1M's count, "
+        ("circuit5M-shaped stand-in", "circuit", f"the matrix of the reference's one published number (README.md:116,137-138: circuit5M, {G.CIRCUIT5M_ROWS}^2, "
+         f"{G.CIRCUIT5M_NNZ} nonzeros, fp64, 62.96 % of the K40's peak in its effective-bandwidth metric); STAND-IN of exactly those sizes with a circuit "
+         "matrix's row-length spread (generators.circuit_csr): the SuiteSparse file cannot be fetched offline", f64, steps,
+         lambda: (G.circuit_csr(dtype=f64, device=dev), G.SEED_CIRCUIT + 9)),
+        ("C3 webbase-1M-sized stand-in", "c3_web", f"BASELINE config 3: R-MAT scale {G.C3_WEBBASE_SCALE}, {G.C3_WEBBASE_EDGES} edges (webbase-1M's count, "
          "ufl_matrices.txt:2379), fp64; STAND-IN: the SuiteSparse file cannot be fetched offline", f64, max(steps, 200),
          lambda: (G.rmat_csr(G.C3_WEBBASE_SCALE, G.C3_WEBBASE_EDGES, dtype=f64, device=dev, seed=G.SEED_C3), G.SEED_C3 + 2)),
-        ("C3 com-Orkut-sized stand-in", f"BASELINE config 3: R-MAT scale {G.C3_ORKUT_SCALE}, {G.C3_ORKUT_EDGES} stored entries mirrored as a symmetric "
+        ("C3 com-Orkut-sized stand-in", "c3_orkut", f"BASELINE config 3: R-MAT scale {G.C3_ORKUT_SCALE}, {G.C3_ORKUT_EDGES} stored entries mirrored as a symmetric "
          "matrix (com-Orkut's count), fp64; STAND-IN: the SuiteSparse file cannot be fetched offline", f64, steps,
          lambda: (G.rmat_symmetric_csr(G.C3_ORKUT_SCALE, G.C3_ORKUT_EDGES, dtype=f64, device=dev, seed=G.SEED_C3), G.SEED_C3 + 2)),
-        ("C4 fp32", "BASELINE config 4: 16 777 216 rows, one row of 67 108 864 nonzeros, one nonzero in every 4096-th other row, "
+        ("C4 fp32", "c4", "BASELINE config 4: 16 777 216 rows, one row of 67 108 864 nonzeros, one nonzero in every 4096-th other row, "
          "the rest empty; uniform values", f32, steps,
          lambda: (G.degenerate_csr(dtype=f32, device=dev, ones=False), G.SEED_C4 + 2)),
-        ("dense32 fp32", "the reference's own streaming input --dense=32 --size=100000000 (gpu_spmv.cu:645-650): 3 125 000 x 32", f32, steps,
+        ("dense32 fp32", "dense32", "the reference's own streaming input --dense=32 --size=100000000 (gpu_spmv.cu:645-650): 3 125 000 x 32", f32, steps,
          lambda: (G.dense_csr(C2_ROWS_PER_GPU, C2_NPR, dtype=f32, device=dev, ones=False), G.SEED_C2 + 2)),
-        ("C5 at G = 1", "BASELINE config 5 on ONE GPU: fp64 R-MAT scale 26, 2 000 000 000 edges (x = 512 MB, beyond the Infinity Cache)",
+        ("C5 at G = 1", "c5", "BASELINE config 5 on ONE GPU: fp64 R-MAT scale 26, 2 000 000 000 edges (x = 512 MB, beyond the Infinity Cache)",
          f64, 5, lambda: (G.rmat_csr(26, 2_000_000_000, dtype=f64, device=dev, seed=G.SEED_C5), G.SEED_C5 + 2)),
     ]
+
+
+def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True):
+    """The `configs` array: every single-GPU configuration of BASELINE.json that the headline does not cover (and the
+    circuit5M-shaped matrix of the reference's published number), through the same stateless call.  Generation is on the GPU
+    and not timed; a configuration that would start after `budget_s` of this function's wall time is reported as skipped
+    rather than run.  Every record carries the reference's own metric (`effective_pct_of_peak`, gpu_spmv.cu:452-465), the
+    tile kernel's roofline fraction, replayed counter traffic where a committed rocprofv3 pass of that workload exists, and
+    the vendor library's time on the same arrays (`vendor`)."""
     out = []
     t_start = time.perf_counter()
-    for name, desc, tdt, k, make in specs:
+    for name, label, desc, tdt, k, make in config_specs(torch, G, dev, steps):
         if time.perf_counter() - t_start > budget_s:
             out.append({"config": name, "skipped": f"the configs leg had used its {budget_s:.0f} s budget"})
             continue
@@ -220,32 +270,53 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0):
             vb = A.values.element_size()
             b_alg = algorithmic_bytes(A.rows, A.cols, A.nnz, vb)
             info = M.launch_info(A.rows, A.nnz, vb)
-            tile_s = prof["tile_ms"] * 1e-3
+            offered = M.band_passes(A.rows, A.cols, A.nnz, vb)
+            # one-launch calls: the kernel IS the step, and hipEvent records around a 30 us kernel add more than the launch gap
+            # they replace -- the wall clock of K back-to-back calls is the smaller, and by construction an upper bound of the
+            # kernel's duration; three-launch calls (column-band candidates): the tile kernel's own event time
+            one_launch = offered <= 1
+            tile_s = (min(prof["tile_ms"], ms) if one_launch else prof["tile_ms"]) * 1e-3
             rec = {"config": name, "workload": desc, "dtype": "f32" if vb == 4 else "f64", "rows": A.rows, "cols": A.cols, "nnz": A.nnz,
                    "steps": k, "ms_per_step": round(ms, 5), "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
                    "tile": f"{info['block_threads']}x{info['items_per_thread']}", "generation_s": round(gen_s, 2),
-                   "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap" if M.band_passes(A.rows, A.cols, A.nnz, vb) <= 1 else "tile_kernel_vec<.., BAND>", "achieved": round(b_alg / tile_s / 1e9, 2) if tile_s > 0 else None,
+                   "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap (one launch)" if one_launch else "tile_kernel_vec<.., BAND>",
+                                "achieved": round(b_alg / tile_s / 1e9, 2) if tile_s > 0 else None,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_alg / tile_s / 1e9 / HBM_PEAK_GBS, 4) if tile_s > 0 else None,
                                 "algorithmic_bytes_per_launch": b_alg,
                                 "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5), "fixup": round(prof["fixup_ms"], 5)},
+                                "duration_used_ms": round(tile_s * 1e3, 5),
+                                "duration_source": ("min(hipEvent average of the one launch, wall clock per step of K back-to-back calls)" if one_launch
+                                                    else "hipEvent average of the tile kernel"),
                                 "events": f"hipEvents on the launch stream, {prof['calls']} launches"}}
-            offered = M.band_passes(A.rows, A.cols, A.nnz, vb)
+            rec.update(effective_record(A.rows, A.nnz, vb, ms))
+            if label == "circuit":
+                rec["reference_published_pct_of_peak"] = REFERENCE_PUBLISHED_PCT
+                rec["reference_published_note"] = "circuit5M itself, fp64, merge-based CsrMV on a Tesla K40 (README.md:116,137-138); other hardware, the real matrix"
             if offered > 1:
                 spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
                 rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
-            # cheap sanity on the result: finite, and the row sums of |y| are not all zero (parity proper is tests/ -m gpu)
-            tr, src = replayed_traffic({"C2 fp64": "c2", "dense32 fp32": "dense32"}.get(name, ""), "f32" if vb == 4 else "f64")
+            tr, src = replayed_traffic(label, "f32" if vb == 4 else "f64")
             if tr is not None:
                 rec["roofline"]["traffic"] = tr; rec["roofline"]["traffic_source"] = src
+                rec["roofline"]["traffic_over_algorithmic"] = round(tr / b_alg, 3)
+            # cheap sanity on the result: finite (parity proper is tests/ -m gpu)
             rec["y_finite"] = bool(torch.isfinite(y).all().item())
             rec["gathers_per_s_G"] = round(A.nnz / (ms * 1e-3) / 1e9, 2)
-            if name.startswith("C5"):
+            if label == "c5":
                 rec["roofline"]["note"] = ("x (512 MB) is beyond every cache: a gather that misses moves a whole 128-byte line whatever the load's cache "
                                            "policy, and the chip delivers ~55 G random lines/s (tools/gather_granularity, profiles/r03_gather_granularity.txt); "
                                            "`gathers_per_s_G` is to be read against that, `frac` counts each x entry once")
-            if name.startswith("C5") or "Orkut" in name:
+            if label in ("c5", "c3_orkut"):
                 # scale-free graphs with an x beyond the caches: the opt-in hot-column plan on the same matrix
                 rec["hot_column_plan"] = M.hotcols_bench_record(A, x, y, steps=k, warmup=2, peak_gbs=HBM_PEAK_GBS)
+            if vendor:
+                v_iters = 3 if label == "c5" else 5 if label == "c4" else min(k, 30)
+                rec["vendor"] = vendor_record(torch, A, x, y, v_iters)
+                if "ms_per_step" in rec["vendor"]:
+                    rec["vendor"]["vendor_time_over_ours"] = round(rec["vendor"]["ms_per_step"] / ms, 3)
+            if label == "dense5":
+                # BASELINE config 1 proper: the product's cpu_spmv kernel on the same matrix, on this box's host cores
+                rec["cpu"] = cpu_baseline(A, x, "C1: --dense=5 fp64", budget_s=4.0, max_iters=60)
             out.append(rec)
             del A, x, ws, y
         except Exception as e:                   # e.g. out of memory on a smaller part: report, keep the headline
@@ -309,6 +380,7 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"],
                     help="N > 1: how the C operator exchanges the boundary-row carries -- one RCCL all-gather per step (default), or the hipIpc "
                          "peer backend (carries written straight into the owner's mailbox, step tags instead of a collective; never timed over links)")
+    ap.add_argument("--no-vendor", action="store_true", help="N = 1: skip the rocSPARSE comparison column (`vendor` sub-records)")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records (the other single-GPU configurations)")
     ap.add_argument("--configs-budget", type=float, default=150.0, help="seconds the `configs` leg may take before it stops starting new ones")
     ap.add_argument("--dist-timeout", type=int, default=900, help="N > 1: seconds a collective may block before the job aborts")
@@ -648,6 +720,7 @@ def main():
                                      f"merge-path diagonal split over {world} GPUs (mspmv_mg_partition): "
                                      f"{local_rows - 1} rows + {local_nnz} nonzeros on rank 0; one exchange of {world} carries per step")},
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
+            "effective_pct_of_peak": round(100.0 * effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 2),
             "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap (one launch per part)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -684,12 +757,16 @@ def main():
             out["single_gpu_same_workload"] = single
         if not mg and workload == "c2" and not args.no_plan and hasattr(M, "CsrMVPlan"):
             out["prepared_plan"] = M.plan_bench_record(A, x, y, steps=args.steps, warmup=args.warmup, peak_gbs=HBM_PEAK_GBS)
+        if not mg and not args.no_vendor:
+            out["vendor"] = vendor_record(torch, A, x, y, min(args.steps, 30))
+            if "ms_per_step" in out["vendor"]:
+                out["vendor"]["vendor_time_over_ours"] = round(out["vendor"]["ms_per_step"] / ms_per_step, 3)
         if not mg and not args.no_cpu_baseline and A.nnz <= 400_000_000:
             out["cpu_baseline"] = cpu_baseline(A, x, "same " + workload.upper() + " matrix")
         if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs and not args.tune and not args.band_passes:
             del A, ws, y
             torch.cuda.empty_cache()
-            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget)
+            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget, vendor=not args.no_vendor)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

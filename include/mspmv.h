@@ -267,7 +267,7 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
                      int32_t items_per_thread, int32_t flags);
 
 /* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of
- * 5.5-40 MiB (fp32; 7-36 MiB fp64) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
+ * 1.375-10 x one XCD's L2 (fp32; 1.75-9 x in fp64: 5.5-40 / 7-36 MiB on MI355X) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
  * pass multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 10-29 %
  * faster.  The call stays stateless, asynchronous and three launches: 64 blocks added to the coordinate
  * launch sample 64 windows of 2048 consecutive column indices, and the tile kernel reads their verdicts and
@@ -277,6 +277,10 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
  *   passes < 0  never
  *   passes >= 2 always that many passes, on any call that takes the 256x11 tile or, in fp64, the 256x7 tile (tests, tuning). */
 int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
+/* What the automatic column-band policy is derived from on the current device: one XCD's L2 in bytes and the number of XCDs
+ * (queried from the runtime once per device; MSPMV_FAKE_L2_MIB / MSPMV_FAKE_XCDS in the environment override them), and the
+ * CU count.  Without a device: the MI355X figures (4 MiB, 8, 256).  Any pointer may be NULL. */
+int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *cus);
 /* Testing aid (per HOST THREAD, like mspmv_set_tuning): how often a tile of the one-launch kernel in which a long row ENDS
  * looks for the partial sum another workgroup publishes before it computes that sum itself from the matrix (0 = the
  * library default, ~0.1 s of polling; 1 = one look; < 0 = never look, which sends every such tile down the recomputing path).  The

@@ -581,6 +581,15 @@ def set_band_passes(value_bytes: int, passes: int = 0) -> None:
     _check(load_library().mspmv_set_band_passes(int(value_bytes), int(passes)), "mspmv_set_band_passes")
 
 
+def device_caches() -> dict:
+    """What the column-band policy is derived from (mspmv_get_device_caches): one XCD's L2 bytes, XCD count, CU count."""
+    l2 = ctypes.c_int64(0); x = ctypes.c_int32(0); c = ctypes.c_int32(0)
+    lib = load_library()
+    lib.mspmv_get_device_caches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib.mspmv_get_device_caches(ctypes.byref(l2), ctypes.byref(x), ctypes.byref(c)), "mspmv_get_device_caches")
+    return {"l2_bytes_per_xcd": l2.value, "xcds": x.value, "cus": c.value}
+
+
 def set_record_polls(polls: int = 0) -> None:
     """Testing aid (mspmv_set_record_polls): 0 = library default, 1 = one look, -1 = never look: tiles in which a long row ends
     compute the pieces held by other workgroups themselves instead of taking the published records."""

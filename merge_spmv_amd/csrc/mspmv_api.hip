@@ -147,9 +147,39 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
     return L;
 }
 
+// What the column-band policy is derived from: the L2 a gather can hit in -- one XCD's, as the runtime reports it -- and
+// how many of them the device has; queried once per device (never on the hot path again).  MSPMV_FAKE_L2_MIB / MSPMV_FAKE_XCDS in
+// the environment override the query (read once: tests, and other parts / partition modes where the runtime's figure is wrong).
+struct DeviceCaches { long long l2_bytes; int xcds; };
+static DeviceCaches device_caches()
+{
+    static std::mutex lock;
+    static DeviceCaches cached[64];
+    static bool have[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void) hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> g(lock);
+    if (!have[dev]) {
+        DeviceCaches c; c.l2_bytes = 4LL << 20; c.xcds = 8;                      // MI355X in SPX mode: 8 XCDs x 4 MiB
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) c.xcds = v; else (void) hipGetLastError();
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeL2CacheSize, dev) == hipSuccess && v > 0) {
+            // (the runtime reports one XCD's L2 on this part; a figure of 16 MiB or more can only be an aggregate)
+            c.l2_bytes = v >= (16 << 20) && c.xcds > 1 ? (long long) v / c.xcds : (long long) v;
+        } else (void) hipGetLastError();
+        if (const char *e = getenv("MSPMV_FAKE_L2_MIB")) { const double m = atof(e); if (m > 0) c.l2_bytes = (long long) (m * 1048576.0); }
+        if (const char *e = getenv("MSPMV_FAKE_XCDS")) { const int n = atoi(e); if (n > 0) c.xcds = n; }
+        cached[dev] = c; have[dev] = true;
+    }
+    return cached[dev];
+}
+
 // Column-band passes (run_band_passes): how many, for a call the host can only describe by its sizes.  0 = none.
-// Automatic choice read from ms per SpMV on MI355X, 96 M uniformly spread nonzeros (tools/band_passes_bench.py,
-// profiles/r02_band_passes.txt), x in MiB:
+// The choice is a function of x_bytes / (one XCD's L2): a band's slice of x must (nearly) stay in the L2 of every XCD that
+// gathers from it, and every further pass costs another CSR stream.  The ratios below were read from ms per SpMV on MI355X
+// (L2 = 4 MiB), 96 M uniformly spread nonzeros (tools/band_passes_bench.py; profiles/r02_band_passes.txt, and
+// profiles/r04_band_passes_5to8.txt for 5, 6 and 8 bands: every one of them slower than 4 up to x = 24 MiB, 5 bands 1 % ahead
+// at 32 MiB fp32 only -- a further pass costs 0.10-0.15 ms, more than the hits it buys), x in MiB:
 //   fp32   one pass   2 bands   3 bands   4 bands        fp64   one pass   2 bands   3 bands   4 bands
 //    4      0.549      0.622     0.767     0.920            8     0.993      0.849     0.980     1.137
 //    6      0.706      0.636     0.774     0.926           12     1.234      0.939     1.020     1.145
@@ -158,11 +188,13 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
 //   16      1.308      1.085     0.939     1.000           32     1.614      1.501     1.462     1.418
 //   24      1.457      1.323     1.225     1.170
 //   32      1.585      1.445     1.397     1.371
-// only for the large-problem shape, from 160 MiB of CSR stream (a matrix the windows refuse pays ~2-4 us for having been
-// asked: 5 % of a 41 us banded SpMV at 24 M nonzeros, 2.5 % from 80 M) and at least 8 nonzeros per row, so that a pass is the
-// CSR stream and little else; whether the columns are in fact spread is decided on the device.  Below 256 MB of stream the
-// passes use ordinary loads like the one-sweep kernel (the matrix then stays in the Infinity Cache from pass to pass:
-// 24 M uniformly spread nonzeros over 7.6 / 11.4 MiB of x: 242 -> 174 us, 301 -> 214 us).
+// i.e. fp32: 2 bands from x = 1.375 L2, 3 from 2.625 L2, 4 from 5 L2, none beyond 10 L2 (the slices miss again and the passes
+// only cost); fp64: 1.75 / 3.5 / 5 / 9 L2.  Only for the large-problem shape, from a CSR stream of 5 x the device's total L2
+// (160 MiB here: a matrix the windows refuse pays ~2-4 us for having been asked, 5 % of a 41 us banded SpMV at 24 M
+// nonzeros, 2.5 % from 80 M) and at least 8 nonzeros per row, so that a pass is the CSR stream and little else; whether the
+// columns are in fact spread is decided on the device.  Below 256 MB of stream the passes use ordinary loads like the
+// one-sweep kernel (the matrix then stays in the Infinity Cache from pass to pass: 24 M uniformly spread nonzeros over
+// 7.6 / 11.4 MiB of x: 242 -> 174 us, 301 -> 214 us).
 static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, int rows, int nnz, const CallExtra &ex, int *force)
 {
     *force = 0;
@@ -171,11 +203,12 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     const int policy = ex.tune.band_passes;
     if (policy < 0) return 0;
     if (policy >= 2) { *force = 1; return x_bytes / value_bytes >= policy ? policy : 0; }
+    const DeviceCaches dc = device_caches();
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
-    if (stream_bytes < (160ull << 20) || (long long) nnz < 8LL * rows) return 0;
-    const double mib = (double) x_bytes / 1048576.0;
-    if (value_bytes == 4) return mib < 5.5 ? 0 : mib < 10.5 ? 2 : mib < 20 ? 3 : mib <= 40 ? 4 : 0;
-    return mib < 7 ? 0 : mib < 14 ? 2 : mib < 20 ? 3 : mib <= 36 ? 4 : 0;
+    if (stream_bytes < 5ull * (unsigned long long) dc.xcds * (unsigned long long) dc.l2_bytes || (long long) nnz < 8LL * rows) return 0;
+    const double r = (double) x_bytes / (double) dc.l2_bytes;
+    if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : 0;
+    return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : 0;
 }
 
 // CU count of the current device, queried once per device (never on the hot path again).
@@ -950,6 +983,15 @@ int mspmv_set_band_passes(int32_t value_bytes, int32_t passes)
 {
     if ((value_bytes != 4 && value_bytes != 8) || passes == 1 || passes > 64) return hipErrorInvalidValue;
     t_tune[value_bytes == 8].band_passes = passes < 0 ? -1 : passes;
+    return hipSuccess;
+}
+
+int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *cus)
+{
+    const DeviceCaches dc = device_caches();
+    if (l2_bytes_per_xcd) *l2_bytes_per_xcd = dc.l2_bytes;
+    if (xcds) *xcds = dc.xcds;
+    if (cus) *cus = device_cus();
     return hipSuccess;
 }
 

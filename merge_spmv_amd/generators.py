@@ -256,3 +256,69 @@ def rmat_symmetric_csr(scale: int, edges: int, dtype=torch.float64, device="cuda
     torch.cumsum(lens, 0, out=offsets[1:])
     vals = (uniform01(seed + 1, ee) * 2.0 - 1.0).to(dtype)
     return DeviceCsr(n, n, offsets.to(torch.int32), cols, vals)
+
+
+# The one matrix the reference publishes a number for (README.md:116,137-138: circuit5M, 5 558 326 x 5 558 326,
+# 59 524 291 nonzeros, fp64: 181.6 effective GB/s = 62.96 % of the K40's peak) cannot be fetched offline either.
+SEED_CIRCUIT = 0x5EED00C5
+CIRCUIT5M_ROWS, CIRCUIT5M_NNZ = 5_558_326, 59_524_291
+# its longest rows as fractions of the nonzero count (the largest is circuit5M's 1 290 501-entry row), and where they sit
+_CIRCUIT_GIANTS = ((1_290_501 / 59_524_291, 0.2), (645_000 / 59_524_291, 0.4), (320_000 / 59_524_291, 0.6), (160_000 / 59_524_291, 0.8))
+
+
+def circuit_csr(rows: int = CIRCUIT5M_ROWS, nnz: int = CIRCUIT5M_NNZ, dtype=torch.float64, device="cuda",
+                seed: int = SEED_CIRCUIT) -> DeviceCsr:
+    """A circuit5M-SHAPED stand-in (a seeded synthetic, not the SuiteSparse matrix): square, exactly `nnz` entries, ~10.7
+    per row on average with the spread of a circuit-simulation matrix -- 70 % of the rows hold 2-8 entries, 27.4 % 8-30,
+    2.6 % 30-90, and four "supply net" rows hold 2.2 %, 1.1 %, 0.5 % and 0.3 % of all nonzeros -- the diagonal present in
+    every row, 80 % of the other entries within +-2000 columns of it (cubic fall-off), 15 % within +-200 000, 3 % anywhere,
+    2 % on four hub columns; the giant rows reference columns uniformly.  CSR sorted by (row, column), duplicates kept,
+    values uniform in [-1, 1).  Element k of every random stream is a pure function of (seed, k): the same matrix on any device."""
+    cols = rows
+    r = torch.arange(rows, dtype=torch.int64, device=device)
+    u, v = uniform01(seed, r), uniform01(seed + 1, r)
+    lens = torch.where(u < 0.70, 2 + (7 * v).to(torch.int64),
+                       torch.where(u < 0.9738, 8 + (23 * v).to(torch.int64), 30 + (61 * v).to(torch.int64)))
+    giant_rows = [min(int(rows * pos), rows - 1) for _, pos in _CIRCUIT_GIANTS]
+    giant_lens = [max(int(round(nnz * frac)), 1) for frac, _ in _CIRCUIT_GIANTS]
+    if rows >= 64 and nnz >= 16 * rows // 2:
+        for gr, gl in zip(giant_rows, giant_lens):
+            lens[gr] = gl
+    # the exact count: +-1 on rows spread evenly over the matrix (never a giant row, never below one entry)
+    diff = nnz - int(lens.sum().item())
+    if diff != 0:
+        ok = torch.ones(rows, dtype=torch.bool, device=device)
+        ok[torch.tensor(giant_rows, device=device)] = False
+        if diff < 0:
+            ok &= lens > 1
+        cand = torch.nonzero(ok).flatten()
+        reps, rest = divmod(abs(diff), int(cand.numel()))
+        step = 1 if diff > 0 else -1
+        lens[cand] += step * reps
+        if rest:
+            pick = cand[(torch.arange(rest, dtype=torch.int64, device=device) * int(cand.numel())) // rest]
+            lens[pick] += step
+        assert int(lens.min().item()) >= 1 or diff > 0
+    offsets = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=offsets[1:])
+    assert int(offsets[-1].item()) == nnz
+    row_of = torch.repeat_interleave(r, lens)
+    k = torch.arange(nnz, dtype=torch.int64, device=device)
+    first = k == offsets[row_of]                                    # the row's first generated entry: the diagonal
+    a, b = uniform01(seed + 2, k), uniform01(seed + 3, k)
+    s = 2.0 * b - 1.0
+    near = row_of + torch.round(s * s * s * 2000.0).to(torch.int64)
+    mid = row_of + torch.round(s * 200_000.0).to(torch.int64)
+    anywhere = (b * cols).to(torch.int64)
+    hub = (((b * 4).to(torch.int64).clamp_(max=3) * 2 + 1) * cols) // 8
+    col = torch.where(a < 0.80, near, torch.where(a < 0.95, mid, torch.where(a < 0.98, anywhere, hub)))
+    is_giant = torch.zeros(rows, dtype=torch.bool, device=device)
+    if rows >= 64 and nnz >= 16 * rows // 2:
+        is_giant[torch.tensor(giant_rows, device=device)] = True
+    col = torch.where(is_giant[row_of], anywhere, col)
+    col = torch.where(first, row_of, col).clamp_(0, cols - 1)
+    del a, b, s, near, mid, anywhere, hub, first
+    order = torch.sort(row_of * cols + col).indices                 # (equal keys are equal entries: stability is moot)
+    col = col[order].to(torch.int32)
+    vals = (uniform01(seed + 4, k[order]) * 2.0 - 1.0).to(dtype)
+    return DeviceCsr(rows, cols, offsets.to(torch.int32), col, vals)

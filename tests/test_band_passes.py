@@ -3,9 +3,12 @@ run_band_passes).  CPU: argument checking and the automatic policy's preconditio
 oracle on every shape family (the passes must be a pure re-association of the same sums), the device-side detector
 on matrices it must accept (uniformly spread columns) and refuse (R-MAT, banded), and that automatic calls stay
 bitwise equal to what the chosen path alone computes -- through plain, prepared and graph-captured calls."""
+import os
+
 import numpy as np
 import pytest
 
+from conftest import ROOT
 import merge_spmv_amd as M
 from oracle import oracle as O
 
@@ -53,6 +56,35 @@ def test_automatic_policy_table():
         assert M.band_passes(1000, 1000, 5000, 4) == 0          # (a forced count needs as many columns per band ... and the large-problem tile shape)
     finally:
         M.set_band_passes(4, 0)
+
+
+def test_policy_follows_the_l2_it_is_told_about():
+    """the band count is a function of x_bytes / (one XCD's L2) and the stream floor of the
+    device's total L2 -- queried from the runtime, here overridden through the environment (read once per process, hence the
+    subprocesses): half the L2 means the same x needs more bands and the passes are offered from half the x; a part with
+    fewer, larger L2s shifts the other way."""
+    import subprocess, sys, json
+    code = ("import json, merge_spmv_amd as M\n"
+            "C2 = (3_125_000, 3_125_000, 100_000_000)\n"
+            "mib = lambda m, vb: m * 2**20 // vb\n"
+            "print(json.dumps({'caches': M.device_caches(), 'c2': [M.band_passes(*C2, 4), M.band_passes(*C2, 8)],\n"
+            "  'f32': [M.band_passes(3_000_000, mib(m, 4), 96_000_000, 4) for m in (2, 3, 4, 6, 8, 12, 16, 24, 32, 48)],\n"
+            "  'small_stream': M.band_passes(1_000_000, mib(12, 4), 12_000_000, 4)}))\n")
+    def run(env_extra):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    base = run({"MSPMV_FAKE_L2_MIB": "4", "MSPMV_FAKE_XCDS": "8"})          # the MI355X figures, spelled out
+    assert base["caches"]["l2_bytes_per_xcd"] == 4 << 20 and base["caches"]["xcds"] == 8
+    assert base["c2"] == [3, 4] and base["f32"] == [0, 0, 0, 2, 2, 3, 3, 4, 4, 0] and base["small_stream"] == 0
+    half = run({"MSPMV_FAKE_L2_MIB": "2", "MSPMV_FAKE_XCDS": "8"})
+    assert half["caches"]["l2_bytes_per_xcd"] == 2 << 20
+    assert half["f32"] == [0, 2, 2, 3, 3, 4, 4, 0, 0, 0]                         # every threshold at half the x
+    assert half["c2"] == [4, 0]                                                  # 11.9 MiB = 5.96 L2; 23.8 MiB fp64 = 11.9 L2: beyond
+    assert half["small_stream"] == 4                                             # 92 MiB of stream >= 5 x 8 x 2 MiB now (x = 6 L2)
+    big = run({"MSPMV_FAKE_L2_MIB": "16", "MSPMV_FAKE_XCDS": "2"})
+    assert big["c2"] == [0, 0] and big["f32"][-3:] == [2, 2, 3]                  # 24 / 32 / 48 MiB = 1.5 / 2 / 3 L2
 
 
 def test_temp_storage_covers_the_band_bookkeeping():

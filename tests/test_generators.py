@@ -94,3 +94,32 @@ def test_lattice_generators_are_the_reference_inputs(kind, width):
     assert np.array_equal(c.row_offsets, d.row_offsets.numpy())
     assert np.array_equal(c.column_indices, d.column_indices.numpy())
     assert np.array_equal(c.values, d.values.numpy())
+
+
+def test_circuit_shaped_stand_in():
+    """circuit_csr: the circuit5M-shaped input of bench.py's `configs` (the reference's one published number is on circuit5M,
+    README.md:116,137-138) -- exact nonzero count, valid sorted CSR, the stated row-length classes, a diagonal in every row,
+    four giant rows, and the same matrix every time."""
+    rows, nnz = 55_583, 595_243                        # 1/100 of circuit5M
+    A = G.circuit_csr(rows, nnz, dtype=torch.float64, device="cpu")
+    off = A.row_offsets.numpy().astype(np.int64); col = A.column_indices.numpy().astype(np.int64)
+    assert A.rows == A.cols == rows and A.nnz == nnz and off[0] == 0 and off[-1] == nnz
+    lens = np.diff(off)
+    assert lens.min() >= 1 and abs(lens.mean() - nnz / rows) < 1e-9
+    row_of = np.repeat(np.arange(rows), lens)
+    assert np.all(np.diff(row_of * rows + col) >= 0) and col.min() >= 0 and col.max() < rows      # sorted by (row, column)
+    giants = np.sort(lens)[-4:]
+    assert np.allclose(giants / nnz, [160_000 / 59_524_291, 320_000 / 59_524_291, 645_000 / 59_524_291, 1_290_501 / 59_524_291], rtol=2e-2)
+    rest = np.sort(lens)[:-4]
+    assert 0.68 < (rest <= 8).mean() < 0.73 and rest.max() <= 91
+    # the diagonal is there; most other entries are near it
+    has_diag = np.zeros(rows, bool); has_diag[row_of[col == row_of]] = True
+    assert has_diag.all()
+    ordinary = lens[row_of] < 1000
+    assert 0.75 < (np.abs(col - row_of)[ordinary] <= 2000).mean() < 0.88
+    v = A.values.numpy()
+    assert v.min() >= -1 and v.max() < 1 and abs(v.mean()) < 0.01
+    B = G.circuit_csr(rows, nnz, dtype=torch.float64, device="cpu")
+    assert torch.equal(A.column_indices, B.column_indices) and torch.equal(A.values, B.values) and torch.equal(A.row_offsets, B.row_offsets)
+    # the stated full size is what the defaults give (no tensor built here)
+    assert (G.CIRCUIT5M_ROWS, G.CIRCUIT5M_NNZ) == (5_558_326, 59_524_291)

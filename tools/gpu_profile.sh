@@ -52,12 +52,16 @@ def avg(name, counter):
         if r["kernel"].startswith("tile_kernel") and r["counter"] == counter: return float(r["avg_per_dispatch"])
     return None
 fetch_kb, write_kb = avg("FETCH_SIZE", "FETCH_SIZE"), avg("WRITE_SIZE", "WRITE_SIZE")
-workload = "dense32" if "dense32" in extra else "c2"
-dtype = "f64" if "f64" in extra else "f32"
-d = {"workload": workload, "dtype": dtype, "kernel": "tile kernel of the call (tile_kernel_vec<..,BAND> for c2, tile_kernel_snap otherwise)",
+workload = os.environ.get("PROFILE_LABEL") or ("dense32" if "dense32" in extra else "c2")
+dtype = os.environ.get("PROFILE_DTYPE") or ("f64" if "f64" in extra else "f32")
+d = {"workload": workload, "dtype": dtype, "command": os.environ.get("PROFILE_CMD", "bench.py " + extra),
+     "collected": "separate rocprofv3 --kernel-trace --pmc passes (tools/gpu_profile.sh), averaged per dispatch of the tile kernel",
+     "kernel": "tile kernel of the call (tile_kernel_vec<..,BAND> for column-band candidates, tile_kernel_snap otherwise)",
      "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
      "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled; KB -> bytes x1024",
-     "tile_kernel_hbm_bytes_per_launch": None if fetch_kb is None or write_kb is None else int((2 * fetch_kb + write_kb) * 1024)}
+     "tile_kernel_hbm_bytes_per_launch": None if fetch_kb is None or write_kb is None else int((2 * fetch_kb + write_kb) * 1024),
+     "TCC_HIT_per_launch": avg("TCC_HIT_sum_TCC_MISS_sum", "TCC_HIT_sum"), "TCC_MISS_per_launch": avg("TCC_HIT_sum_TCC_MISS_sum", "TCC_MISS_sum"),
+     "TCC_EA0_RDREQ_128B_per_launch": avg("TCC_EA0_RDREQ_64B_sum_TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_128B_sum")}
 json.dump(d, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(d))
 PY

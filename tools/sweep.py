@@ -35,6 +35,9 @@ def workloads(names):
         elif n == "rmat":
             A = G.rmat_csr(22, 60_000_000, dtype=torch.float64, seed=G.SEED_C3)
             yield "rmat22_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n == "circuit":
+            A = G.circuit_csr(dtype=torch.float64)
+            yield "circuit5M_shaped_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "rmat24":
             A = G.rmat_csr(24, 250_000_000, dtype=torch.float64, seed=G.SEED_C5)
             yield "rmat24_250M_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
