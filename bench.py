@@ -706,7 +706,7 @@ def main():
         traffic = None
         traffic_source = "not measured: hardware counters need rocprofv3 --pmc passes (tools/gpu_profile.sh), which bench.py does not run"
         if not mg:
-            traffic, src = replayed_traffic(workload, dtype_name)
+            traffic, src = replayed_traffic("c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload, dtype_name)
             if traffic is not None:
                 traffic_source = src
         out = {
