@@ -374,7 +374,9 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                        reinterpret_cast<uintptr_t>(p.row_end - 1)) & 15) == 0;
     // a profiler slot is taken only by calls that run all the passes it brackets
     const int slot = phase == PHASE_COORDS_ONLY ? -1 : prof_take_slot();
-    if (L.snap && vec && ex.tile_map == 0 && ex.band_passes <= 1) {
+    // (the band-major plan's contiguous tile ranges, ex.tile_map: through the one-launch kernel in fp64 -- C2 plan 0.669 -> 0.640 ms --,
+    //  through the classic launches in fp32, where the one-launch form measured 3 % slower: 0.508 -> 0.523)
+    if (L.snap && vec && (ex.tile_map == 0 || sizeof(V) == 8) && ex.band_passes <= 1) {
         // ---- ONE launch: row-snapped tiles on verified coordinate hints (tile_kernel_snap) ----
         int *rstart = reinterpret_cast<int *>(base + L.rstart_off);
         if (phase == PHASE_COORDS_ONLY) {
@@ -396,7 +398,9 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         static std::atomic<int> snap_cache[64];
         const int chunk_flag = (L.flags >> 24) & 0xf;
         const int wanted = chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
-        const int chunk_log2 = safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
+        // (ex.tile_map: the band-major plan's one contiguous tile range per XCD -- inside a range a lower-numbered tile sits on an
+        //  earlier block of the same XCD, so a tile that waits for records waits for blocks dispatched before it)
+        const int chunk_log2 = ex.tile_map ? ex.tile_map : safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
         const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
         const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (256ull << 20));
         const unsigned grid = (unsigned) L.num_tiles;
