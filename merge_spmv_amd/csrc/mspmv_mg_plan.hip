@@ -126,11 +126,13 @@ __global__ __launch_bounds__(256) void mg_push_rows_kernel(const V *__restrict__
 {
     const long long stride = (long long) gridDim.x * blockDim.x;
     V *__restrict__ out = dst[blockIdx.y];
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = y[i];
     // the replicas may belong to other devices (and, in the hipIpc form, the "rows are there" flag is written by the NEXT
-    // kernel of this stream and polled by a kernel of the owner's device): make the stores visible system-wide before this
-    // kernel ends, rather than rely on what scope the end-of-kernel release of back-to-back launches has
-    __threadfence_system();
+    // kernel of this stream and polled by a kernel of the owner's device): every element is stored with system scope --
+    // written through, not left dirty in this device's L2 -- so the rows are visible system-wide when the kernel has ended,
+    // whatever scope the end-of-kernel release of back-to-back launches has.  (A __threadfence_system() per thread instead
+    // means one L2 write-back per wave: 7 x the time of the push, 0.014 -> 0.098 ms for 32 MB.)
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        __hip_atomic_store(out + i, y[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- IPC backend: the mailbox block every part shares with its peers (device memory, opened by them through hipIpc) ----

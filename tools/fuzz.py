@@ -13,7 +13,8 @@ from merge_spmv_amd import multi_gpu as MG
 
 # 16 = beyond the self-searching small-problem kernel: ONE launch of tile_kernel_snap; + 0x40000000 = the classic three launches
 FLAGS = [0, 0, 0, 2, 4, 8, 16, 16, 16, 20, 24, 48, 80, 128, 144, 0xF000010, 0x3000010, 0xE000010, 0x20000010, 0x20000000, 0x40000000, 0x40000000,
-         0x40000010, 0x40000010, 0x60000010, 0x4E000010, 0x40000030, 0x40000050]
+         0x40000010, 0x40000010, 0x60000010, 0x4E000010, 0x40000030, 0x40000050,
+         -0x80000000, -0x80000000 | 16, -0x80000000 | 32]          # (MSPMV_TUNE_NO_LEAN: closed short-row tiles through the general reduction as well)
 SHAPES = {4: [(256, 7), (256, 11)], 8: [(256, 7), (256, 11)]}           # the product library's shapes (the sweep shapes live in the dev build)
 
 
@@ -78,6 +79,7 @@ def main():
         try:
             M.set_tuning(vb, shape[0], shape[1], flags)
             M.set_band_passes(vb, passes)
+            M.set_record_polls(int(rng.choice([0, 0, 0, 1, -1])))       # default / one look / never look at the published records: the recomputing path
             mode = rng.integers(0, 5)
             if mode == 3:                              # prepared band-major plan (mspmv_csrmv_plan_*)
                 x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
@@ -160,6 +162,7 @@ def main():
         finally:
             M.set_tuning(vb)
             M.set_band_passes(vb, 0)
+            M.set_record_polls(0)
         cases += 1
     torch.cuda.synchronize()
     print(f"fuzz: {cases} cases in {budget:.0f} s, all within tolerance (worst |err|/bound = {worst:.3f})")

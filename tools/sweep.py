@@ -35,6 +35,9 @@ def workloads(names):
         elif n == "rmat":
             A = G.rmat_csr(22, 60_000_000, dtype=torch.float64, seed=G.SEED_C3)
             yield "rmat22_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
+        elif n.startswith("g2d"):                      # g2d<width>: a small 5-point grid, e.g. g2d100
+            A = G.grid2d_csr(int(n[3:]), torch.float64)
+            yield f"grid2d_{n[3:]}_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
         elif n == "circuit":
             A = G.circuit_csr(dtype=torch.float64)
             yield "circuit5M_shaped_f64", A, G.uniform_pm1(1, A.cols, torch.float64, "cuda")
