@@ -14,7 +14,9 @@
 //                      (LookBack).  Inside the tile: 16-byte streaming of (col, val) and row offsets, gather of x (from a
 //                      per-block LDS copy when x is <= 4 KB), products and 16-bit tile-relative row ends staged in LDS, one
 //                      bit per row start; segmented running sums over 12 consecutive products per thread + one block-wide
-//                      DPP segmented scan (consume_tile_flags), y stored per row from registers  (ref: DeviceSpmvKernel)
+//                      DPP segmented scan (consume_tile_flags), y stored per row from registers  (ref: DeviceSpmvKernel);
+//                      closed tiles of short rows: a thread per row straight from LDS instead (consume_tile_rows);
+//                      fp64 values read non-temporally are fetched line by line over the wave (ld_stream4_linewise)
 //   the classic three launches (column-band candidates, the band-major plan's tile order, unaligned arrays, tuning options):
 //   1. tile boundaries of the merge path -> coords[tile]            (ref: DeviceSpmvSearchKernel)
 //        coords_scatter_kernel : ONE coalesced pass over row_offsets (row end r sits at path position
@@ -740,7 +742,8 @@ __device__ __forceinline__ void consume_tile_lds(const Params<V> &p, const Coord
 // publishing), and workgroups are dispatched in order: an awaited block is running or done (mspmv_api.hip:
 // safe_chunk_log2 keeps that true under the XCD-chunked tile order).  The reference's fp64 fix-up relies on the same
 // property (decoupled look-back, agent_segment_fixup.cuh:262-341 with single_pass_scan_operators.cuh); unlike it,
-// nothing here spins on a chain.  Records: rec_store / rec_take above.
+// nothing here spins on a chain -- and when the property does not hold (fewer resident blocks than assumed) the waiting
+// tile computes the sum itself after a bounded poll (recompute_row_head).  Records: rec_store / rec_take above.
 // ---------------------------------------------------------------------------
 struct LookBack {
     unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
@@ -2078,8 +2081,10 @@ __global__ __launch_bounds__(BLOCK) void fixup_onepass_kernel(const Carry<V> *__
 //    the whole block, 8 records per thread and round), adds them in a fixed order and clears them.  A publisher never
 //    waits before it publishes, so there are no chains; a waiting tile needs lower-numbered TILES to have been dispatched,
 //    which the block -> tile mapping guarantees as long as one of its XCD runs fits the resident blocks twice over
-//    (mspmv_api.hip: safe_chunk_log2).  Deterministic and bitwise reproducible: the result does not depend on whether
-//    the hints were right.
+//    (mspmv_api.hip: safe_chunk_log2) -- and otherwise recomputes the missing sum itself after a bounded poll, so the call
+//    never depends on another workgroup's progress.  Deterministic and bitwise reproducible (a recomputed sum is the one
+//    re-association that can differ): the result does not depend on whether the hints were right.
+//  * Closed tiles of short rows take the lean row-by-row reduction (consume_tile_rows) instead of flags + scan.
 // ---------------------------------------------------------------------------
 // Merge-path point of a diagonal WITHOUT a coordinate pass and, on a regular matrix, at the price of the one memory round
 // trip that loading a stored coordinate costs: the row is guessed arithmetically -- x ~ diagonal * rows / (rows + nnz),
