@@ -517,6 +517,45 @@ def test_config3_orkut_sized_fp64(M):
     assert lens.max() > 1000 * max(lens.mean(), 1)          # genuinely skewed
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("kind", ["dense5", "grid2d", "ragged_0_8", "upto16"])
+def test_short_row_matrices_are_bitwise_the_sequential_definition(M, kind, prec):
+    """Closed tiles of short rows take the lean reduction (consume_tile_rows): every row of at most 16 nonzeros is added up
+    left to right from +0.0, product by product -- the very order of the reference's SpmvGold (gpu_spmv.cu:262-278,
+    cpu_spmv.cpp:257-277) -- so on a matrix whose tiles are all such tiles y is BIT FOR BIT the oracle's sequential gold in
+    the matrix's own precision, at a size of the small tile shape and at one of the large shape; with the general
+    reduction forced (MSPMV_TUNE_NO_LEAN) it is the same sums in another association (strict bound only)."""
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(len(kind) * 3 + vb)
+    for rows in (3000, 1_300_000):
+        if kind == "dense5":
+            lens = np.full(rows, 5); cols = 5
+        elif kind == "grid2d":
+            w = int(np.sqrt(rows)); rows = w * w
+            lens = None
+        elif kind == "ragged_0_8":
+            lens = rng.integers(0, 9, rows); cols = rows
+        else:       # mostly short, some of 9..16: the average stays <= 8 in every tile
+            lens = np.where(rng.random(rows) < 0.2, rng.integers(9, 17, rows), rng.integers(0, 5, rows)); cols = rows
+        if lens is None:
+            g = O.make("grid2d", w, dtype=dtype)
+            csr = O.Csr(g.rows, g.cols, g.row_offsets, g.column_indices, rng.uniform(-1, 1, g.nnz).astype(dtype))
+        else:
+            csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
+        x = rng.uniform(-1, 1, csr.cols).astype(dtype)
+        y, _ = run_gpu(M, csr, x)
+        gold = O.spmv_gold(csr, x)
+        assert np.array_equal(y.view(np.uint32 if vb == 4 else np.uint64), gold.view(np.uint32 if vb == 4 else np.uint64)), \
+            (kind, prec, rows, int((y != gold).sum()))
+        check_strict(M, csr, x, y)
+        try:
+            M.set_tuning(vb, 0, 0, -0x80000000)             # MSPMV_TUNE_NO_LEAN
+            y2, _ = run_gpu(M, csr, x)
+        finally:
+            M.set_tuning(vb)
+        check_strict(M, csr, x, y2)
+
+
 def test_circuit5m_shaped_stand_in_full_size_fp64(M):
     """The reference's one published number is on circuit5M (README.md:116,137-138: 5 558 326^2, 59 524 291 nonzeros, fp64);
     the file cannot be fetched offline, so bench.py's `configs` run a seeded stand-in of exactly those sizes with a circuit
