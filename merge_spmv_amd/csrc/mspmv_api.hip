@@ -153,14 +153,15 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
 struct DeviceCaches { long long l2_bytes; int xcds; };
 static DeviceCaches device_caches()
 {
-    static std::mutex lock;
-    static DeviceCaches cached[64];
-    static bool have[64];
+    // (lock-free after the first call per device: this sits on the path of every large-problem call.  Two threads racing through
+    //  the first call compute the same values.)
+    static std::atomic<long long> cached_l2[64];
+    static std::atomic<int> cached_xcds[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void) hipGetLastError(); dev = 0; }
-    std::lock_guard<std::mutex> g(lock);
-    if (!have[dev]) {
-        DeviceCaches c; c.l2_bytes = 4LL << 20; c.xcds = 8;                      // MI355X in SPX mode: 8 XCDs x 4 MiB
+    DeviceCaches c; c.l2_bytes = cached_l2[dev].load(std::memory_order_acquire); c.xcds = cached_xcds[dev].load(std::memory_order_relaxed);
+    if (c.l2_bytes == 0) {
+        c.l2_bytes = 4LL << 20; c.xcds = 8;                                      // MI355X in SPX mode: 8 XCDs x 4 MiB
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) c.xcds = v; else (void) hipGetLastError();
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeL2CacheSize, dev) == hipSuccess && v > 0) {
@@ -169,9 +170,10 @@ static DeviceCaches device_caches()
         } else (void) hipGetLastError();
         if (const char *e = getenv("MSPMV_FAKE_L2_MIB")) { const double m = atof(e); if (m > 0) c.l2_bytes = (long long) (m * 1048576.0); }
         if (const char *e = getenv("MSPMV_FAKE_XCDS")) { const int n = atoi(e); if (n > 0) c.xcds = n; }
-        cached[dev] = c; have[dev] = true;
+        cached_xcds[dev].store(c.xcds, std::memory_order_relaxed);
+        cached_l2[dev].store(c.l2_bytes, std::memory_order_release);
     }
-    return cached[dev];
+    return c;
 }
 
 // Column-band passes (run_band_passes): how many, for a call the host can only describe by its sizes.  0 = none.
@@ -203,9 +205,10 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     const int policy = ex.tune.band_passes;
     if (policy < 0) return 0;
     if (policy >= 2) { *force = 1; return x_bytes / value_bytes >= policy ? policy : 0; }
+    if ((long long) nnz < 8LL * rows) return 0;
     const DeviceCaches dc = device_caches();
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
-    if (stream_bytes < 5ull * (unsigned long long) dc.xcds * (unsigned long long) dc.l2_bytes || (long long) nnz < 8LL * rows) return 0;
+    if (stream_bytes < 5ull * (unsigned long long) dc.xcds * (unsigned long long) dc.l2_bytes) return 0;
     const double r = (double) x_bytes / (double) dc.l2_bytes;
     if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : 0;
     return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : 0;
