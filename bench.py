@@ -190,6 +190,48 @@ def replayed_traffic(workload, dtype_name):
                                                       "from separate rocprofv3 --pmc passes over this workload, " + str(pmc.get("collected", "see profiles/README.md")))
 
 
+def live_traffic(label, steps=24, timeout_s=150):
+    """HBM-side bytes per launch of the tile kernel, MEASURED IN THIS RUN on this box: two separate `rocprofv3 --kernel-trace --pmc`
+    passes (FETCH_SIZE, then WRITE_SIZE: never combined with other trace domains) over `tools/run_config.py <label>`, which runs
+    the same call on the same synthetic matrix in a child process; corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+    (KB -> bytes, and gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes: doubled).  None when rocprofv3 is missing, fails
+    or takes longer than `timeout_s` per pass -- the caller then falls back to the committed passes (replayed_traffic)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="mspmv_pmc_", dir="/tmp")
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    got = {}
+    try:
+        for pmc in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, pmc)
+            cmd = [exe, "--kernel-trace", "--pmc", pmc, "--output-format", "csv", "-d", out, "-o", "b", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "run_config.py"), label, "--steps", str(steps)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {pmc} failed (rc {r.returncode})"
+            n, total = 0, 0.0
+            for row in csv.DictReader(open(files[0])):
+                if "tile_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == pmc:
+                    n += 1; total += float(row.get("Counter_Value", 0) or 0)
+            if n == 0:
+                return None, f"no tile-kernel dispatch in the {pmc} pass"
+            got[pmc] = (total / n, n)
+    except Exception as e:  # noqa: BLE001 - measurement garnish: never at the price of the line
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fetch_kb, nf = got["FETCH_SIZE"]; write_kb, nw = got["WRITE_SIZE"]
+    return int((2.0 * fetch_kb + write_kb) * 1024), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/run_config.py {label}, "
+                                                    f"average of {nf} / {nw} dispatches of the tile kernel; FETCH_SIZE {fetch_kb:.0f} KB x 1024 x 2 (gfx950 correction) + WRITE_SIZE {write_kb:.0f} KB x 1024")
+
+
 REFERENCE_PUBLISHED_PCT = 62.96      # circuit5M fp64 on a K40: 181.6 effective GB/s of 288.4 (README.md:116,137-138)
 
 
@@ -247,7 +289,7 @@ def config_specs(torch, G, dev, steps):
     ]
 
 
-def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True):
+def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True, live_pmc=True):
     """The `configs` array: every single-GPU configuration of BASELINE.json that the headline does not cover (and the
     circuit5M-shaped matrix of the reference's published number), through the same stateless call.  Generation is on the GPU
     and not timed; a configuration that would start after `budget_s` of this function's wall time is reported as skipped
@@ -295,10 +337,14 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True)
             if offered > 1:
                 spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
                 rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
-            tr, src = replayed_traffic(label, "f32" if vb == 4 else "f64")
+            rep_tr, src = replayed_traffic(label, "f32" if vb == 4 else "f64")
+            live_tr, live_src = (None, "config 5: rocprofv3 does not survive generating its 36 GB") if (label == "c5" or not live_pmc) else live_traffic(label)
+            tr = live_tr if live_tr is not None else rep_tr
             if tr is not None:
-                rec["roofline"]["traffic"] = tr; rec["roofline"]["traffic_source"] = src
+                rec["roofline"]["traffic"] = tr
+                rec["roofline"]["traffic_source"] = live_src if live_tr is not None else src + f" [live counters: {live_src}]"
                 rec["roofline"]["traffic_over_algorithmic"] = round(tr / b_alg, 3)
+                rec["roofline"]["traffic_replayed_from_committed_passes"] = rep_tr
             # cheap sanity on the result: finite (parity proper is tests/ -m gpu)
             rec["y_finite"] = bool(torch.isfinite(y).all().item())
             rec["gathers_per_s_G"] = round(A.nnz / (ms * 1e-3) / 1e9, 2)
@@ -380,6 +426,7 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"],
                     help="N > 1: how the C operator exchanges the boundary-row carries -- one RCCL all-gather per step (default), or the hipIpc "
                          "peer backend (carries written straight into the owner's mailbox, step tags instead of a collective; never timed over links)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="N = 1: do not measure the headline's counter traffic with two rocprofv3 --pmc child runs (replay the committed passes instead)")
     ap.add_argument("--no-vendor", action="store_true", help="N = 1: skip the rocSPARSE comparison column (`vendor` sub-records)")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records (the other single-GPU configurations)")
     ap.add_argument("--configs-budget", type=float, default=150.0, help="seconds the `configs` leg may take before it stops starting new ones")
@@ -704,11 +751,17 @@ def main():
         tile_s = prof["tile_ms"] * 1e-3
         achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
         traffic = None
-        traffic_source = "not measured: hardware counters need rocprofv3 --pmc passes (tools/gpu_profile.sh), which bench.py does not run"
+        replayed = None
+        traffic_source = "not measured: the counter passes (rocprofv3 --pmc) are run for single-GPU workloads only"
         if not mg:
-            traffic, src = replayed_traffic("c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload, dtype_name)
-            if traffic is not None:
-                traffic_source = src
+            label = "c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload
+            replayed, src = replayed_traffic(label, dtype_name)
+            live, live_src = ((None, "skipped (--no-live-pmc, a tuning override, or config 5: rocprofv3 does not survive generating its 36 GB)")
+                              if args.no_live_pmc or args.tune or args.band_passes or workload == "c5" else live_traffic(label))
+            if live is not None:
+                traffic, traffic_source = live, live_src
+            elif replayed is not None:
+                traffic, traffic_source = replayed, src + f" [live counters: {live_src}]"
         out = {
             "metric": "CsrMV GFLOP/s", "value": round(gflops, 3), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -724,7 +777,8 @@ def main():
             "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap (one launch per part)", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": b_alg,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_over_algorithmic": round(traffic / b_alg, 3) if traffic else None,
+                         "traffic_replayed_from_committed_passes": (replayed if not mg else None), "algorithmic_bytes_per_launch": b_alg,
                          "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5),
                                        "fixup": round(prof["fixup_ms"], 5)},
                          "events": f"hipEvents on the launch stream, {prof['calls']} launches"},
@@ -766,7 +820,7 @@ def main():
         if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs and not args.tune and not args.band_passes:
             del A, ws, y
             torch.cuda.empty_cache()
-            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget, vendor=not args.no_vendor)
+            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget, vendor=not args.no_vendor, live_pmc=not args.no_live_pmc)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
