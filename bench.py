@@ -190,7 +190,19 @@ def replayed_traffic(workload, dtype_name):
                                                       "from separate rocprofv3 --pmc passes over this workload, " + str(pmc.get("collected", "see profiles/README.md")))
 
 
-def live_traffic(label, steps=24, timeout_s=150):
+_LIVE_PMC = {"ok": True, "why": ""}       # one failure (no rocprofv3, a crash, a time-out) turns the live passes off for the rest of the run
+
+
+def live_traffic(label, steps=24, timeout_s=60):
+    if not _LIVE_PMC["ok"]:
+        return None, "live counters switched off after an earlier failure in this run: " + _LIVE_PMC["why"]
+    tr, why = _live_traffic(label, steps, timeout_s)
+    if tr is None:
+        _LIVE_PMC["ok"] = False; _LIVE_PMC["why"] = why
+    return tr, why
+
+
+def _live_traffic(label, steps, timeout_s):
     """HBM-side bytes per launch of the tile kernel, MEASURED IN THIS RUN on this box: two separate `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE, then WRITE_SIZE: never combined with other trace domains) over `tools/run_config.py <label>`, which runs
     the same call on the same synthetic matrix in a child process; corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
