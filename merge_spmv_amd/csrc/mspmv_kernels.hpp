@@ -1320,6 +1320,26 @@ __device__ __forceinline__ Vec4<float> linewise_own(const Vec4<float> &w) { retu
 // values as issue_nonzero_loads left them in the tile's registers -> the values of the lane's own chunk k
 template <typename V, bool NT, bool LAZY>
 constexpr bool vals_linewise() { return sizeof(V) == 8 && NT && !LAZY; }
+// WIRE staging (the production kernels): the values stay as ld_stream4_linewise fetched them -- val.a = the first half of the own chunk
+// (lanes 0-31) / the second half of the chunk 32 lanes down (lanes 32-63), val.b = the first half of the chunk 32 lanes up / the own
+// second half -- and the COLUMNS are swapped to match (two v_permlane32_swap instead of four): every lane then multiplies two pairs that
+// belong to two different chunks, and writes each pair where it belongs in the LDS tile.  Lanes 0-31 and 32-63 of one store
+// instruction together cover 1 KB of consecutive 16-byte units (a lane writing its own 32 bytes as two stores 32 bytes apart
+// collided two-way with the lane four further on).  cols[0..1] belong to val.a, cols[2..3] to val.b.
+__device__ __forceinline__ void wire_cols(const Vec4<int> &col, int (&c)[4])
+{
+    const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned) col.v.x, (unsigned) col.v.z, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned) col.v.y, (unsigned) col.v.w, false, false);
+    c[0] = (int) s0[0]; c[1] = (int) s1[0]; c[2] = (int) s0[1]; c[3] = (int) s1[1];
+}
+// chunk index (in units of 4 elements, relative to the tile's first chunk) and element offset inside it of the pair in val.a / val.b
+struct WirePos { int qa, qb, off; };
+__device__ __forceinline__ WirePos wire_pos(int q, int tid)
+{
+    const bool hi = (tid & 32) != 0;
+    WirePos w; w.qa = hi ? q - 32 : q; w.qb = hi ? q : q + 32; w.off = hi ? 2 : 0;
+    return w;
+}
 
 template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
@@ -1382,9 +1402,23 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     unsigned in_band = 0u;                     // BAND: one bit per staged nonzero of this thread (its column lies in the pass's band)
     constexpr bool LAZY = band_lazy_values<V, BAND>();
     Vec4<V> bval[LAZY ? CPT : 1];              // LAZY: the values, fetched here and only for chunks with a nonzero of the band
+    constexpr bool WIRE = vals_linewise<V, NT, LAZY>() && FL;
+    unsigned wire_in = 0u;                     // WIRE: one bit per held nonzero that lies in the tile
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int e0 = a0 + 4 * (tid + k * BLOCK);
+        if constexpr (WIRE) {
+            int gc[4]; wire_cols(regs.col[k], gc);
+            const WirePos wp = wire_pos(tid + k * BLOCK, tid);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int eb = a0 + 4 * (i < 2 ? wp.qa : wp.qb);             // first element of the chunk this value belongs to
+                const bool in = (unsigned) (eb + wp.off + (i & 1) - c0.y) < (unsigned) tile_nnz && eb <= last_full_nz;
+                wire_in |= in ? 1u << (4 * k + i) : 0u;
+                xv[k][i] = XL ? s_x[in ? gc[i] : 0] : p.x[in ? gc[i] : 0];
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in = (unsigned) (e0 + i - c0.y) < (unsigned) tile_nnz && e0 <= last_full_nz;
@@ -1418,8 +1452,8 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     }
     if (FL && !lean && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - a0));
     // ---- stage products
-    Vec4<V> own_val[LAZY ? 1 : CPT];
-    if constexpr (!LAZY) {
+    Vec4<V> own_val[LAZY || WIRE ? 1 : CPT];
+    if constexpr (!LAZY && !WIRE) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k) own_val[k] = vals_linewise<V, NT, LAZY>() ? linewise_own(regs.val[k]) : regs.val[k];
     }
@@ -1427,6 +1461,19 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
         const int e0 = a0 + 4 * chunk;
+        if constexpr (WIRE) {
+            const WirePos wp = wire_pos(chunk, tid);
+            const V w[4] = {regs.val[k].get(0), regs.val[k].get(1), regs.val[k].get(2), regs.val[k].get(3)};
+            V pa[2], pb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                pa[i] = ((wire_in >> (4 * k + i)) & 1u) ? w[i] * xv[k][i] : (V) 0;
+                pb[i] = ((wire_in >> (4 * k + 2 + i)) & 1u) ? w[2 + i] * xv[k][2 + i] : (V) 0;
+            }
+            st_unit(&s_prod_raw[2 * prod_unit<V, CPT>(2 * wp.qa + (wp.off >> 1), lean)], pa);
+            st_unit(&s_prod_raw[2 * prod_unit<V, CPT>(2 * wp.qb + (wp.off >> 1), lean)], pb);
+            continue;
+        }
         V prod[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1504,8 +1551,15 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
     unsigned in_band = 0u;                     // BAND: one bit per staged nonzero of this thread
     constexpr bool LAZY = band_lazy_values<V, BAND>();
     Vec4<V> bval[LAZY ? CPT : 1];              // LAZY: the values, fetched here and only for chunks with a nonzero of the band
+    constexpr bool WIRE = vals_linewise<V, NT, LAZY>() && FL;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
+        if constexpr (WIRE) {
+            int gc[4]; wire_cols(regs.col[k], gc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[k][i] = XL ? s_x[(unsigned) gc[i]] : p.x[(unsigned) gc[i]];
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (BAND) {
@@ -1543,14 +1597,23 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
         }
     }
     if (FL && !lean && tid == 0) atomicOr(&s_flag[0], 1u << (c0.y - (c0.y & ~3)));
-    Vec4<V> own_val[LAZY ? 1 : CPT];
-    if constexpr (!LAZY) {
+    Vec4<V> own_val[LAZY || WIRE ? 1 : CPT];
+    if constexpr (!LAZY && !WIRE) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k) own_val[k] = vals_linewise<V, NT, LAZY>() ? linewise_own(regs.val[k]) : regs.val[k];
     }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
+        if constexpr (WIRE) {
+            const WirePos wp = wire_pos(chunk, tid);
+            V pa[2], pb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { pa[i] = regs.val[k].get(i) * xv[k][i]; pb[i] = regs.val[k].get(2 + i) * xv[k][2 + i]; }
+            st_unit(&s_prod_raw[2 * prod_unit<V, CPT>(2 * wp.qa + (wp.off >> 1), lean)], pa);
+            st_unit(&s_prod_raw[2 * prod_unit<V, CPT>(2 * wp.qb + (wp.off >> 1), lean)], pb);
+            continue;
+        }
         V prod[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
