@@ -166,7 +166,12 @@ SHAPES = {
 
 PATHS = {"one_launch_small_shape": 0, "classic_small_shape": 0x40000000, "one_launch_large_shape": 16, "one_launch_runs_of_8": 0x3000010,
          "one_launch_round_robin": 0xF000010, "classic_three_launch": 0x40000010, "classic_interp_coords": 0x60000010, "classic_search_kernel": 0x40000018,
-         "classic_contiguous_map": 0x4E000010, "classic_atomic_fix": 0x12, "classic_multilevel_fix": 0x90, "reference_walk": 4 | 16}
+         "classic_contiguous_map": 0x4E000010, "classic_atomic_fix": 0x12, "classic_multilevel_fix": 0x90, "reference_walk": 4 | 16,
+         # non-temporal streams whatever the size (the default beyond 256 MB): in fp64 the values are fetched line by line over the
+         # wave and staged in wire layout (ld_stream4_linewise, wire_cols) -- here on every shape family, ragged array tails included
+         "one_launch_nontemporal": 32 | 16, "one_launch_nontemporal_small_shape": 32, "classic_nontemporal": 0x40000030,
+         # closed tiles of short rows through the general flag / segmented-scan reduction as well (MSPMV_TUNE_NO_LEAN)
+         "one_launch_general_reduction": -0x80000000 | 16, "one_launch_general_reduction_nontemporal": -0x80000000 | 32}
 
 
 @pytest.mark.parametrize("shape", sorted(SHAPES))
