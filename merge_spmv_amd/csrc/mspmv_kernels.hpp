@@ -2243,7 +2243,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // re-assign them under the load (a later, separate s_waitcnt left exactly that open).  What used to sit between the two --
     // clearing the flag words, requesting a tiny x -- now comes first; the block has nothing else to do until its hints are
     // there anyway.
-    constexpr bool SCALAR_HINTS = IPT > 7;
+    constexpr bool SCALAR_HINTS = true;
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     // a tiny x goes to LDS: scalar-hint shapes request it now and write it after the streams have been requested
     XRegs<V, BLOCK> xr;
@@ -2273,8 +2273,8 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     const LookBack lbe = with_epoch(lb, epoch);
     MSPMV_SNAP_TR(1);
     const int total = p.rows + p.nnz;                               // < 2^31
-    const long long d0l = (long long) tile * TILE, d1l = d0l + TILE;
-    const int d0 = (int) (d0l < total ? d0l : total), d1 = (int) (d1l < total ? d1l : total);
+    // (32-bit: tile < num_tiles = ceil(total / TILE), so tile * TILE < total <= 2^31 - 65537 and adding TILE cannot overflow)
+    const int d0 = tile * TILE, d1 = d0 + TILE < total ? d0 + TILE : total;
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
     int x0 = single ? 0 : hint_c.x, rs0 = single ? 0 : hint_r.x, x1 = single ? p.rows : hint_c.z, rs1 = single ? p.nnz : hint_r.y;
@@ -2285,11 +2285,16 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     c0.x = x0; c0.y = snap0 ? rs0 : y0;
     c1.x = x1; c1.y = snap1 ? rs1 : y1;
     // closed tile of short rows (block-uniform; consume_tile_rows): no row-start bits, raw product positions, one LDS phase
-    bool lean = snap0 && snap1 && (long long) (c1.y - c0.y) <= (long long) lean_avg * (c1.x - c0.x);
+    // (unsigned: with garbage hints the product may wrap -- harmless, `lean` is only used once the hints have passed `good`,
+    //  and then a tile has at most TILE rows)
+    bool lean = snap0 && snap1 && (unsigned) (c1.y - c0.y) <= (unsigned) lean_avg * (unsigned) (c1.x - c0.x);
     // hints: anything may be in there.  Only values that keep every speculative access inside the arrays and the LDS tile
     // are tried at all (block-uniform)
-    bool good = x0 >= 0 && x0 <= x1 && x1 <= p.rows && y0 >= 0 && y1 >= y0 && y1 <= p.nnz && rs0 >= 0 && rs0 <= y0 &&
-                rs1 >= rs0 && rs1 <= y1 && c1.y >= c0.y;
+    // 0 <= x0 <= x1 <= rows, 0 <= y0 <= y1 <= nnz, 0 <= rs0 <= y0, rs0 <= rs1 <= y1, as unsigned comparisons without branches (each
+    // chain's last link bounds the earlier ones from below by zero); the last: the snapped boundaries in order
+    bool good = ((unsigned) x0 <= (unsigned) x1) & ((unsigned) x1 <= (unsigned) p.rows) & ((unsigned) y0 <= (unsigned) y1) &
+                ((unsigned) y1 <= (unsigned) p.nnz) & ((unsigned) rs0 <= (unsigned) y0) & ((unsigned) rs0 <= (unsigned) rs1) &
+                ((unsigned) rs1 <= (unsigned) y1) & (c1.y >= c0.y);
     if (good) {
         // the four row offsets that decide whether (x0, rs0) and (x1, rs1) are the points of diagonals d0 and d1: requested
         // BEFORE the tile's streams, so they are back first
@@ -2337,7 +2342,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         snap0 = y0 - rs0 <= HEAD_MAX; snap1 = y1 - rs1 <= HEAD_MAX;
         c0.x = x0; c0.y = snap0 ? rs0 : y0;
         c1.x = x1; c1.y = snap1 ? rs1 : y1;
-        lean = snap0 && snap1 && (long long) (c1.y - c0.y) <= (long long) lean_avg * (c1.x - c0.x);
+        lean = snap0 && snap1 && (unsigned) (c1.y - c0.y) <= (unsigned) lean_avg * (unsigned) (c1.x - c0.x);
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
@@ -2352,10 +2357,10 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // handed its short piece on by the rule above -- up to this tile
     int first_piece = tile;
     if (!snap0 && x1 > x0) {
-        const long long item = (long long) x0 + rs0;
-        const int ft = (int) (item / TILE);
-        const long long tail_ft = (long long) (ft + 1) * TILE - item;
-        first_piece = ft + (tail_ft <= HEAD_MAX ? 1 : 0);
+        const unsigned item = (unsigned) x0 + (unsigned) rs0;         // (<= rows + nnz < 2^31)
+        const int ft = (int) (item / (unsigned) TILE);
+        const unsigned tail_ft = (unsigned) (ft + 1) * (unsigned) TILE - item;
+        first_piece = ft + (tail_ft <= (unsigned) HEAD_MAX ? 1 : 0);
     }
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
