@@ -2216,7 +2216,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
-    __shared__ int s_bnd[7];
+    __shared__ int s_bnd[6];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
 
     const int tid = threadIdx.x;
@@ -2233,43 +2233,31 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     if (snap_tr && tid == 0) snap_tr[0] = t_entry;
 #endif
     const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
-    // the hints: the tile's two boundaries (x, y) and their row starts.  The large-problem shapes read them THROUGH THE SCALAR
+    // the hints: the tile's two boundaries (x, y), their row starts, and the epoch of the record tags, read THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
-    // same-box A/B in profiles/r03_scalar_hints.txt).  In the small shape nothing was gained (small grids the same, a 20 M-item
-    // matrix that then still took it 3 % slower), so that shape keeps the two-lane vector load + LDS broadcast.  (The hints were written by
-    // vector stores of an earlier launch; the scalar cache is invalidated at every kernel start.)  Request and wait are ONE asm
-    // statement: the compiler never sees destination registers whose load is still in flight, so it cannot copy, spill or
-    // re-assign them under the load (a later, separate s_waitcnt left exactly that open).  What used to sit between the two --
-    // clearing the flag words, requesting a tiny x -- now comes first; the block has nothing else to do until its hints are
-    // there anyway.
-    constexpr bool SCALAR_HINTS = true;
+    // same-box A/B in profiles/r03_scalar_hints.txt), and since round 4 in the small tile shape as well (two lanes' vector
+    // loads + an LDS broadcast until then): 4.1-4.2 -> 3.8-4.0 us per call below 1 M nonzeros, 19.9 -> 18.0 us at 5.8 M, with
+    // the rest of this prologue in 32-bit, branch-free scalar code.  (The hints were written by vector stores of an earlier
+    // launch; the scalar cache is invalidated at every kernel start.)  Request and wait are ONE asm statement: the compiler never
+    // sees destination registers whose load is still in flight, so it cannot copy, spill or re-assign them under the load (a
+    // later, separate s_waitcnt left exactly that open).  What used to sit between the two -- clearing the flag words,
+    // requesting a tiny x -- comes first; the block has nothing else to do until its hints are there anyway.
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
-    // a tiny x goes to LDS: scalar-hint shapes request it now and write it after the streams have been requested
+    // a tiny x goes to LDS: requested now, written after the streams have been requested
     XRegs<V, BLOCK> xr;
     const V *s_x = nullptr;
-    if constexpr (SCALAR_HINTS) {
-        if (p.x_lds > 0) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
-    } else s_x = stage_x_in_lds<V>(p, s_dyn, BLOCK);
+    if (p.x_lds > 0) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
     const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
     int4v hint_c; int2v hint_r;
     unsigned epoch = 0u;                                            // (mixed into the record tags: "NOTHING DEPENDS ON A RECORD ARRIVING")
-    if constexpr (SCALAR_HINTS) {
-        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(hint_c), "=&s"(hint_r), "=&s"(epoch) : "s"(coords + tile), "s"(rstart + tile), "s"(lb.error) : "memory");
-    } else if (tid < 2) {
-        const Coord h = coords[tile + tid]; const int rs = rstart[tile + tid];
-        s_bnd[3 * tid] = h.x; s_bnd[3 * tid + 1] = rs; s_bnd[3 * tid + 2] = h.y;
-    } else if (tid == 2) s_bnd[6] = __hip_atomic_load(lb.error + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (s_flag cleared, the LDS copy of x complete, s_bnd written.  With scalar hints and a tiny x being copied into LDS, every
-    //  wave requests its share of the streams first and the barrier -- which waits for that copy -- comes after the requests:
-    //  dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier is the better place, by 1-2 %)
-    const bool late_barrier = SCALAR_HINTS && s_x != nullptr;       // block-uniform
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(hint_c), "=&s"(hint_r), "=&s"(epoch) : "s"(coords + tile), "s"(rstart + tile), "s"(lb.error) : "memory");
+    // (s_flag cleared.  With a tiny x being copied into LDS, every wave requests its share of the streams first and the barrier --
+    //  which waits for that copy -- comes after the requests: dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier
+    //  is the better place, by 1-2 %)
+    const bool late_barrier = s_x != nullptr;                       // block-uniform
     if (!late_barrier) __syncthreads();
-    if constexpr (!SCALAR_HINTS) {
-        hint_c.x = s_bnd[0]; hint_r.x = s_bnd[1]; hint_c.y = s_bnd[2]; hint_c.z = s_bnd[3]; hint_r.y = s_bnd[4]; hint_c.w = s_bnd[5];
-        epoch = (unsigned) s_bnd[6];
-    }
     const LookBack lbe = with_epoch(lb, epoch);
     MSPMV_SNAP_TR(1);
     const int total = p.rows + p.nnz;                               // < 2^31
@@ -2310,8 +2298,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         MSPMV_SNAP_TR(2);
-        if constexpr (SCALAR_HINTS) { if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); }
-        if (late_barrier) __syncthreads();
+        if (late_barrier) { commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); __syncthreads(); }
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
         MSPMV_SNAP_TR(3);
         // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
@@ -2328,7 +2315,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     }
     if (!good) {
         // no usable hints (the first call on this temp storage, or another matrix since): find the two boundaries, stage (again)
-        if constexpr (SCALAR_HINTS) { if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); }      // (again, or for the first time: same values)
+        if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn);      // (again, or for the first time: same values)
         __syncthreads();
         const int wave = tid / WAVE;
         if (wave < 2) {
