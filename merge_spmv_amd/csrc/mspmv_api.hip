@@ -409,7 +409,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const unsigned grid = (unsigned) L.num_tiles;
         const size_t xl = (size_t) p.x_lds * sizeof(V);
         const int lean_avg = (L.flags & MSPMV_TUNE_NO_LEAN) ? 0 : lean_avg_default();
-#define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, p, coords, rstart, carries, L.num_tiles, chunk_log2, lb, lean_avg)
+#define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, lb.error, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
         if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
         else if (nt) MSPMV_LAUNCH_SNAP(false, true);
         else MSPMV_LAUNCH_SNAP(false, false);

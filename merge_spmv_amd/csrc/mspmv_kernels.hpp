@@ -1089,9 +1089,16 @@ constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one
 constexpr int LEAN_BATCH = 8;          // products of a row requested before any is looked at
 template <typename V, int BLOCK, int IPT, bool AXPBY>
 __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coord c0, int tile_rows, const end16_t *s_end,
-                                                  const V *s_prod_raw, int pshift, Carry<V> *__restrict__ carry_out)
+                                                  const V *s_prod_raw, int pshift, Carry<V> *__restrict__ carry_out,
+                                                  unsigned long long *tr = nullptr)
 {
     const int tid = threadIdx.x;
+#ifdef MSPMV_DEV
+#define MSPMV_LEAN_TR(i) do { if (tr && tid == 0) tr[i] = wall_clock64(); } while (0)
+#else
+#define MSPMV_LEAN_TR(i) do { } while (0)
+#endif
+    MSPMV_LEAN_TR(8);
     if (tid == BLOCK - 1) { Carry<V> c; c.key = c0.x + tile_rows; c.value = (V) 0; *carry_out = c; }     // (nothing open: what mspmv_debug_read_tiles reports)
     V *__restrict__ y = p.y + c0.x;
     // Two rows per thread and iteration (r, r + BLOCK), and every LDS read of a step requested before the first is waited for:
@@ -1108,6 +1115,7 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
             e0[h] = rr > 0 ? s_end[rr - 1] : 0;
             len[h] = valid[h] ? e1 - e0[h] : 0;
         }
+        if (r0 == 0) MSPMV_LEAN_TR(9);
         V v[2][LEAN_BATCH];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -1118,6 +1126,7 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
         for (int j = 0; j < LEAN_BATCH; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[h] = j < len[h] ? acc[h] + v[h][j] : acc[h];
+        if (r0 == 0) MSPMV_LEAN_TR(10);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const V *src = s_prod_raw + (pshift + e0[h]);
@@ -1164,6 +1173,7 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
                     if (lane == owner[g]) acc[h] = total;
                 }
             }
+            if (r0 == 0 && h == 0) MSPMV_LEAN_TR(11);
             if (valid[h]) {
                 const int r = r0 + h * BLOCK + tid;
                 if (AXPBY) y[r] = p.alpha * acc[h] + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
@@ -1171,6 +1181,8 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
             }
         }
     }
+    MSPMV_LEAN_TR(12);
+#undef MSPMV_LEAN_TR
 }
 
 // ---------------------------------------------------------------------------
@@ -1721,6 +1733,17 @@ __device__ __forceinline__ int xcd_chunked_tile(int b, int num_tiles, int chunk_
     return b;
 }
 
+// the same map without a branch (the head of tile_kernel_snap: scalar selects, nothing between the wave's start and its hint request)
+__device__ __forceinline__ int xcd_chunked_tile_flat(int b, int num_tiles, int chunk_log2)
+{
+    const int q8 = num_tiles >> 3, r8 = num_tiles & 7, xcd = b & 7;
+    const int contiguous = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int sh = (chunk_log2 & 15) + 3, cl = chunk_log2 & 15;                     // (& 15: the shifts stay defined when chunk_log2 is the contiguous code)
+    const int q = b >> sh, r = b & ((1 << sh) - 1);
+    const int chunked = b < ((num_tiles >> sh) << sh) ? (((q << 3) | (r & 7)) << cl) + (r >> 3) : b;
+    return chunk_log2 == TILE_MAP_CONTIGUOUS ? contiguous : chunk_log2 > 0 ? chunked : b;
+}
+
 // What the tile kernel needs to know about them (BAND variants of tile_kernel_vec; verdict == nullptr otherwise)
 struct BandArgs {
     const int *verdict;        // BAND_WINDOWS verdicts of band_detect_block
@@ -2201,9 +2224,9 @@ constexpr int snap_head_max()
 }
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Params<V> p, Coord *__restrict__ coords,
-                                                           int *__restrict__ rstart, Carry<V> *__restrict__ carries, int num_tiles,
-                                                           int xcd_chunk_log2, LookBack lb, int lean_avg)
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Coord *__restrict__ coords, int *__restrict__ rstart,
+                                                           const int *__restrict__ epoch_words, int num_tiles, int xcd_chunk_log2,
+                                                           Params<V> p, Carry<V> *__restrict__ carries, LookBack lb, int lean_avg)
 {
     constexpr int TILE = BLOCK * IPT;
     constexpr int NW = BLOCK / WAVE;
@@ -2223,7 +2246,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
 #ifdef MSPMV_DEV
     // development (tools/trace_snap.py): 100 MHz wall-clock stamps of this block's phases, 8 words per block
     const unsigned long long t_entry = wall_clock64();           // (before the load of the trace pointer: that is a memory round trip)
-    unsigned long long *const snap_tr = g_mspmv_trace ? g_mspmv_trace + (size_t) blockIdx.x * 8 : nullptr;
+    unsigned long long *const snap_tr = g_mspmv_trace ? g_mspmv_trace + (size_t) blockIdx.x * 16 : nullptr;     // (8 words of the block + 8 of the lean reduction)
 #define MSPMV_SNAP_TR(i) do { if (snap_tr && tid == 0) snap_tr[i] = wall_clock64(); } while (0)
     if (snap_tr && tid == 0) { snap_tr[6] = __builtin_amdgcn_s_getreg(63492); snap_tr[7] = __builtin_amdgcn_s_getreg(6164); }
 #else
@@ -2232,7 +2255,11 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
 #ifdef MSPMV_DEV
     if (snap_tr && tid == 0) snap_tr[0] = t_entry;
 #endif
-    const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
+    // THE FIRST FIVE ARGUMENTS -- all the hint request needs -- are in SGPRs when the wave starts (kernel-argument preload, 8 dwords:
+    // the Makefile's -amdgpu-kernarg-preload-count=8), the tile index below is branch-free scalar arithmetic on them, and the other
+    // arguments are pinned behind the hint request: the block's first memory round trip is the hints AND the rest of the kernel
+    // arguments together, where the arguments (in three batches, as the compiler sank them to their uses) came first.
+    const int tile = xcd_chunked_tile_flat((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     // the hints: the tile's two boundaries (x, y), their row starts, and the epoch of the record tags, read THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
@@ -2243,16 +2270,19 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // sees destination registers whose load is still in flight, so it cannot copy, spill or re-assign them under the load (a
     // later, separate s_waitcnt left exactly that open).  What used to sit between the two -- clearing the flag words,
     // requesting a tiny x -- comes first; the block has nothing else to do until its hints are there anyway.
+    const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
+    int4v hint_c; int2v hint_r;
+    unsigned epoch = 0u;                                            // (mixed into the record tags: "NOTHING DEPENDS ON A RECORD ARRIVING")
+    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(hint_c), "=&s"(hint_r), "=&s"(epoch) : "s"(coords + tile), "s"(rstart + tile), "s"(epoch_words) : "memory");
+    // (uses in this very basic block: the loads of these arguments stay up here, requested before the wait above)
+    asm volatile("" :: "s"(p.row_end), "s"(p.cols), "s"(p.values), "s"(p.x), "s"(p.y), "s"(p.rows), "s"(p.nnz), "s"(p.x_lds), "s"(lean_avg),
+                 "s"(carries), "s"(lb.rec), "s"(lb.tag_a), "s"(lb.tag_b), "s"(lb.error), "s"(lb.call_tag), "s"(lb.max_polls), "s"(p.band_pass));
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     // a tiny x goes to LDS: requested now, written after the streams have been requested
     XRegs<V, BLOCK> xr;
     const V *s_x = nullptr;
     if (p.x_lds > 0) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
-    const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
-    int4v hint_c; int2v hint_r;
-    unsigned epoch = 0u;                                            // (mixed into the record tags: "NOTHING DEPENDS ON A RECORD ARRIVING")
-    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(hint_c), "=&s"(hint_r), "=&s"(epoch) : "s"(coords + tile), "s"(rstart + tile), "s"(lb.error) : "memory");
     // (s_flag cleared.  With a tiny x being copied into LDS, every wave requests its share of the streams first and the barrier --
     //  which waits for that copy -- comes after the requests: dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier
     //  is the better place, by 1-2 %)
@@ -2351,7 +2381,11 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     }
     const int pshift = c0.y - (c0.y & ~3);
     const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
+    #ifdef MSPMV_DEV
+    if (lean) consume_tile_rows<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, s_end_raw + eshift, s_prod_raw, pshift, carries + tile, snap_tr);
+#else
     if (lean) consume_tile_rows<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, s_end_raw + eshift, s_prod_raw, pshift, carries + tile);
+#endif
     else consume_tile_flags<V, BLOCK, IPT, AXPBY, 4>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
                                                      s_wave_key, s_wave_val, carries + tile, pshift, nullptr, &lbe, tile, !snap1, first_piece, -1, rs0);
     MSPMV_SNAP_TR(4);

@@ -17,7 +17,7 @@ for label, A, x in sweep.workloads(sys.argv[1:] or ["dense5d"]):
     M.set_tuning(vb, 0, 0, flags)
     info = M.launch_info(A.rows, A.nnz, vb)
     nblk = info["num_tiles"]
-    buf = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nblk * 16, dtype=torch.int64, device="cuda")
     ws = M.CsrMVWorkspace(A.rows, A.nnz, A.values.dtype)
     y = torch.empty(A.rows, dtype=A.values.dtype, device="cuda")
     call = lambda: M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=A.cols, workspace=ws)
@@ -26,7 +26,8 @@ for label, A, x in sweep.workloads(sys.argv[1:] or ["dense5d"]):
     assert lib.mspmv_dev_set_trace(ctypes.c_void_p(buf.data_ptr())) == 0
     call(); torch.cuda.synchronize()
     assert lib.mspmv_dev_set_trace(None) == 0
-    t = buf.cpu().numpy().reshape(nblk, 8)
+    t = buf.cpu().numpy().reshape(nblk, 16)
+    lean_us = t[:, 8:13].astype(np.float64) / 100.0
     us = t[:, :6].astype(np.float64) / 100.0
     t0 = us[:, 0].min()
     span = us[:, 5].max() - t0
@@ -40,6 +41,11 @@ for label, A, x in sweep.workloads(sys.argv[1:] or ["dense5d"]):
     print(f"  boundaries, stream loads issued       : {d(1,2):6.2f}")
     print(f"  staging (loads awaited, x, LDS, barrier): {d(2,3):6.2f}")
     print(f"  in-tile reduction + y stores issued   : {d(3,4):6.2f}")
+    ln = lean_us[:, 0] > 0
+    if ln.any():
+        e = lambda a, b: float(np.mean(lean_us[ln, b] - lean_us[ln, a]))
+        print(f"    lean reduction ({int(ln.sum())} blocks): staging barrier -> its start {float(np.mean(lean_us[ln, 0] - us[ln, 3])):5.2f}, row ends read {e(0,1):5.2f}, "
+              f"products read + first {8} added {e(1,2):5.2f}, longer rows {e(2,3):5.2f}, y stores issued {e(3,4):5.2f}")
     print(f"  stores acknowledged                   : {d(4,5):6.2f}")
     print(f"  block life                            : {life.mean():6.2f}  (p10 {np.percentile(life,10):.2f}, p50 {np.percentile(life,50):.2f}, p90 {np.percentile(life,90):.2f})")
     print(f"  blocks alive per CU (sum of lives / span / CUs): {life.sum() / span / ncu:5.2f}")
