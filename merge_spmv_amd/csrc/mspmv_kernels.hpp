@@ -1114,7 +1114,8 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
             valid[h] = r < tile_rows;
             const int rr = valid[h] ? r : 0;                       // (row 0 exists: tile_rows > 0 here)
             const int e1 = s_end[rr];
-            e0[h] = rr > 0 ? s_end[rr - 1] : 0;
+            const int ep = s_end[rr > 0 ? rr - 1 : 0];             // (read whatever rr is: a select afterwards, not a branch around a second LDS round trip)
+            e0[h] = rr > 0 ? ep : 0;
             len[h] = valid[h] ? e1 - e0[h] : 0;
         }
         if (r0 == 0) MSPMV_LEAN_TR(9);
@@ -1123,6 +1124,11 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < LEAN_BATCH; ++j) v[h][j] = s_prod_raw[pshift + e0[h] + j];
+        // (all of them requested here, in one go: without this the compiler sinks a read into the branch of the first addition that uses it)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < LEAN_BATCH; ++j) asm volatile("" : "+v"(v[h][j]));
         V acc[2] = {(V) 0, (V) 0};
 #pragma unroll
         for (int j = 0; j < LEAN_BATCH; ++j)
@@ -2340,11 +2346,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
         // memory latency; a barrier is cheap)
         {
-            const int before0 = __shfl(vre, 0, WAVE), at0 = __shfl(vre, 1, WAVE), before1 = __shfl(vre, 2, WAVE), at1 = __shfl(vre, 3, WAVE);
+            // (v_readlane: the four words and everything derived from them are scalars -- a shuffle goes through LDS and leaves vectors)
+            const int before0 = __builtin_amdgcn_readlane(vre, 0), at0 = __builtin_amdgcn_readlane(vre, 1), before1 = __builtin_amdgcn_readlane(vre, 2), at1 = __builtin_amdgcn_readlane(vre, 3);
             // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
-            const bool ok0 = (x0 > 0 ? before0 == rs0 : rs0 == 0) && (x0 < p.rows ? y0 <= at0 : d0 == total);
-            const bool ok1 = (x1 > 0 ? before1 == rs1 : rs1 == 0) && (x1 < p.rows ? y1 <= at1 : d1 == total);
-            good = single || (ok0 && ok1);
+            const bool ok0 = (x0 > 0 ? before0 == rs0 : rs0 == 0) & (x0 < p.rows ? y0 <= at0 : d0 == total);
+            const bool ok1 = (x1 > 0 ? before1 == rs1 : rs1 == 0) & (x1 < p.rows ? y1 <= at1 : d1 == total);
+            good = single | (ok0 & ok1);
         }
         // (a failed check: every wave is past the staging barrier, and the search below starts with a barrier of its own)
         if (!good && tid < SLOTS / 32 + 1) s_flag[tid] = 0u;       // (the staging above touched nothing but LDS)
