@@ -1085,6 +1085,10 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
 //   * which reduction a tile takes depends only on its boundaries (closed, nonzeros <= lean_avg * rows), i.e. on the
 //     matrix and the tile shape -- never on hints, timing or the device.
 // ---------------------------------------------------------------------------
+// which tile shapes take the branch likelihoods below: the small ones (what a small problem runs on).  In the fp64 256x11 kernel the
+// same hints changed nothing on a full device (dense5, the grids, dense32, circuit, Orkut-sized within +-0.5 %), in the fp32 one
+// they cost spills.
+template <typename V, int IPT> constexpr bool layout_hints() { return IPT <= 7; }
 #define MSPMV_LIKELY(on, c) ((on) ? __builtin_expect(!!(c), 1) : !!(c))            // (on: a constant -- which tile shapes take the hint)
 #define MSPMV_UNLIKELY(on, c) ((on) ? __builtin_expect(!!(c), 0) : !!(c))
 constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one thread
@@ -1139,7 +1143,7 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
         for (int h = 0; h < 2; ++h) {
             const V *src = s_prod_raw + (pshift + e0[h]);
             // rows of LEAN_BATCH + 1 ... LEAN_SERIAL nonzeros: the same left-to-right order, continued
-            if (MSPMV_UNLIKELY(IPT <= 7, __ballot(len[h] > LEAN_BATCH) != 0ull)) {
+            if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), __ballot(len[h] > LEAN_BATCH) != 0ull)) {
                 V w[LEAN_SERIAL - LEAN_BATCH];
 #pragma unroll
                 for (int j = 0; j < LEAN_SERIAL - LEAN_BATCH; ++j) w[j] = src[LEAN_BATCH + j];
@@ -1149,7 +1153,7 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
             // rows longer than that: four at a time, each by the 16 lanes of one DPP row -- lane j adds products j, j + 16, ... from
             // +0.0, the 16 partial sums are folded left to right (row_shr 1, 2, 4, 8) -- and the total replaces what the owner has
             unsigned long long pending = __ballot(len[h] > LEAN_SERIAL);
-            while (MSPMV_UNLIKELY(IPT <= 7, pending != 0ull)) {       // wave-uniform
+            while (MSPMV_UNLIKELY((layout_hints<V, IPT>()), pending != 0ull)) {       // wave-uniform
                 int owner[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1668,15 +1672,15 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
     if constexpr (BAND) {              // (a banded pass is for an x beyond L2: never the LDS copy)
         if (interior) stage_tile_interior<V, BLOCK, IPT, NT, FL, false, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, tid_in);
         else stage_tile_careful<V, BLOCK, IPT, NT, FL, false, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, tid_in);
-    } else if (MSPMV_LIKELY(IPT <= 7, s_x == nullptr)) {
+    } else if (MSPMV_LIKELY((layout_hints<V, IPT>()), s_x == nullptr)) {
         // (the likelihoods order the code of the SMALL tile shapes: x in memory, interior tile, usable hints, lean reduction first and in
         //  one piece -- a block that runs alone, i.e. a small problem, waits for every stretch of instructions it jumps to:
         //  instruction-cache misses per 28-tile launch 169 -> 87, wave-cycles -21 %, profiles/r04_small_call_counters.txt; a full
         //  device has them all in its caches, and the large fp32 shape sits at its register limit: the hints cost it spills)
-        if (MSPMV_LIKELY(IPT <= 7, interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, -1, lean);
+        if (MSPMV_LIKELY((layout_hints<V, IPT>()), interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, -1, lean);
         else stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, -1, lean);
     } else {                                  // block-uniform: x lives in LDS (tiny x only)
-        if (MSPMV_LIKELY(IPT <= 7, interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x, -1, lean);
+        if (MSPMV_LIKELY((layout_hints<V, IPT>()), interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x, -1, lean);
         else stage_tile_careful<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
     }
 }
@@ -2294,7 +2298,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // a tiny x goes to LDS: requested now, written after the streams have been requested
     XRegs<V, BLOCK> xr;
     const V *s_x = nullptr;
-    if (MSPMV_UNLIKELY(IPT <= 7, p.x_lds > 0)) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
+    if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), p.x_lds > 0)) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
     // (s_flag cleared.  With a tiny x being copied into LDS, every wave requests its share of the streams first and the barrier --
     //  which waits for that copy -- comes after the requests: dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier
     //  is the better place, by 1-2 %)
@@ -2325,7 +2329,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     bool good = ((unsigned) x0 <= (unsigned) x1) & ((unsigned) x1 <= (unsigned) p.rows) & ((unsigned) y0 <= (unsigned) y1) &
                 ((unsigned) y1 <= (unsigned) p.nnz) & ((unsigned) rs0 <= (unsigned) y0) & ((unsigned) rs0 <= (unsigned) rs1) &
                 ((unsigned) rs1 <= (unsigned) y1) & (c1.y >= c0.y);
-    if (MSPMV_LIKELY(IPT <= 7, good)) {
+    if (MSPMV_LIKELY((layout_hints<V, IPT>()), good)) {
         // the four row offsets that decide whether (x0, rs0) and (x1, rs1) are the points of diagonals d0 and d1: requested
         // BEFORE the tile's streams, so they are back first
         // (by four lanes of EVERY wave: each wave then decides for itself -- all from the same four words, so all alike --
@@ -2340,7 +2344,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         TileRegs<V, BLOCK, IPT> regs;
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         MSPMV_SNAP_TR(2);
-        if (MSPMV_UNLIKELY(IPT <= 7, late_barrier)) { commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); __syncthreads(); }
+        if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), late_barrier)) { commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); __syncthreads(); }
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
         MSPMV_SNAP_TR(3);
         // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
@@ -2356,7 +2360,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         // (a failed check: every wave is past the staging barrier, and the search below starts with a barrier of its own)
         if (!good && tid < SLOTS / 32 + 1) s_flag[tid] = 0u;       // (the staging above touched nothing but LDS)
     }
-    if (MSPMV_UNLIKELY(IPT <= 7, !good)) {
+    if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), !good)) {
         // no usable hints (the first call on this temp storage, or another matrix since): find the two boundaries, stage (again)
         if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn);      // (again, or for the first time: same values)
         __syncthreads();
@@ -2401,7 +2405,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
 #define MSPMV_SNAP_END() do { } while (0)
     unsigned long long *const lean_tr = nullptr;
 #endif
-    if (MSPMV_LIKELY(IPT <= 7, lean)) {
+    if (MSPMV_LIKELY((layout_hints<V, IPT>()), lean)) {
         consume_tile_rows<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, s_end_raw + eshift, s_prod_raw, pshift, carries + tile, lean_tr);
         MSPMV_SNAP_END();
         return;                                                     // (the program ends HERE, not after a jump over the general reduction)
