@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
 // same hints changed nothing on a full device (dense5, the grids, dense32, circuit, Orkut-sized within +-0.5 %), in the fp32 one
 // they cost spills.
 template <typename V, int IPT> constexpr bool layout_hints() { return IPT <= 7; }
-#define MSPMV_LIKELY(on, c) ((on) ? __builtin_expect(!!(c), 1) : !!(c))            // (on: a constant -- which tile shapes take the hint)
+#define MSPMV_LIKELY(on, c) ((on) ? __builtin_expect(!!(c), 1) : !!(c))      // (on: a constant -- which tile shapes take the hint)
 #define MSPMV_UNLIKELY(on, c) ((on) ? __builtin_expect(!!(c), 0) : !!(c))
 constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one thread
 constexpr int LEAN_BATCH = 8;          // products of a row requested before any is looked at
@@ -1394,11 +1394,14 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
 // and x gathers are issued, tile-relative row ends and products land in LDS (every slot of
 // both arrays is written: +inf / 0 outside the tile), the ragged array tails are patched,
 // and the block is synchronised.
-template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false>
+// (after_gather: called once the x gathers have been requested -- scalar work of the caller that then runs in the shadow of their
+//  latency instead of after the staging barrier: the hint verdict of tile_kernel_snap)
+struct NoAfterGather { __device__ __forceinline__ void operator()() const {} };
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false, typename AG = NoAfterGather>
 __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coord c0, const Coord c1,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw, V *s_prod_raw,
                                            int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1,
-                                           bool lean = false)
+                                           bool lean = false, AG after_gather = AG())
 {
     // lean (block-uniform; FL only): the tile will be reduced row by row (consume_tile_rows) -- no row-start bits, products at their raw positions
     constexpr int CPT = IPT / 4 + 1;
@@ -1456,6 +1459,7 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
             if ((in_band >> (4 * k)) & 0xfu) bval[k] = ld_stream4<NT>(p.values + e0);     // (a bit set => a chunk of this tile, <= last_full_nz)
         }
     }
+    after_gather();
     // ---- stage row ends
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -1545,11 +1549,11 @@ __device__ __forceinline__ void stage_tile_careful(const Params<V> &p, const Coo
 //    least IPT path items past every thread of a full tile.
 // Only whole chunks beyond the needed range are redirected to a cached address (no HBM bytes
 // for data the tile does not use).  This removes ~200 of the ~1100 instructions per wave per tile.
-template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool XL = false, bool BAND = false, typename AG = NoAfterGather>
 __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Coord c0, const Coord c1,
                                                     const TileRegs<V, BLOCK, IPT> &regs,
                                                     typename EndType<FL>::type *s_end_raw, V *s_prod_raw, unsigned *s_flag,
-                                                    const V *s_x = nullptr, int tid_in = -1, bool lean = false)
+                                                    const V *s_x = nullptr, int tid_in = -1, bool lean = false, AG after_gather = AG())
 {
     constexpr int CPT = IPT / 4 + 1;
     const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
@@ -1602,6 +1606,7 @@ __device__ __forceinline__ void stage_tile_interior(const Params<V> &p, const Co
             }
         }
     }
+    after_gather();
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int q = tid + k * BLOCK;
@@ -1662,11 +1667,11 @@ __device__ __forceinline__ bool tile_is_interior(const Coord c0, const Coord c1,
     return tile != num_tiles - 1 && c1.y <= last_full_nz + 4 && i0 + 4 * ro_chunks <= last_full_ro + 4;
 }
 
-template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool BAND = false>
+template <typename V, int BLOCK, int IPT, bool NT, bool FL, bool BAND = false, typename AG = NoAfterGather>
 __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, const Coord c1, int tile, int num_tiles,
                                            const TileRegs<V, BLOCK, IPT> &regs, typename EndType<FL>::type *s_end_raw,
                                            V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag, const V *s_x = nullptr, int tid_in = -1,
-                                           bool lean = false)
+                                           bool lean = false, AG after_gather = AG())
 {
     const bool interior = tile_is_interior<IPT>(c0, c1, tile, num_tiles, last_full_nz, last_full_ro);      // block-uniform
     if constexpr (BAND) {              // (a banded pass is for an x beyond L2: never the LDS copy)
@@ -1677,11 +1682,11 @@ __device__ __forceinline__ void stage_tile(const Params<V> &p, const Coord c0, c
         //  one piece -- a block that runs alone, i.e. a small problem, waits for every stretch of instructions it jumps to:
         //  instruction-cache misses per 28-tile launch 169 -> 87, wave-cycles -21 %, profiles/r04_small_call_counters.txt; a full
         //  device has them all in its caches, and the large fp32 shape sits at its register limit: the hints cost it spills)
-        if (MSPMV_LIKELY((layout_hints<V, IPT>()), interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, -1, lean);
-        else stage_tile_careful<V, BLOCK, IPT, NT, FL>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, -1, lean);
+        if (MSPMV_LIKELY((layout_hints<V, IPT>()), interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL, false, false, AG>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, nullptr, -1, lean, after_gather);
+        else stage_tile_careful<V, BLOCK, IPT, NT, FL, false, false, AG>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, nullptr, -1, lean, after_gather);
     } else {                                  // block-uniform: x lives in LDS (tiny x only)
-        if (MSPMV_LIKELY((layout_hints<V, IPT>()), interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x, -1, lean);
-        else stage_tile_careful<V, BLOCK, IPT, NT, FL, true>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
+        if (MSPMV_LIKELY((layout_hints<V, IPT>()), interior)) stage_tile_interior<V, BLOCK, IPT, NT, FL, true, false, AG>(p, c0, c1, regs, s_end_raw, s_prod_raw, s_flag, s_x, -1, lean, after_gather);
+        else stage_tile_careful<V, BLOCK, IPT, NT, FL, true, false, AG>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean, after_gather);
     }
 }
 
@@ -2329,6 +2334,13 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     bool good = ((unsigned) x0 <= (unsigned) x1) & ((unsigned) x1 <= (unsigned) p.rows) & ((unsigned) y0 <= (unsigned) y1) &
                 ((unsigned) y1 <= (unsigned) p.nnz) & ((unsigned) rs0 <= (unsigned) y0) & ((unsigned) rs0 <= (unsigned) rs1) &
                 ((unsigned) rs1 <= (unsigned) y1) & (c1.y >= c0.y);
+    // the hints of the next call on this temp storage (and what mspmv_debug_read_tiles returns): stored when they were not there
+    auto store_hints = [&](bool found_here) {
+        if (tid == 0) {
+            if (found_here || single || hint_y0 != y0) { Coord h; h.x = x0; h.y = y0; coords[tile] = h; rstart[tile] = rs0; }
+            if (tile == num_tiles - 1 && (found_here || single || hint_y1 != y1)) { Coord h; h.x = x1; h.y = y1; coords[num_tiles] = h; rstart[num_tiles] = rs1; }
+        }
+    };
     if (MSPMV_LIKELY((layout_hints<V, IPT>()), good)) {
         // the four row offsets that decide whether (x0, rs0) and (x1, rs1) are the points of diagonals d0 and d1: requested
         // BEFORE the tile's streams, so they are back first
@@ -2345,18 +2357,21 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         MSPMV_SNAP_TR(2);
         if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), late_barrier)) { commit_x_to_lds<V, BLOCK>(p, xr, s_dyn); __syncthreads(); }
-        stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
-        MSPMV_SNAP_TR(3);
-        // (looked at only now: a wave that waited for them before staging would hold its share of the streams back by a
-        // memory latency; a barrier is cheap)
-        {
-            // (v_readlane: the four words and everything derived from them are scalars -- a shuffle goes through LDS and leaves vectors)
+        // The verdict on the hints: looked at once the tile's x gathers have been requested -- the four words came back before the
+        // streams did, and the scalar arithmetic on them runs in the shadow of the gathers (after the staging barrier it was ~100
+        // instructions of a lone wave's critical path; before the staging it would hold the wave's share of the streams back).
+        // (v_readlane: the four words and everything derived from them are scalars -- a shuffle goes through LDS and leaves vectors)
+        bool verdict = true;
+        auto check_hints = [&]() {
             const int before0 = __builtin_amdgcn_readlane(vre, 0), at0 = __builtin_amdgcn_readlane(vre, 1), before1 = __builtin_amdgcn_readlane(vre, 2), at1 = __builtin_amdgcn_readlane(vre, 3);
             // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
             const bool ok0 = (x0 > 0 ? before0 == rs0 : rs0 == 0) & (x0 < p.rows ? y0 <= at0 : d0 == total);
             const bool ok1 = (x1 > 0 ? before1 == rs1 : rs1 == 0) & (x1 < p.rows ? y1 <= at1 : d1 == total);
-            good = single | (ok0 & ok1);
-        }
+            verdict = single | (ok0 & ok1);
+        };
+        stage_tile<V, BLOCK, IPT, NT, true, false, decltype(check_hints)>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean, check_hints);
+        MSPMV_SNAP_TR(3);
+        good = verdict;
         // (a failed check: every wave is past the staging barrier, and the search below starts with a barrier of its own)
         if (!good && tid < SLOTS / 32 + 1) s_flag[tid] = 0u;       // (the staging above touched nothing but LDS)
     }
@@ -2381,11 +2396,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs);
         stage_tile<V, BLOCK, IPT, NT, true>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean);
     }
-    if (tid == 0) {
-        // the hints of the next call on this temp storage (and what mspmv_debug_read_tiles returns): stored when they were not there
-        if (!good || single || hint_y0 != y0) { Coord h; h.x = x0; h.y = y0; coords[tile] = h; rstart[tile] = rs0; }
-        if (tile == num_tiles - 1 && (!good || single || hint_y1 != y1)) { Coord h; h.x = x1; h.y = y1; coords[num_tiles] = h; rstart[num_tiles] = rs1; }
-    }
+    store_hints(!good);
     // the tiles that hold published pieces of this tile's first row (only when the row ends here and began > HEAD_MAX
     // nonzeros before the tile): from the tile of its first nonzero (path item x0 + rs0) -- or the one after, if that one
     // handed its short piece on by the rule above -- up to this tile
