@@ -2246,7 +2246,7 @@ constexpr int snap_head_max()
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
 __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Coord *__restrict__ coords, int *__restrict__ rstart,
-                                                           const int *__restrict__ epoch_words, int num_tiles, int xcd_chunk_log2,
+                                                           const int *epoch_words, int num_tiles, int xcd_chunk_log2,
                                                            Params<V> p, Carry<V> *__restrict__ carries, LookBack lb, int lean_avg)
 {
     constexpr int TILE = BLOCK * IPT;
@@ -2276,6 +2276,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
 #ifdef MSPMV_DEV
     if (snap_tr && tid == 0) snap_tr[0] = t_entry;
 #endif
+    // (epoch_words == lb.error, the same two words under a second name -- hence no __restrict__ on it)
     // THE FIRST FIVE ARGUMENTS -- all the hint request needs -- are in SGPRs when the wave starts (kernel-argument preload, 8 dwords:
     // the Makefile's -amdgpu-kernarg-preload-count=8), the tile index below is branch-free scalar arithmetic on them, and the other
     // arguments are pinned behind the hint request: the block's first memory round trip is the hints AND the rest of the kernel
