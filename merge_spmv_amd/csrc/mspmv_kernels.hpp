@@ -1133,6 +1133,8 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < LEAN_BATCH; ++j) asm volatile("" : "+v"(v[h][j]));
+        // (what lies beyond the row becomes +0.0 first -- independent selects -- and is then added like the rest: the running sum is
+        //  never -0.0 (it starts from +0.0), so adding +0.0 leaves every bit of it, and the dependent chain is the additions alone)
         V acc[2] = {(V) 0, (V) 0};
 #pragma unroll
         for (int j = 0; j < LEAN_BATCH; ++j)
@@ -2300,16 +2302,16 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // (uses in this very basic block: the loads of these arguments stay up here, requested before the wait above)
     asm volatile("" :: "s"(p.row_end), "s"(p.cols), "s"(p.values), "s"(p.x), "s"(p.y), "s"(p.rows), "s"(p.nnz), "s"(p.x_lds), "s"(lean_avg),
                  "s"(carries), "s"(lb.rec), "s"(lb.tag_a), "s"(lb.tag_b), "s"(lb.error), "s"(lb.call_tag), "s"(lb.max_polls), "s"(p.band_pass));
-    if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
+    if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;                     // (the row-start bits)
     // a tiny x goes to LDS: requested now, written after the streams have been requested
     XRegs<V, BLOCK> xr;
     const V *s_x = nullptr;
     if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), p.x_lds > 0)) { request_x_for_lds<V, BLOCK>(p, xr); s_x = reinterpret_cast<const V *>(s_dyn); }
-    // (s_flag cleared.  With a tiny x being copied into LDS, every wave requests its share of the streams first and the barrier --
-    //  which waits for that copy -- comes after the requests: dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier
-    //  is the better place, by 1-2 %)
+    // (With a tiny x being copied into LDS, every wave requests its share of the streams first and the barrier -- which waits for
+    //  that copy -- comes after the requests: dense32 fp32 -3 %, fp64 -6.5 %; without the copy the early barrier is the better
+    //  place, by 1-2 %)
     const bool late_barrier = s_x != nullptr;                       // block-uniform
-    if (!late_barrier) __syncthreads();
+    if constexpr (!layout_hints<V, IPT>()) { if (!late_barrier) __syncthreads(); }      // (the large shapes: see below)
     const LookBack lbe = with_epoch(lb, epoch);
     MSPMV_SNAP_TR(1);
     const int total = p.rows + p.nnz;                               // < 2^31
@@ -2328,6 +2330,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // (unsigned: with garbage hints the product may wrap -- harmless, `lean` is only used once the hints have passed `good`,
     //  and then a tile has at most TILE rows)
     bool lean = snap0 && snap1 && (unsigned) (c1.y - c0.y) <= (unsigned) lean_avg * (unsigned) (c1.x - c0.x);
+    // the clearing of the row-start bits is fenced from the staging's ORs by a barrier only in a tile that will use them -- a lean
+    // tile neither sets nor reads them, and spares its waves the meeting (3.5-3.7 -> 3.4-3.6 us per small call).  As early as `lean`
+    // is known (whatever the hints are worth: hints that fail the checks below send the block through the search, which clears
+    // and fences for itself).  In the small shapes only: in the large one the circuit-shaped matrix, a mix of lean and other tiles,
+    // was 1 % slower in every variant tried and dense5 / the grids as much faster (same-box A/B, profiles/r04_small_call_lean_barrier.txt)
+    if constexpr (layout_hints<V, IPT>()) { if (!lean && !late_barrier) __syncthreads(); }
     // hints: anything may be in there.  Only values that keep every speculative access inside the arrays and the LDS tile
     // are tried at all (block-uniform)
     // 0 <= x0 <= x1 <= rows, 0 <= y0 <= y1 <= nnz, 0 <= rs0 <= y0, rs0 <= rs1 <= y1, as unsigned comparisons without branches (each
@@ -2373,11 +2381,12 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
         stage_tile<V, BLOCK, IPT, NT, true, false, decltype(check_hints)>(p, c0, c1, tile, num_tiles, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_x, -1, lean, check_hints);
         MSPMV_SNAP_TR(3);
         good = verdict;
-        // (a failed check: every wave is past the staging barrier, and the search below starts with a barrier of its own)
-        if (!good && tid < SLOTS / 32 + 1) s_flag[tid] = 0u;       // (the staging above touched nothing but LDS)
     }
     if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), !good)) {
         // no usable hints (the first call on this temp storage, or another matrix since): find the two boundaries, stage (again)
+        // (after a failed check every wave is past the staging barrier, which touched nothing but LDS; the bits are cleared whatever
+        //  was done to them, and the barrier below comes before the new staging)
+        if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
         if (late_barrier) commit_x_to_lds<V, BLOCK>(p, xr, s_dyn);      // (again, or for the first time: same values)
         __syncthreads();
         const int wave = tid / WAVE;
