@@ -121,7 +121,8 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
     constexpr int classic = MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX;
     L.snap = L.num_tiles >= 1 && !(L.flags & (classic | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | DEV_FLAG_MASK));
     // published carries of rows longer than the snap limit (16 bytes per tile)
-    L.pub_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * 16);
+    // (one record per tile + one per group of LB_GROUP tiles: kernels, "GROUP RECORDS")
+    L.pub_off = off; off = align256(off + (uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) + uint64_t(L.num_tiles) / LB_GROUP + 1) * 16);
     // column-band passes: the window verdicts and 8 claim counters (always laid out: a buffer sized under one tuning stays
     // large enough under MSPMV_TUNE_NO_FUSED), and one int per tile of the large-problem shape (the chain of tiles each block ran)
     L.band_off = off; off = align256(off + uint64_t(BAND_WINDOWS + 8 * BAND_COUNTER_STRIDE) * sizeof(int));
@@ -397,6 +398,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const unsigned long long tag = next_call_tag();
         LookBack lb; lb.rec = reinterpret_cast<unsigned long long *>(base + L.pub_off);
         lb.tag_a = (unsigned) (tag >> 32) | 1u; lb.tag_b = (unsigned) tag; lb.error = reinterpret_cast<int *>(base + L.err_off);
+        lb.group_base = L.num_tiles;
         lb.call_tag = lb.tag_a; lb.max_polls = ex.tune.record_polls > 0 ? ex.tune.record_polls : ex.tune.record_polls < 0 ? 0 : REC_MAX_POLLS;
         static std::atomic<int> snap_cache[64];
         const int chunk_flag = (L.flags >> 24) & 0xf;

@@ -752,7 +752,19 @@ struct LookBack {
                                   // sum itself (a diagnostic: debug_sync reports it), [1] is the epoch mixed into the tags
     unsigned call_tag;            // what the host compares word [0] with
     int max_polls;                // how often a consumer looks for a record before it computes the sum itself (REC_MAX_POLLS; tests: 1, or 0 = never looks)
+    int group_base;               // record index of the first GROUP record (= the launch's number of tiles): see LB_GROUP
 };
+// GROUP RECORDS: a row spanning thousands of tiles (BASELINE config 4: one row of 67 M nonzeros = 23 800 tiles) left its last tile
+// 23 800 records to take -- 24 rounds of memory latency by ONE block, 50 us at the end of a 130 us launch while the chip idles.
+// So every LB_GROUP-th piece of a long row is a group LEADER: a tile without a row end, tile % LB_GROUP == LB_GROUP - 1, whose row
+// began at or before the group's first tile.  The leader takes its LB_GROUP - 1 predecessors' records (one wave, one round), adds its
+// own partial sum and publishes the total as group record tile / LB_GROUP -- instead of a record of its own.  The tile in which
+// the row ends derives the same set of leaders from the same two numbers (the row's first piece, its own index) and takes the
+// group records of the complete groups plus the single records before the first and after the last of them: at most
+// 2 * (LB_GROUP - 1) + pieces / LB_GROUP records.  Every record still has exactly one taker, which clears it; the order of the
+// additions is fixed by the tile indices alone; and nothing depends on a record arriving -- a leader whose poll runs out
+// computes its group's sum from the matrix, like any consumer.
+constexpr int LB_GROUP = 64;
 // the tags of this launch: the call's tag and the epoch word as the block found it
 __device__ __forceinline__ LookBack with_epoch(LookBack lb, unsigned epoch)
 {
@@ -802,9 +814,9 @@ __device__ __forceinline__ V lb_take_wave(const LookBack &lb, int tile, int coun
 // The same for a long list (a row spanning more than 64 tiles), by the whole block: thread j takes tiles tile-1-j,
 // tile-1-j-BLOCK, ... in that order; wave butterflies; the wave partials in wave order.  Block-uniform call (it has a
 // barrier); the result is valid on thread 0.
-template <typename V, int BLOCK, int U>
-__device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int count, V *s_wave_val, bool &ok)
-{
+template <typename V, int BLOCK, int U, typename SlotOf>
+__device__ __forceinline__ V lb_take_block(const LookBack &lb, int count, V *s_wave_val, bool &ok, SlotOf slot_of)
+{   // (slot_of(i): the record index of the i-th of the `count` records to take)
     // U records per thread and round are requested before any is looked at (a round costs one memory latency whatever its
     // width: with U = 4 a row spanning 37 000 tiles is 37 rounds); one that is not there yet -- only ever among the nearest
     // tiles -- is then polled for.  The order of the additions is fixed by (thread, round, slot).  (U is what the register
@@ -817,7 +829,7 @@ __device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int cou
             const int i = i0 + u * BLOCK;
             w0[u] = w1[u] = 0ull;
             if (i < count) {
-                unsigned long long *r = lb.rec + 2 * (size_t) (tile - 1 - i);
+                unsigned long long *r = lb.rec + 2 * (size_t) slot_of(i);
                 w0[u] = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 w1[u] = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -827,11 +839,11 @@ __device__ __forceinline__ V lb_take_block(const LookBack &lb, int tile, int cou
             const int i = i0 + u * BLOCK;
             if (i < count) {
                 if (lb.max_polls > 0 && (unsigned) (w0[u] >> 32) == lb.tag_a && (unsigned) (w1[u] >> 32) == lb.tag_b) {
-                    unsigned long long *r = lb.rec + 2 * (size_t) (tile - 1 - i);
+                    unsigned long long *r = lb.rec + 2 * (size_t) slot_of(i);
                     __hip_atomic_store(r, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(r + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     part += LbBits<V>::join((unsigned) w0[u], (unsigned) w1[u]);
-                } else part += lb_take<V>(lb, tile - 1 - i, ok);
+                } else part += lb_take<V>(lb, slot_of(i), ok);
             }
         }
     }
@@ -1007,6 +1019,8 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         // block-uniform: no row ends in this tile (a slice of one long row): only the running sum
         // at the tile's last nonzero is needed -- the carry.  No write-back, no third barrier.
         if (tid < FLAG_WORDS) s_flag[tid] = 0u;
+        // a group leader ("GROUP RECORDS"; first_row_tile < tile only when the tile begins inside a row that began in an earlier one)
+        const bool leader = lb != nullptr && publish && tile % LB_GROUP == LB_GROUP - 1 && first_row_tile <= tile - (LB_GROUP - 1);
         const int last = pshift + tile_nnz - 1;
         if (tile_nnz > 0 ? tid == last / NPT : tid == 0) {
             V v = 0;
@@ -1015,7 +1029,27 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
             Carry<V> c; c.key = c0.x; c.value = v;
             if (p.band_pass > 0) c.value += carry_out->value;      // later column-band pass: same tile, same key
             *carry_out = c;
-            if (lb && publish) lb_publish<V>(*lb, tile, v);                         // (only when some tile will take it)
+            if (lb && publish && !leader) lb_publish<V>(*lb, tile, v);              // (only when some tile will take it)
+            if (leader) s_wave_val[0] = v;
+        }
+        if (leader) {
+            // (block-uniform) the group's total: the LB_GROUP - 1 records before this tile, by one wave, + this tile's own sum
+            __syncthreads();
+            const V own = s_wave_val[0];
+            bool ok = true;
+            V before = 0;
+            if (tid < WAVE) before = lb_take_wave<V>(*lb, tile, LB_GROUP - 1, ok);
+            if (__syncthreads_or(ok ? 0 : 1)) {
+                // a poll ran out: the nonzeros of the group's earlier tiles, from the matrix (they are the row's, one tile's worth each --
+                // or from the row's first nonzero, when the group begins with the row's first piece)
+                const int j0 = first_row_tile == tile - (LB_GROUP - 1) ? first_row_start : c0.y - (LB_GROUP - 1) * (BLOCK * IPT);
+                before = recompute_row_head<V, BLOCK>(p, j0, c0.y, s_wave_val);
+                if (tid == 0 && lb->error) {
+                    __hip_atomic_store(lb->error, (int) lb->call_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(lb->error + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (tid == 0) lb_publish<V>(*lb, lb->group_base + tile / LB_GROUP, before + own);
         }
         return;
     }
@@ -1042,7 +1076,15 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         const int pieces = tile - first_row_tile;            // block-uniform
         if (pieces > 0) {
             bool ok = true;
-            if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, tile, pieces, s_wave_val, ok);
+            // the complete groups among the pieces [first_row_tile, tile): their leaders folded them into group records
+            const int g_first = (first_row_tile + LB_GROUP - 1) / LB_GROUP, g_end = tile / LB_GROUP;
+            if (g_first < g_end) {
+                const int n_tail = tile - g_end * LB_GROUP, n_groups = g_end - g_first, n_head = g_first * LB_GROUP - first_row_tile;
+                const int gb = lb->group_base;
+                // nearest first: the single records after the last complete group, the group records, the singles before the first
+                first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, n_tail + n_groups + n_head, s_wave_val, ok, [=](int i) {
+                    return i < n_tail ? tile - 1 - i : i < n_tail + n_groups ? gb + g_end - 1 - (i - n_tail) : g_first * LB_GROUP - 1 - (i - n_tail - n_groups); });
+            } else if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, pieces, s_wave_val, ok, [=](int i) { return tile - 1 - i; });
             else if (tid < WAVE) first_row_carry = lb_take_wave<V>(*lb, tile, pieces, ok);
             // a poll ran out (see "NOTHING DEPENDS ON A RECORD ARRIVING" above): the whole block computes the sum from the
             // matrix -- the row's nonzeros before this tile -- and moves the epoch on
@@ -2411,7 +2453,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // nonzeros before the tile): from the tile of its first nonzero (path item x0 + rs0) -- or the one after, if that one
     // handed its short piece on by the rule above -- up to this tile
     int first_piece = tile;
-    if (!snap0 && x1 > x0) {
+    if (!snap0) {                                                   // (also for a tile without a row end: a group leader needs it)
         const unsigned item = (unsigned) x0 + (unsigned) rs0;         // (<= rows + nnz < 2^31)
         const int ft = (int) (item / (unsigned) TILE);
         const unsigned tail_ft = (unsigned) (ft + 1) * (unsigned) TILE - item;

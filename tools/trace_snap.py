@@ -60,6 +60,10 @@ for label, A, x in sweep.workloads(sys.argv[1:] or ["dense5d"]):
         if res >= 1 and k > res:
             gaps.append(np.mean(starts[res:k] - ends[:k - res]))
     if gaps: print(f"  a slot's end -> the next block's first instruction (64 CUs): {np.mean(gaps):6.2f} us")
+    # the longest-lived blocks: when they start and end in the launch, and the phase that made them long
+    for b in np.argsort(-life)[:3]:
+        ph = [us[b, i + 1] - us[b, i] for i in range(5)]
+        print(f"  longest: block {b} lives {life[b]:.1f} us, from {us[b, 0] - t0:.1f} to {us[b, 5] - t0:.1f} of {span:.1f}; hints {ph[0]:.1f} issue {ph[1]:.1f} staging {ph[2]:.1f} reduction {ph[3]:.1f} ack {ph[4]:.1f}")
     # fraction of the span during which the first / last 10 % of the blocks run
     order = np.argsort(us[:, 0]); n10 = max(nblk // 10, 1)
     print(f"  last block starts at {us[:, 0].max() - t0:.1f} us; the last 10 % of the blocks start after {us[order[-n10], 0] - t0:.1f} us")
