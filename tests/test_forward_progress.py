@@ -179,3 +179,47 @@ def test_giant_row_beside_a_kernel_that_hogs_the_device(M):
     torch.cuda.synchronize()
     for y in ys:
         _check(M, csr, x, y)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_group_records_of_rows_that_span_hundreds_of_tiles(M, prec):
+    """A row over more than 64 tiles is summed through GROUP records (kernels: "GROUP RECORDS"): every 64th piece folds its 63
+    predecessors into one record and the tile in which the row ends takes groups plus the singles at both ends.  Rows that begin at
+    every kind of offset against the group boundaries (preceded by 0 ... 200 tiles of short rows), two long rows back to back, one
+    row that is nearly the whole matrix; values and x small integers, so every sum is exact in either precision and y must EQUAL
+    the integer result -- with the default poll budget, with one look per record and with none (leaders and consumers then
+    compute their sums from the matrix), and bit for bit the same on a second call."""
+    dtype = np.float32 if prec == "f32" else np.float64
+    tdt = torch.float32 if prec == "f32" else torch.float64
+    rng = np.random.default_rng(64)
+    info = M.launch_info(1000, 3_000_000, dtype().itemsize)
+    tile = info["tile_items"]
+    cases = []
+    for lead_tiles in (0, 1, 37, 63, 64, 65, 200):
+        lens = [np.full(lead_tiles * tile // 4, 3), [70 * tile + 11], rng.integers(0, 5, 300), [130 * tile - 5], [64 * tile], rng.integers(0, 5, 50)]
+        cases.append(np.concatenate([np.asarray(l, np.int64) for l in lens]))
+    cases.append(np.concatenate([rng.integers(0, 3, 40), [400 * tile + 1], rng.integers(0, 3, 40)]).astype(np.int64))
+    for lens in cases:
+        rows = lens.size
+        off = np.zeros(rows + 1, np.int64); np.cumsum(lens, out=off[1:])
+        nnz = int(off[-1]); cols = 4096
+        csr = O.Csr(rows, cols, off.astype(np.int32), rng.integers(0, cols, nnz).astype(np.int32), rng.integers(1, 3, nnz).astype(dtype))
+        x = rng.integers(1, 3, cols).astype(dtype)
+        expect = np.add.reduceat(np.concatenate([csr.values.astype(np.float64) * x[csr.column_indices], [0.0]]), np.minimum(off[:-1], nnz))
+        expect = np.where(lens > 0, expect, 0.0)
+        assert expect.max() < 2 ** 24
+        d = [dev(v) for v in (csr.values, csr.row_offsets, csr.column_indices, x)]
+        ws = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)
+        try:
+            for polls in (0, 1, -1):
+                M.set_record_polls(polls)
+                ys = []
+                for _ in range(2):
+                    y = torch.full((rows,), float("nan"), dtype=tdt, device="cuda")
+                    M.csrmv(*d, y=y, num_cols=cols, workspace=ws)
+                    torch.cuda.synchronize()
+                    ys.append(y.cpu().numpy())
+                assert np.array_equal(ys[0], expect.astype(dtype)), (prec, polls, rows, int((ys[0] != expect).sum()))
+                assert np.array_equal(ys[0], ys[1])
+        finally:
+            M.set_record_polls(0)
