@@ -29,6 +29,9 @@ for label, A, x in sweep.workloads(sys.argv[1:] or ["dense5d"]):
     t = buf.cpu().numpy().reshape(nblk, 16)
     lean_us = t[:, 8:13].astype(np.float64) / 100.0
     us = t[:, :6].astype(np.float64) / 100.0
+    if not (t[:, 0] != 0).any():
+        print(f"== {label}: this call does not run tile_kernel_snap (column-band candidates take the classic launches): nothing traced")
+        M.set_tuning(vb); continue
     t0 = us[:, 0].min()
     span = us[:, 5].max() - t0
     hw, xcc = t[:, 6], t[:, 7] & 0xf
