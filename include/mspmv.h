@@ -281,12 +281,24 @@ int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
  * (queried from the runtime once per device; MSPMV_FAKE_L2_MIB / MSPMV_FAKE_XCDS in the environment override them), and the
  * CU count.  Without a device: the MI355X figures (4 MiB, 8, 256).  Any pointer may be NULL. */
 int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *cus);
+/* Measuring aid: ONE launch of a bare read stream over d_buf (16-byte aligned; bytes / 16 sixteen-byte loads, 256 x 11 per block
+ * like a tile's nonzero stream; nontemporal != 0: non-temporal loads), asynchronous on `stream`.  Timed over a buffer that stays
+ * in the Infinity Cache it gives the rate a cache-resident SpMV's algorithmic bytes are to be read against -- the HBM peak is not
+ * the bound of such a call (bench.py: `roofline.bound` = "infinity_cache"). */
+int mspmv_probe_read_stream(const void *d_buf, size_t bytes, int32_t nontemporal, mspmv_stream_t stream);
 /* Testing aid (per HOST THREAD, like mspmv_set_tuning): how often a tile of the one-launch kernel in which a long row ENDS
  * looks for the partial sum another workgroup publishes before it computes that sum itself from the matrix (0 = the
  * library default, ~0.1 s of polling; 1 = one look; < 0 = never look, which sends every such tile down the recomputing path).  The
  * result is correct for any value: nothing in a call depends on another workgroup making progress; only the time and, by a
  * re-association, the last bits of such a row do. */
 int mspmv_set_record_polls(int32_t polls);
+/* Testing / tuning aid (per HOST THREAD): up to how many tiles a call of the small tile shape runs the one-launch kernel behind its
+ * COMPACT FRONT END (csrc/mspmv_kernels.hpp: compact_front -- problems of one block generation; closed lean tiles on good hints take
+ * ~200 instructions per wave of straight-line code at the head of the kernel, every other tile the general body of the same kernel).
+ * 0 = the library default (1024 tiles: every block resident at once), > 0 = that many, < 0 = never.  y is bit for bit the same
+ * either way (tests/test_gpu_parity.py: the `compact` / `no_compact` paths).  Matches the reference's special case for small
+ * problems (dispatch_spmv_orig.cuh:674-679, agent_spmv_orig.cuh:867-891). */
+int mspmv_set_compact_tiles(int32_t max_tiles);
 /* *passes = how many passes a call of these sizes is offered under the current setting (0: none; the aligned,
  * vectorised path is assumed); with the automatic setting the device-side verdicts still have the last word. */
 int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes);

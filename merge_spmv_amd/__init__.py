@@ -105,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_set_band_passes.argtypes = [ctypes.c_int32, ctypes.c_int32]
     lib.mspmv_set_record_polls.restype = ctypes.c_int
     lib.mspmv_set_record_polls.argtypes = [ctypes.c_int32]
+    lib.mspmv_set_compact_tiles.restype = ctypes.c_int
+    lib.mspmv_set_compact_tiles.argtypes = [ctypes.c_int32]
     lib.mspmv_get_band_passes.restype = ctypes.c_int
     lib.mspmv_get_band_passes.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
     lib.mspmv_debug_band_windows.restype = ctypes.c_int
@@ -596,6 +598,35 @@ def set_record_polls(polls: int = 0) -> None:
     _check(load_library().mspmv_set_record_polls(int(polls)), "mspmv_set_record_polls")
 
 
+def cache_stream_rate(nbytes: int, reps: int = 20) -> float:
+    """GB/s of a bare 16-byte-per-lane read stream (mspmv_probe_read_stream, ordinary loads) over a buffer of `nbytes` that has been
+    read before -- for nbytes within the 256 MB Infinity Cache this is the rate out of that cache (and the L2s), the bound a
+    cache-resident SpMV's algorithmic bytes are to be read against (bench.py)."""
+    import time
+    import torch
+    lib = load_library()
+    lib.mspmv_probe_read_stream.restype = ctypes.c_int
+    lib.mspmv_probe_read_stream.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p]
+    n = max(int(nbytes) // 16 * 16, 16)
+    buf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    st = _stream_handle(None)
+    for _ in range(3):
+        _check(lib.mspmv_probe_read_stream(ctypes.c_void_p(buf.data_ptr()), n, 0, st), "mspmv_probe_read_stream")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.mspmv_probe_read_stream(ctypes.c_void_p(buf.data_ptr()), n, 0, st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    del buf
+    return n / dt / 1e9
+
+
+def set_compact_tiles(max_tiles: int = 0) -> None:
+    """Testing / tuning aid (mspmv_set_compact_tiles): up to how many tiles a call of the small tile shape runs the one-launch kernel
+    behind its compact front end (0 = library default, > 0 = that many, < 0 = never).  y is bit for bit the same either way."""
+    _check(load_library().mspmv_set_compact_tiles(int(max_tiles)), "mspmv_set_compact_tiles")
+
+
 def band_passes(rows: int, cols: int, nnz: int, value_bytes: int) -> int:
     """Passes a call of these sizes is offered (0: none); automatic setting: subject to the device-side verdicts."""
     n = ctypes.c_int32(0)
@@ -627,3 +658,63 @@ def debug_read_tiles(workspace_buffer, num_rows: int, num_nonzeros: int, value_b
         coords.ctypes.data_as(ctypes.c_void_p), keys.ctypes.data_as(ctypes.c_void_p),
         vals.ctypes.data_as(ctypes.c_void_p), _stream_handle(stream)), "mspmv_debug_read_tiles")
     return coords, keys[:nt], vals[:nt]
+
+
+def sampled_check(A, x, y, samples: int = 1 << 16, seed: int = 0x5A3D, depth: Optional[int] = None) -> dict:
+    """An untimed correctness witness for a benchmark record (NOT the parity tests: those are tests/ -m gpu against the oracle):
+    `samples` seeded rows -- plus the first, the last and the longest row -- recomputed on the device in fp64 with torch gathers
+    (val.double() * x.double()[col], rows up to 4096 nonzeros by index_add_, longer ones by torch.sum's tree) and compared with
+    y under the stated bound of SURVEY 8d / DESIGN 3: |y - g| <= 2 (ceil(log2(len + 1)) + depth + 8) eps s, s = sum |val x|,
+    eps = 2^-24 / 2^-53, empty rows exactly zero.  depth = serial_sum_depth of the call's shape unless given.
+    Returns {"rows_checked", "worst_ratio" (max |y - g| / bound; < 1 passes), "violations", "longest_row"}."""
+    import torch
+    rows, nnz = int(A.rows), int(A.nnz)
+    dev = A.values.device
+    if rows == 0:
+        return {"rows_checked": 0, "worst_ratio": 0.0, "violations": 0, "longest_row": 0}
+    vb = A.values.element_size()
+    if depth is None:
+        depth = serial_sum_depth(rows, A.cols, nnz, vb)
+    eps = 2.0 ** -24 if vb == 4 else 2.0 ** -53
+    off = A.row_offsets.to(torch.int64)
+    lens_all = off[1:] - off[:-1]
+    g = torch.Generator(device="cpu"); g.manual_seed(int(seed))
+    pick = torch.randint(0, rows, (min(int(samples), rows),), generator=g, dtype=torch.int64).to(dev)
+    longest = int(torch.argmax(lens_all).item())
+    pick = torch.unique(torch.cat([pick, torch.tensor([0, rows - 1, longest], dtype=torch.int64, device=dev)]))
+    lens = lens_all[pick]
+    start = off[pick]
+    gold = torch.zeros(pick.numel(), dtype=torch.float64, device=dev)
+    mag = torch.zeros_like(gold)
+    xd = x.double()
+    short = lens <= 4096
+    if bool(short.any()):
+        sl = lens[short]; st = start[short]
+        total = int(sl.sum().item())
+        if total > 0:
+            seg = torch.repeat_interleave(torch.arange(sl.numel(), device=dev), sl)
+            first = torch.cumsum(sl, 0) - sl
+            j = st[seg] + (torch.arange(total, device=dev) - first[seg])
+            p = A.values[j].double() * xd[A.column_indices[j].to(torch.int64)]
+            gs = torch.zeros(sl.numel(), dtype=torch.float64, device=dev); ms = torch.zeros_like(gs)
+            gs.index_add_(0, seg, p); ms.index_add_(0, seg, p.abs())
+            gold[short] = gs; mag[short] = ms
+    for k in torch.nonzero(~short).flatten().tolist():          # a handful of long rows: tree sums
+        a, b = int(start[k].item()), int(start[k].item() + lens[k].item())
+        gk, mk = 0.0, 0.0
+        for c0 in range(a, b, 1 << 26):
+            c1 = min(b, c0 + (1 << 26))
+            p = A.values[c0:c1].double() * xd[A.column_indices[c0:c1].to(torch.int64)]
+            gk += float(p.sum().item()); mk += float(p.abs().sum().item())
+        gold[k] = gk; mag[k] = mk
+    yy = y[pick].double()
+    c = 2.0 * (torch.ceil(torch.log2(lens.double() + 1.0)) + float(depth) + 8.0)
+    bound = c * eps * mag
+    err = (yy - gold).abs()
+    bad_empty = (lens == 0) & (y[pick] != 0)
+    ratio = torch.where(bound > 0, err / bound, torch.where(err == 0, torch.zeros_like(err), torch.full_like(err, float("inf"))))
+    ratio = torch.where(torch.isfinite(yy), ratio, torch.full_like(ratio, float("inf")))
+    ratio = torch.where(bad_empty, torch.full_like(ratio, float("inf")), ratio)
+    worst = float(ratio.max().item())
+    return {"rows_checked": int(pick.numel()), "worst_ratio": round(worst, 4) if worst != float("inf") else "inf",
+            "violations": int((ratio > 1.0).sum().item()), "longest_row": int(lens_all[longest].item()), "depth_term": int(depth)}

@@ -41,6 +41,13 @@ static int small_max_tiles()
 // Closed tiles of the one-launch kernel whose rows average at most this many nonzeros take the lean row-by-row reduction
 // (mspmv_kernels.hpp: consume_tile_rows); MSPMV_LEAN_AVG in the environment overrides it (read once: a re-tuning aid), 0 = never
 constexpr int LEAN_AVG_DEFAULT = 8;
+// The compact front end serves problems of ONE block generation: every tile resident at once (the compact variant is compiled for 4 blocks
+// per CU).  MSPMV_COMPACT_MAX_TILES in the environment overrides it (read once: a re-tuning aid), 0 = never
+static int compact_max_tiles()
+{
+    static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAX_TILES"); const int n = e ? atoi(e) : -1; return n >= 0 ? n : 1024; }();
+    return v;
+}
 static int lean_avg_default()
 {
     static const int v = [] { const char *e = getenv("MSPMV_LEAN_AVG"); const int n = e ? atoi(e) : -1; return n >= 0 ? n : LEAN_AVG_DEFAULT; }();
@@ -412,7 +419,15 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         const size_t xl = (size_t) p.x_lds * sizeof(V);
         const int lean_avg = (L.flags & MSPMV_TUNE_NO_LEAN) ? 0 : lean_avg_default();
 #define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, lb.error, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
-        if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
+        // problems of one block generation: the same kernel behind its compact front end (kernels: compact_front) -- bit for bit the same y
+        bool compact = false;
+        if constexpr (BLOCK == COMPACT_BLOCK && IPT == COMPACT_IPT) {
+            compact = !nt && ex.tile_map == 0 && L.num_tiles > 1 && L.num_tiles <= (ex.tune.compact_tiles > 0 ? ex.tune.compact_tiles : ex.tune.compact_tiles < 0 ? 0 : compact_max_tiles()) &&
+                      p.x_lds == 0 && (unsigned long long) ex.num_cols * sizeof(V) < (1ull << 32);      // (32-bit byte offsets in the fast lane)
+            if (compact) launch_snap_compact<V>(axpby, grid, xl, stream, coords, rstart, L.num_tiles, p, carries, lb, lean_avg);
+        }
+        if (compact) { }
+        else if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
         else if (nt) MSPMV_LAUNCH_SNAP(false, true);
         else MSPMV_LAUNCH_SNAP(false, false);
 #undef MSPMV_LAUNCH_SNAP
@@ -1004,9 +1019,27 @@ int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *c
     return hipSuccess;
 }
 
+int mspmv_probe_read_stream(const void *d_buf, size_t bytes, int32_t nontemporal, mspmv_stream_t stream_)
+{
+    if (!d_buf || (reinterpret_cast<uintptr_t>(d_buf) & 15) != 0) return hipErrorInvalidValue;
+    const unsigned long long n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const unsigned long long blocks = (n16 + 256ull * 11 - 1) / (256ull * 11);
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (nontemporal) hipLaunchKernelGGL((probe_read_kernel<true>), dim3((unsigned) blocks), dim3(256), 0, stream, static_cast<const int4v *>(d_buf), n16);
+    else hipLaunchKernelGGL((probe_read_kernel<false>), dim3((unsigned) blocks), dim3(256), 0, stream, static_cast<const int4v *>(d_buf), n16);
+    return (int) hipGetLastError();
+}
+
 int mspmv_set_record_polls(int32_t polls)
 {
     t_tune[0].record_polls = t_tune[1].record_polls = polls < 0 ? -1 : polls;
+    return hipSuccess;
+}
+int mspmv_set_compact_tiles(int32_t max_tiles)
+{
+    t_tune[0].compact_tiles = t_tune[1].compact_tiles = max_tiles < 0 ? -1 : max_tiles;
     return hipSuccess;
 }
 

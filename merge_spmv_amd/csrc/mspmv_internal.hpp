@@ -19,7 +19,7 @@ enum { PHASE_ALL = 0, PHASE_COORDS_ONLY = 1, PHASE_SKIP_COORDS = 2 };
 // the calling host thread's development override (mspmv_set_tuning, mspmv_set_band_passes) into it once, on entry; the
 // prepared band-major plan and the multi-GPU plan always pass the defaults, so what they store at build time (tile
 // coordinates) can never disagree with what a later apply derives.
-struct Tune { int block = 0, ipt = 0, flags = 0, band_passes = 0, record_polls = 0; };
+struct Tune { int block = 0, ipt = 0, flags = 0, band_passes = 0, record_polls = 0, compact_tiles = 0; };
 
 struct CallExtra {
     int phase = PHASE_ALL;

@@ -2288,8 +2288,307 @@ constexpr int snap_head_max()
     return slack < 192 ? slack : 192;
 }
 
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Coord *__restrict__ coords, int *__restrict__ rstart,
+// ---------------------------------------------------------------------------
+// COMPACT FRONT END of the one-launch kernel, for problems of ONE BLOCK GENERATION (mspmv_api.hip: compact_max_tiles).
+// The reference special-cases small problems too (dispatch_spmv_orig.cuh:674-679: one tile -> no search, no fix-up;
+// agent_spmv_orig.cuh:867-891).  Below a few hundred tiles a call is one generation of blocks that each run alone on their CU:
+// what it costs is the block's dependent memory trips (hints -> streams -> x) PLUS ONE INSTRUCTION PER ~5 CYCLES of a lone wave and
+// every stretch of code the block has to fetch -- the general kernel issues ~440 instructions per wave on its likeliest path
+// (hints, checks for every shape of tile, 16-bit row ends, row-start bits, the two-rows-at-a-time lean reduction) out of 19-37 KB
+// of code.  This front end is that likeliest path and nothing else, written for instruction count (~200 per wave, ~2 KB of
+// straight-line code at the head of the kernel):
+//   * the tile is the block index (no XCD chunking: a generation that is resident all at once gains nothing from it);
+//   * hints by two scalar loads; the tile is taken here only if they describe a CLOSED LEAN tile (exactly the tiles the general
+//     kernel hands to consume_tile_rows) whose every speculative access stays inside the arrays and LDS -- anything else (no usable
+//     hints yet, a long row, x in LDS, hints that fail the four-word verification) returns false BEFORE anything but LDS and registers
+//     was touched, and the block runs the general body from its start: the compact kernel is complete, this is only its fast lane;
+//   * CSR chunks are clamped to the last full chunk of their array (min, no branch); the one ragged chunk an array can end with is
+//     re-aligned in a wave-uniform, rarely taken branch -- so the LAST tile of a problem stays in the fast lane (a launch is as slow
+//     as its slowest block);
+//   * row offsets go to LDS as they are (32 bits, x0 .. x1: a row's start and end are ONE ds_read2_b32), products at their raw
+//     positions; ONE barrier;
+//   * a thread sums a row left to right from +0.0 -- the first eight products under a shrinking EXEC mask (v_cmpx + v_add per
+//     product instead of compare + select + add), nine to sixteen the same way in a second batch, longer rows by the 16 lanes of a
+//     DPP row exactly as consume_tile_rows does: THE SAME ADDITIONS IN THE SAME ORDER, so y is bit for bit what the general kernel
+//     writes (tests/test_gpu_parity.py: the `compact` paths; tools/fuzz.py).
+// ---------------------------------------------------------------------------
+constexpr int COMPACT_BLOCK = 256, COMPACT_IPT = 7;
+template <typename V> struct CompactChain;
+template <> struct CompactChain<double> {
+    // acc (+0.0 on entry) += v[j] for j < len, left to right, lanes leaving as their row ends (EXEC restored)
+    static __device__ __forceinline__ void add8(double &acc, const double (&v)[8], int len, int base)
+    {
+        unsigned long long sv;
+        const int l = len - base;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f64 %[a], %[a], %[v0]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f64 %[a], %[a], %[v1]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f64 %[a], %[a], %[v2]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f64 %[a], %[a], %[v3]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 4, %[l]\n\tv_add_f64 %[a], %[a], %[v4]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 5, %[l]\n\tv_add_f64 %[a], %[a], %[v5]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 6, %[l]\n\tv_add_f64 %[a], %[a], %[v6]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 7, %[l]\n\tv_add_f64 %[a], %[a], %[v7]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(sv)
+                     : [l] "v"(l), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+                     : "vcc");
+    }
+};
+template <> struct CompactChain<float> {
+    static __device__ __forceinline__ void add8(float &acc, const float (&v)[8], int len, int base)
+    {
+        unsigned long long sv;
+        const int l = len - base;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v0]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v1]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v2]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v3]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 4, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v4]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 5, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v5]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 6, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v6]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 7, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v7]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(sv)
+                     : [l] "v"(l), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+                     : "vcc");
+    }
+};
+// element i of a chunk that was loaded `s` elements too early (the last, ragged chunk of an array is fetched at n - 4): what
+// belongs at position i is what was loaded at position i + s (positions that fall off the end are never used)
+template <typename T>
+__device__ __forceinline__ void compact_realign(Vec4<T> &c, int s)
+{
+    T l[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l[i] = c.get(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int j = i + s; o[i] = j <= 0 ? l[0] : j == 1 ? l[1] : j == 2 ? l[2] : l[3]; }
+    if constexpr (sizeof(T) == 8) { c.a[0] = o[0]; c.a[1] = o[1]; c.b[0] = o[2]; c.b[1] = o[3]; }
+    else { c.v[0] = o[0]; c.v[1] = o[1]; c.v[2] = o[2]; c.v[3] = o[3]; }
+}
+// (the ragged chunk sits at n - 4, which need not be 16-byte aligned: dword-aligned 16-byte global loads are fine on gfx9; the
+//  packed attribute keeps the compiler from assuming more)
+typedef int int4v_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float4v_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double double2v_u __attribute__((ext_vector_type(2), aligned(8)));
+
+// loads through a 32-bit unsigned BYTE offset from a uniform base (global_load ... v_off, s[base]: one shift, no 64-bit address
+// arithmetic per lane).  The dispatcher takes the compact kernel only when every array is < 4 GB (mspmv_api.hip).
+template <typename T>
+__device__ __forceinline__ T compact_ld(const void *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ Vec4<int> compact_ld4(const int *base, int e) { Vec4<int> r; r.v = compact_ld<int4v_u>(base, (unsigned) e << 2); return r; }
+__device__ __forceinline__ Vec4<float> compact_ld4(const float *base, int e) { Vec4<float> r; r.v = compact_ld<float4v_u>(base, (unsigned) e << 2); return r; }
+__device__ __forceinline__ Vec4<double> compact_ld4(const double *base, int e)
+{
+    Vec4<double> r; r.a = compact_ld<double2v_u>(base, (unsigned) e << 3); r.b = compact_ld<double2v_u>(base, ((unsigned) e << 3) + 16u); return r;
+}
+
+// Written for the ORDER OF ITS CODE as much as for its instruction count: the translation unit that instantiates the compact kernel
+// (mspmv_compact.hip) is compiled with the block placement pass off, so the machine code keeps the order of this source -- the
+// fast lane from the hint request to its s_endpgm in one piece, what is rarely needed (the ragged end of the nonzero arrays, tiles
+// of more than 511 rows, rows of more than 8 nonzeros) behind it, reached by `goto` and left by `goto`.
+template <typename V, bool AXPBY>
+__device__ __forceinline__ void compact_front(const Coord *coords, const int *rstart, int num_tiles, const Params<V> &p,
+                                              Carry<V> *__restrict__ carries, int lean_avg, int tile, V *s_prod, int *s_ro)
+{
+    constexpr int BLOCK = COMPACT_BLOCK, IPT = COMPACT_IPT, TILE = BLOCK * IPT, CPT = IPT / 4 + 1;
+    constexpr int HEAD_MAX = snap_head_max<BLOCK, IPT>();
+    constexpr int RO_ROUNDS = (TILE + 1 + BLOCK - 1) / BLOCK;         // row offsets x0 .. x1, one per lane and round: <= 8 rounds
+    static_assert(CPT == 2 && TILE + HEAD_MAX + 16 <= CPT * BLOCK * 4 && RO_ROUNDS * BLOCK <= CPT * BLOCK * 4, "two chunks per thread; room for the snapped rows");
+    static_assert(LEAN_SERIAL == 2 * LEAN_BATCH && LEAN_BATCH == 8, "two batches of eight");
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    // (everything the cold sections at the end touch is declared up here: a goto may not jump past an initialisation)
+    Vec4<int> col[CPT]; Vec4<V> val[CPT];
+    int rov[RO_ROUNDS];
+    int r0, r, start, len, vre; bool valid; V acc; const V *src;
+    // ---- hints (scalar cache; the tile index is uniform).  Request and wait in ONE asm statement (see tile_kernel_snap)
+    int4v hc; int2v hr;
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(hc), "=&s"(hr) : "s"(coords + tile), "s"(rstart + tile) : "memory");
+    // (used in this very basic block: the kernel-argument loads are requested before the wait above)
+    asm volatile("" :: "s"(p.row_end), "s"(p.cols), "s"(p.values), "s"(p.x), "s"(p.y), "s"(p.rows), "s"(p.nnz), "s"(p.x_lds), "s"(lean_avg), "s"(carries));
+    const int x0 = hc.x, x1 = hc.z, rs0 = hr.x, rs1 = hr.y;
+    const int total = p.rows + p.nnz;                                  // < 2^31
+    const int d0 = tile * TILE, d1 = d0 + TILE < total ? d0 + TILE : total;
+    const int y0 = d0 - x0, y1 = d1 - x1;
+    const int tile_rows = x1 - x0, tile_nnz = rs1 - rs0;
+    // A closed lean tile whose hints keep every access below inside the arrays and the LDS tile (anything may be in the hints):
+    //   stored y's are the derived ones; both boundaries snap (0 <= y - rs <= HEAD_MAX); 0 <= x0 <= x1 <= rows; 0 <= rs0 <= rs1 <= nnz;
+    //   the tile fits (rows <= TILE, nonzeros <= TILE + HEAD_MAX); nonzeros <= lean_avg * rows (the general kernel's `lean`); x in memory
+    const bool take = (hc.y == y0) & (hc.w == y1) & ((unsigned) (y0 - rs0) <= (unsigned) HEAD_MAX) & ((unsigned) (y1 - rs1) <= (unsigned) HEAD_MAX) &
+                      ((unsigned) x0 <= (unsigned) x1) & ((unsigned) x1 <= (unsigned) p.rows) & ((unsigned) rs0 <= (unsigned) rs1) &
+                      ((unsigned) rs1 <= (unsigned) p.nnz) & ((unsigned) tile_rows <= (unsigned) TILE) &
+                      ((unsigned) tile_nnz <= (unsigned) (TILE + HEAD_MAX)) & ((unsigned) tile_nnz <= (unsigned) lean_avg * (unsigned) tile_rows) &
+                      (p.x_lds == 0) & (num_tiles > 1);
+    // ONE way out to the general body (the caller's code behind this function): `go` stays 0 when the tile is not taken or its hints
+    // fail the verification, and is tested once, after the staging -- two exits would be merged by the compiler through flag
+    // variables and a common block at the far end of the kernel, which puts two far jumps into the fast lane
+    int go = 0;
+    const int *__restrict__ row_offsets = p.row_end - 1;
+    const int a0 = rs0 & ~3;
+    const int nz4 = p.nnz - 4;                                          // (nnz >= 4 on this path)
+    const int a0c = a0 < nz4 ? a0 : nz4;
+    const int n_ro = tile_rows + 1;
+    if (__builtin_expect(!take, 0)) goto staged;
+    // ---- the four row offsets that decide whether (x0, rs0), (x1, rs1) are the points of diagonals d0, d1: requested first
+    vre = 0;
+    if (lane < 4) {
+        int idx = (lane < 2 ? x0 : x1) - 1 + (lane & 1);               // x0 - 1, x0, x1 - 1, x1
+        idx = idx < 0 ? 0 : idx >= p.rows ? p.rows - 1 : idx;           // (rows >= 3 on this path)
+        vre = compact_ld<int>(p.row_end, (unsigned) idx << 2);
+    }
+    // ---- the tile's nonzeros: 4-element chunks aligned in array index space, clamped to the array's last full chunk
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int e = a0 + 4 * (tid + k * BLOCK);
+        const int ee = e < rs1 ? (e < nz4 ? e : nz4) : a0c;             // (a chunk past the tile re-reads the tile's first: no bytes for data it does not use)
+        col[k] = compact_ld4(p.cols, ee);
+        val[k] = compact_ld4(p.values, ee);
+    }
+    // ---- row offsets x0 .. x1 (a row's start and end both come from here), one per lane and round: no alignment, no ragged end
+    rov[0] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid < n_ro ? tid : 0)) << 2);
+    if (BLOCK < n_ro) rov[1] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid + BLOCK < n_ro ? tid + BLOCK : 0)) << 2);      // block-uniform
+    if (__builtin_expect(2 * BLOCK < n_ro, 0)) goto more_row_offsets;
+have_row_offsets:
+    // the one ragged chunk the nonzero arrays can end with was fetched at nnz - 4: its elements are put where they belong
+    if (__builtin_expect(((rs1 + 3) & ~3) > p.nnz, 0)) goto ragged_end;
+aligned:
+    {
+        // ---- x gathers
+        V xv[CPT][4];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[k][i] = compact_ld<V>(p.x, (unsigned) col[k].get(i) * (unsigned) sizeof(V));
+        // ---- the verdict on the hints, in the shadow of the gathers (scalar: v_readlane).  Acted upon after the barrier -- a branch
+        // here would hold the gathers back behind it --: until then nothing but registers and LDS is touched
+        const int before0 = __builtin_amdgcn_readlane(vre, 0), at0 = __builtin_amdgcn_readlane(vre, 1);
+        const int before1 = __builtin_amdgcn_readlane(vre, 2), at1 = __builtin_amdgcn_readlane(vre, 3);
+        // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
+        // (written with integer selects: the tests stay on the scalar unit)
+        const int lim0 = x0 < p.rows ? at0 : (d0 == total ? 0x7fffffff : -1);
+        const int lim1 = x1 < p.rows ? at1 : (d1 == total ? 0x7fffffff : -1);
+        const bool verdict = ((x0 > 0 ? before0 : 0) == rs0) & (y0 <= lim0) & ((x1 > 0 ? before1 : 0) == rs1) & (y1 <= lim1);
+        // ---- LDS: row offsets as they are, products at their raw positions (element e of the array -> slot e - a0)
+        s_ro[tid] = rov[0];
+        if (BLOCK < n_ro) s_ro[tid + BLOCK] = rov[1];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            V prod[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) prod[i] = val[k].get(i) * xv[k][i];
+            st_lds4(&s_prod[4 * (tid + k * BLOCK)], prod);
+        }
+        __syncthreads();
+        go = verdict;
+    }
+staged:
+    asm volatile("" : "+v"(go));                                       // (opaque: the test below is not threaded back into the two places `go` comes from)
+    go = __builtin_amdgcn_readfirstlane(go);
+    if (__builtin_expect(go == 0, 0)) return;                          // (every wave alike; the general body starts from scratch)
+    // ---- row by row: consume_tile_rows' arithmetic (left to right from +0.0; > LEAN_SERIAL: 16-lane groups), one row per thread and round
+    if (tid == BLOCK - 1) { Carry<V> c; c.key = x1; c.value = (V) 0; carries[tile] = c; }       // (nothing open: what mspmv_debug_read_tiles reports)
+    r0 = 0;
+next_round:
+    // (the wave's program ENDS here -- s_endpgm, not a return: a return value is merged with the general body's exit and the
+    //  reduction then sits behind two far jumps)
+    //  (readfirstlane: the compiler has to SEE that the test is wave-uniform -- an exit it takes for divergent is routed through
+    //   flag variables and a common exit block, with the same effect)
+    if (r0 + (__builtin_amdgcn_readfirstlane(tid) & ~(WAVE - 1)) >= tile_rows) __builtin_amdgcn_endpgm();   // this wave's rows are done
+    r = r0 + tid;
+    valid = r < tile_rows;
+    {
+        const int rr = valid ? r : 0;                                   // (row 0 exists: tile_rows > 0 here)
+        start = s_ro[rr]; const int end = s_ro[rr + 1];
+        len = valid ? end - start : 0;
+        src = s_prod + (start - a0);                                   // (start - a0 + 15 < SLOTS for any lane)
+        V v[LEAN_BATCH];
+#pragma unroll
+        for (int j = 0; j < LEAN_BATCH; ++j) v[j] = src[j];
+        acc = (V) 0;
+        CompactChain<V>::add8(acc, v, len, 0);
+    }
+    if (__builtin_expect(__ballot(len > LEAN_BATCH) != 0ull, 0)) goto longer_rows;
+store_row:
+    if (valid) {
+        V *__restrict__ y = p.y + x0;
+        if (AXPBY) y[r] = p.alpha * acc + (p.beta == (V) 0 ? (V) 0 : p.beta * y[r]);
+        else y[r] = acc;
+    }
+    r0 += BLOCK;
+    goto next_round;
+
+    // ======== what is rarely needed ========
+more_row_offsets:                                                      // tiles of more than 511 rows (rows that average < 3.5 nonzeros)
+#pragma unroll
+    for (int k = 2; k < RO_ROUNDS; ++k)
+        if (k * BLOCK < n_ro) rov[k] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid + k * BLOCK < n_ro ? tid + k * BLOCK : 0)) << 2);
+#pragma unroll
+    for (int k = 2; k < RO_ROUNDS; ++k)
+        if (k * BLOCK < n_ro) s_ro[tid + k * BLOCK] = rov[k];           // (the barrier of the fast lane follows)
+    goto have_row_offsets;
+ragged_end:
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int e = a0 + 4 * (tid + k * BLOCK);
+        const int s = (e < rs1 && e > nz4) ? e - nz4 : 0;
+        if (__ballot(s != 0) != 0ull) { compact_realign(col[k], s); compact_realign(val[k], s); }
+    }
+    goto aligned;
+longer_rows:
+    {
+        // (a lane index the compiler cannot hoist out of the round loop: everything derived from it -- the DPP groups' bookkeeping --
+        //  stays down here instead of being computed ahead of the fast lane's loop)
+        int lane_c = tid; asm volatile("" : "+v"(lane_c)); lane_c &= WAVE - 1;
+        V w[LEAN_BATCH];
+#pragma unroll
+        for (int j = 0; j < LEAN_BATCH; ++j) w[j] = src[LEAN_BATCH + j];
+        CompactChain<V>::add8(acc, w, len, LEAN_BATCH);
+        // rows longer than LEAN_SERIAL: four at a time, each by the 16 lanes of one DPP row (as consume_tile_rows)
+        unsigned long long pending = __ballot(len > LEAN_SERIAL);
+        while (pending != 0ull) {                                       // wave-uniform
+            int owner[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
+                pending &= pending - 1ull;
+            }
+            const int grp = lane_c >> 4, j = lane_c & 15;
+            const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
+            const int g_start = __shfl(start, own < 0 ? 0 : own, WAVE);
+            const int g_len_any = __shfl(len, own < 0 ? 0 : own, WAVE);
+            const int g_len = own < 0 ? 0 : g_len_any;
+            const V *gsrc = s_prod + (g_start - a0);
+            V part = (V) 0;
+            for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
+                V u4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) u4[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) part += u4[u];
+            }
+            part += dpp_move<0x111, 0xf>((V) 0, part);                 // row_shr:1
+            part += dpp_move<0x112, 0xf>((V) 0, part);                 // row_shr:2
+            part += dpp_move<0x114, 0xf>((V) 0, part);                 // row_shr:4
+            part += dpp_move<0x118, 0xf>((V) 0, part);                 // row_shr:8  -> lane 15 of every row holds its total
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const V total_g = __shfl(part, 16 * g + 15, WAVE);
+                if (lane_c == owner[g]) acc = total_g;
+            }
+        }
+    }
+    goto store_row;
+}
+
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT, bool COMPACT = false>
+__global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Coord *__restrict__ coords, int *__restrict__ rstart,
                                                            const int *epoch_words, int num_tiles, int xcd_chunk_log2,
                                                            Params<V> p, Carry<V> *__restrict__ carries, LookBack lb, int lean_avg)
 {
@@ -2306,6 +2605,14 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     __shared__ V s_wave_val[NW];
     __shared__ int s_bnd[6];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
+    // COMPACT (problems of one block generation): the fast lane for closed lean tiles on good hints comes first -- its own LDS layout
+    // (32-bit row offsets) in an array of its own, the product array shared --; a tile it does not take runs the general body below
+    // from the start.  tile = block index in both.
+    if constexpr (COMPACT) {
+        static_assert(BLOCK == COMPACT_BLOCK && IPT == COMPACT_IPT && !NT, "the compact front end is written for the small tile shape");
+        __shared__ __attribute__((aligned(16))) int s_ro32[SLOTS];
+        compact_front<V, AXPBY>(coords, rstart, num_tiles, p, carries, lean_avg, (int) blockIdx.x, s_prod_raw, s_ro32);      // (a tile it takes ends there)
+    }
 
     const int tid = threadIdx.x;
 #ifdef MSPMV_DEV
@@ -2325,7 +2632,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
     // the Makefile's -amdgpu-kernarg-preload-count=8), the tile index below is branch-free scalar arithmetic on them, and the other
     // arguments are pinned behind the hint request: the block's first memory round trip is the hints AND the rest of the kernel
     // arguments together, where the arguments (in three batches, as the compiler sank them to their uses) came first.
-    const int tile = xcd_chunked_tile_flat((int) blockIdx.x, num_tiles, xcd_chunk_log2);
+    const int tile = COMPACT ? (int) blockIdx.x : xcd_chunked_tile_flat((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     // the hints: the tile's two boundaries (x, y), their row starts, and the epoch of the record tags, read THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
@@ -2479,6 +2786,29 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, true>())
 #undef MSPMV_SNAP_END
 #undef MSPMV_SNAP_TR
 }
+
+// mspmv_probe_read_stream: a bare 16-byte-per-lane read stream over a buffer, one 256 x 11-chunk piece per block like a tile's
+// nonzero stream, ordinary or non-temporal loads -- the rate a measured kernel's algorithmic bytes are to be read against when
+// its arrays live in the Infinity Cache (bench.py: records whose matrix fits 256 MB), where the HBM peak is not the bound.
+__device__ int g_probe_sink;
+template <bool NT>
+__global__ __launch_bounds__(256) void probe_read_kernel(const int4v *__restrict__ p, unsigned long long n16)
+{
+    constexpr int PER = 11;
+    const unsigned long long base = (unsigned long long) blockIdx.x * (256ull * PER) + threadIdx.x;
+    int4v acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const unsigned long long i = base + 256ull * k;
+        if (i < n16) { const int4v v = NT ? __builtin_nontemporal_load(p + i) : p[i]; acc ^= v; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x5a5a5a5a) g_probe_sink = 1;        // (keeps the loads; practically never true)
+}
+
+// host side of the compact variant (defined and instantiated in mspmv_compact.hip, the translation unit compiled for it)
+template <typename V>
+void launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStream_t stream, Coord *coords, int *rstart, int num_tiles,
+                         const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg);
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,
 // like the reference's fp32 path (agent_segment_fixup.cuh:226-260); order of

@@ -65,6 +65,36 @@ struct GpuTimer {                                       // utils.h:624-658 with 
     float ElapsedMillis() { float ms; HIP_OK(hipEventSynchronize(stop)); HIP_OK(hipEventElapsedTime(&ms, start, stop)); return ms; }
 };
 
+// --chunk-times=<n> (diagnostic, non-quiet): after a method's timed loop, the same loop again with an event every n calls --
+// the time line of the loop, us per call and chunk (where a loop average that moves from run to run comes from: a clock ramp
+// at its start, a step in the middle, or isolated long calls)
+int g_chunk = 0;
+template <typename Call>
+void ChunkTimes(int iterations, Call &&call)
+{
+    if (g_chunk <= 0 || iterations <= 0) return;
+    const int chunks = (iterations + g_chunk - 1) / g_chunk;
+    std::vector<hipEvent_t> ev((size_t) chunks + 1);
+    for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventRecord(ev[0], 0));
+    for (int k = 0, it = 0; k < chunks; ++k) {
+        for (int j = 0; j < g_chunk && it < iterations; ++j, ++it) call();
+        HIP_OK(hipEventRecord(ev[(size_t) k + 1], 0));
+    }
+    HIP_OK(hipEventSynchronize(ev[(size_t) chunks]));
+    printf("\tchunk times (us per call, %d calls per chunk):", g_chunk);
+    float lo = 1e30f, hi = 0;
+    for (int k = 0, it = 0; k < chunks; ++k) {
+        const int n = std::min(g_chunk, iterations - it); it += n;
+        float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t) k], ev[(size_t) k + 1]));
+        const float us = ms * 1000.0f / n;
+        lo = std::min(lo, us); hi = std::max(hi, us);
+        printf(" %.2f", us);
+    }
+    printf("\n\tchunk min %.2f us, max %.2f us\n", lo, hi);
+    for (auto &e : ev) (void) hipEventDestroy(e);
+}
+
 struct Device {
     hipDeviceProp_t prop;
     double giga_bandwidth = 0;
@@ -175,6 +205,7 @@ float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> 
     for (int it = 0; it < iterations; ++it) HIP_OK(call(d_temp, temp_bytes, false));
     timer.Stop();
     const float ms = timer.ElapsedMillis() / iterations;
+    if (!c.quiet) ChunkTimes(iterations, [&]() { HIP_OK(call(d_temp, temp_bytes, false)); });
     HIP_OK(hipFree(d_temp));
     return ms;
 }
@@ -330,6 +361,9 @@ float TestRocsparseCsrmv(const RunConfig &c, const CsrMatrix<V> &a, const std::v
                                    p.d_row_offsets, p.d_cols, info, p.d_x, &beta, p.d_y));
     timer.Stop();
     const float ms = timer.ElapsedMillis() / iterations;
+    if (!c.quiet) ChunkTimes(iterations, [&]() {
+        ROCSPARSE_OK(Roc<V>::csrmv(handle, rocsparse_operation_none, p.rows, p.cols, p.nnz, &alpha, descr, p.d_values,
+                                   p.d_row_offsets, p.d_cols, info, p.d_x, &beta, p.d_y)); });
     ROCSPARSE_OK(rocsparse_destroy_mat_info(info));
     ROCSPARSE_OK(rocsparse_destroy_mat_descr(descr));
     return ms;
@@ -451,7 +485,7 @@ int main(int argc, char **argv)
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
                "[--no-strict] [--no-vendor] [--no-hyb] [--cache] [--prepared] [--plan[=<bands>]] [--hotcols] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
-               "[--mg-exchange=peer|rccl] [--band-passes=<n>]\n"
+               "[--mg-exchange=peer|rccl] [--band-passes=<n>] [--chunk-times=<calls per chunk>]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;
@@ -474,6 +508,7 @@ int main(int argc, char **argv)
         }
     }
     ex.mg_one_device = args.CheckCmdLineFlag("mg-one-device");
+    args.GetCmdLineArgument("chunk-times", g_chunk);
     std::string gpus, exchange;
     args.GetCmdLineArgument("gpus", gpus);
     args.GetCmdLineArgument("mg-exchange", exchange);

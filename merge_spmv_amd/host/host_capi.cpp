@@ -130,13 +130,17 @@ int mspmv_host_merge_csrmv_bench_f64(int threads, int pin, int rows, int cols, i
     return BenchMerge<double>(threads, pin, rows, cols, nnz, row_offsets, col_idx, vals, x, budget_s, max_iters, avg_ms, iters_done,
                               pinned, packages, y_out);
 }
-// Write a Matrix Market `coordinate pattern` file (general or symmetric banner) from 0-based index arrays:
-// the corpus-scale ingest test (tools/c3_ingest.py) writes its 117 M-line input with this.
-int mspmv_host_write_pattern_mtx(const char *path, int rows, int cols, long long n, const int *row, const int *col, int symmetric)
+// Write a Matrix Market `coordinate` file (general or symmetric banner) from 0-based index arrays: `pattern` when `values` is
+// null, `real` otherwise; `comment` (optional, one line without the leading %) goes right after the banner.  The corpus-scale
+// ingest test (tools/c3_ingest.py) and the stand-in corpus (tools/make_standin_mtx.py) write their 10^6..10^8-line inputs with this.
+int mspmv_host_write_mtx(const char *path, int rows, int cols, long long n, const int *row, const int *col, const double *values,
+                         int symmetric, const char *comment)
 {
     FILE *f = fopen(path, "wb");
     if (!f) return 1;
-    fprintf(f, "%%%%MatrixMarket matrix coordinate pattern %s\n%d %d %lld\n", symmetric ? "symmetric" : "general", rows, cols, n);
+    fprintf(f, "%%%%MatrixMarket matrix coordinate %s %s\n", values ? "real" : "pattern", symmetric ? "symmetric" : "general");
+    if (comment && comment[0]) fprintf(f, "%%%s\n", comment);
+    fprintf(f, "%d %d %lld\n", rows, cols, n);
     const int T = omp_get_max_threads();
     const long long chunk = 1 << 22;                       // entries formatted per round and thread
     std::vector<std::string> out((size_t) T);
@@ -146,15 +150,20 @@ int mspmv_host_write_pattern_mtx(const char *path, int rows, int cols, long long
             const int t = omp_get_thread_num();
             std::string &b = out[(size_t) t]; b.clear();
             const long long lo = std::min(n, base + chunk * t), hi = std::min(n, lo + chunk);
-            char tmp[32];
+            char tmp[64];
             for (long long k = lo; k < hi; ++k) {
-                int len = snprintf(tmp, sizeof(tmp), "%d %d\n", row[k] + 1, col[k] + 1);
+                int len = values ? snprintf(tmp, sizeof(tmp), "%d %d %.17g\n", row[k] + 1, col[k] + 1, values[k])
+                                 : snprintf(tmp, sizeof(tmp), "%d %d\n", row[k] + 1, col[k] + 1);
                 b.append(tmp, (size_t) len);
             }
         }
         for (int t = 0; t < T; ++t) if (!out[(size_t) t].empty() && fwrite(out[(size_t) t].data(), 1, out[(size_t) t].size(), f) != out[(size_t) t].size()) { fclose(f); return 2; }
     }
     return fclose(f) == 0 ? 0 : 2;
+}
+int mspmv_host_write_pattern_mtx(const char *path, int rows, int cols, long long n, const int *row, const int *col, int symmetric)
+{
+    return mspmv_host_write_mtx(path, rows, cols, n, row, col, nullptr, symmetric, nullptr);
 }
 
 // the thread count the drivers default to: hardware threads capped by the cgroup CPU quota (utils.hpp)

@@ -204,6 +204,68 @@ def test_random_and_degenerate_shapes(M, shape, prec, path):
         M.set_tuning(vb)
 
 
+COMPACT_SHAPES = dict(SHAPES)
+COMPACT_SHAPES.update({
+    # what the compact front end's fast lane is made for, and its edges: closed lean tiles of short rows, rows of 9..16 and > 16
+    # nonzeros inside lean tiles (second batch, 16-lane groups), tiles of > 511 rows (further row-offset rounds), every residue of
+    # nnz and rows + 1 modulo 4 (the ragged last chunk of the nonzero arrays), empty rows around, a last tile of a few items
+    "five_point": lambda rng: (20000, 20000, np.full(20000, 5)),
+    "short_0_to_8": lambda rng: (30011, 9000, rng.integers(0, 9, 30011)),
+    "short_with_16s": lambda rng: (12000, 5000, np.where(rng.random(12000) < 0.05, rng.integers(9, 17, 12000), rng.integers(0, 5, 12000))),
+    "short_with_long": lambda rng: (15000, 5000, np.where(rng.random(15000) < 0.004, rng.integers(17, 1500, 15000), rng.integers(0, 4, 15000))),
+    "mostly_empty": lambda rng: (60000, 300, (rng.random(60000) < 0.2).astype(np.int64) * rng.integers(1, 4, 60000)),
+    "ragged_1": lambda rng: (7001, 700, np.concatenate([np.full(7000, 3), [2]])),
+    "ragged_2": lambda rng: (7002, 700, np.concatenate([np.full(7001, 3), [3]])),
+    "ragged_3": lambda rng: (7003, 700, np.concatenate([np.full(7002, 3), [1]])),
+    "ragged_tail_tile_of_3_items": lambda rng: (3585, 100, np.concatenate([np.full(3583, 1), [0, 2]])),
+})
+
+
+@pytest.mark.parametrize("shape", sorted(COMPACT_SHAPES))
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_compact_front_end_is_bitwise_the_general_kernel(M, shape, prec):
+    """Problems of one block generation run tile_kernel_snap behind its compact front end (mspmv_kernels.hpp: compact_front;
+    reference: the small-problem special case of dispatch_spmv_orig.cuh:674-679 / agent_spmv_orig.cuh:867-891): closed lean tiles
+    on verified hints take a fast lane of ~200 instructions, every other tile the general body of the same kernel.  Same y, bit
+    for bit, as the general kernel (mspmv_set_compact_tiles(-1)) -- on the first call (garbage hints: every tile falls through
+    to the general body), on the second (right hints: the fast lane) and with x changed; right coordinates and carries afterwards;
+    strict tolerance against the oracle."""
+    dtype, vb = DT[prec]
+    tdt = torch.float32 if vb == 4 else torch.float64
+    rng = np.random.default_rng(sum(map(ord, shape)) + 5)
+    rows, cols, lens = COMPACT_SHAPES[shape](rng)
+    csr = random_csr(rng, rows, cols, np.asarray(lens, np.int64), dtype)
+    xs = [rng.uniform(-1, 1, size=cols).astype(dtype) for _ in range(2)]
+    dv, do, dc = dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices)
+
+    def run(ws, x):
+        y = torch.full((csr.rows,), float("nan"), dtype=tdt, device="cuda")
+        M.csrmv(dv, do, dc, dev(x), y=y, num_cols=csr.cols, workspace=ws)
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+
+    try:
+        M.set_compact_tiles(-1)
+        ws_g = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)
+        want = [run(ws_g, xs[0]), run(ws_g, xs[0]), run(ws_g, xs[1])]
+        assert np.array_equal(want[0], want[1])
+        M.set_compact_tiles(0)
+        ws_c = M.CsrMVWorkspace(csr.rows, csr.nnz, tdt)
+        ws_c.buffer.random_(0, 255)                     # garbage hints
+        got = [run(ws_c, xs[0]), run(ws_c, xs[0]), run(ws_c, xs[1])]
+        for g, w in zip(got, want):
+            assert not np.isnan(g).any(), "a row was never written"
+            assert np.array_equal(g, w)
+        check_strict(M, csr, xs[1], got[2])
+        check_tiles(M, csr, xs[1], ws_c)
+        # hints of the general kernel serve the compact one and the other way round
+        assert np.array_equal(run(ws_g, xs[1]), want[2])
+        M.set_compact_tiles(-1)
+        assert np.array_equal(run(ws_c, xs[0]), want[0])
+    finally:
+        M.set_compact_tiles(0)
+
+
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_one_launch_path_does_not_depend_on_its_coordinate_hints(M, prec):
     """tile_kernel_snap reads its tile boundaries from temp storage as HINTS and verifies them against the row offsets:
