@@ -56,6 +56,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+INFINITY_CACHE_BYTES = 256 << 20      # the die-level L3 (same guide): a call whose arrays fit it is not bound by HBM once they are in there
+TRAFFIC_IS = ("L2 <-> fabric bytes of the tile kernel (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction): requests the L2s send to the "
+              "memory side -- Infinity-Cache hits INCLUDED, so for a record whose arrays live in that cache this is fabric traffic, not HBM traffic")
 
 WORKLOADS = {
     # name: default dtype.  "c2" is the N = 1 headline (BASELINE config 2); "dense32" its reference-compatible
@@ -75,6 +78,35 @@ def algorithmic_bytes(rows, cols, nnz, vb):
 def effective_bytes(rows, nnz, vb):
     """the reference's byte model, gpu_spmv.cu:452-456"""
     return nnz * (2 * vb + 4) + rows * (4 + vb)
+
+
+_CACHE_RATE = {}
+
+
+def roofline_bound(M, b_alg, achieved_gbs):
+    """The fields of a `roofline` record that say WHAT the achieved rate is read against.  Arrays beyond the 256 MB Infinity Cache:
+    the HBM3E spec peak.  Arrays that fit it (they stay there from SpMV to SpMV): the HBM peak is not the bound -- `peak` is then the
+    rate of a bare 16-byte-per-lane read stream over a buffer of the same size, measured in this run on this box
+    (mspmv_probe_read_stream), `frac` is against THAT, and `frac_of_hbm_spec_peak` keeps the old figure beside it, labelled."""
+    if b_alg > INFINITY_CACHE_BYTES:
+        return {"bound": "hbm", "resident": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "peak_source": "HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (its measured float4-copy rate is 6.29 TB/s = 0.79 of it)"}
+    key = int(b_alg) >> 20
+    if key not in _CACHE_RATE:
+        try:
+            _CACHE_RATE[key] = M.cache_stream_rate(b_alg)
+        except Exception as e:  # noqa: BLE001
+            _CACHE_RATE[key] = None
+            sys.stderr.write(f"cache stream probe failed: {e}\n")
+    peak = _CACHE_RATE[key]
+    rec = {"bound": "infinity_cache", "resident": "infinity_cache", "unit": "GB/s", "frac_of_hbm_spec_peak": round(achieved_gbs / HBM_PEAK_GBS, 4),
+           "note": f"the call's arrays ({b_alg / 2**20:.0f} MB) fit the 256 MB Infinity Cache and stay there between SpMVs: a cache-bandwidth figure, not an HBM one"}
+    if peak:
+        rec.update({"peak": round(peak, 1), "frac": round(achieved_gbs / peak, 4),
+                    "peak_source": f"measured in this run: bare 16-byte-per-lane read stream (mspmv_probe_read_stream) over a {b_alg / 2**20:.0f} MB buffer resident in the Infinity Cache"})
+    else:
+        rec.update({"peak": None, "frac": None, "peak_source": "cache stream probe unavailable"})
+    return rec
 
 
 def _cgroup_cpu_stat():
@@ -171,7 +203,7 @@ def time_stateless(M, torch, A, x, steps, warmup):
 
 
 def replayed_traffic(workload, dtype_name):
-    """HBM-side bytes per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same workload
+    """L2 <-> fabric bytes (Infinity-Cache hits included) per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same workload
     (profiles/*/pmc_latest.json, written by tools/gpu_profile.sh): replayed constants, labelled as such.  The newest
     round's file wins."""
     import glob
@@ -186,7 +218,7 @@ def replayed_traffic(workload, dtype_name):
     if best is None:
         return None, None
     pmc, rel = best
-    return pmc["tile_kernel_hbm_bytes_per_launch"], (f"{rel} (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
+    return pmc["tile_kernel_hbm_bytes_per_launch"], (f"{TRAFFIC_IS}; {rel} (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
                                                       "from separate rocprofv3 --pmc passes over this workload, " + str(pmc.get("collected", "see profiles/README.md")))
 
 
@@ -203,7 +235,7 @@ def live_traffic(label, steps=24, timeout_s=60):
 
 
 def _live_traffic(label, steps, timeout_s):
-    """HBM-side bytes per launch of the tile kernel, MEASURED IN THIS RUN on this box: two separate `rocprofv3 --kernel-trace --pmc`
+    """L2 <-> fabric bytes (Infinity-Cache hits included) per launch of the tile kernel, MEASURED IN THIS RUN on this box: two separate `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE, then WRITE_SIZE: never combined with other trace domains) over `tools/run_config.py <label>`, which runs
     the same call on the same synthetic matrix in a child process; corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
     (KB -> bytes, and gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes: doubled).  None when rocprofv3 is missing, fails
@@ -211,6 +243,7 @@ def _live_traffic(label, steps, timeout_s):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
@@ -222,12 +255,24 @@ def _live_traffic(label, steps, timeout_s):
     try:
         for pmc in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, pmc)
-            cmd = [exe, "--kernel-trace", "--pmc", pmc, "--output-format", "csv", "-d", out, "-o", "b", "--",
+            # (counters only for the tile kernel -- --kernel-include-regex: the generation of the matrix in the child runs unprofiled,
+            #  which is what lets config 5's 36 GB through --; the child in a session of its own, so that a time-out takes the
+            #  grandchild python along instead of leaving it on the GPU beside the configurations timed next)
+            cmd = [exe, "--kernel-trace", "--pmc", pmc, "--kernel-include-regex", "tile_kernel", "--output-format", "csv", "-d", out, "-o", "b", "--",
                    sys.executable, os.path.join(ROOT, "tools", "run_config.py"), label, "--steps", str(steps)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.communicate()
+                return None, f"rocprofv3 --pmc {pmc} took longer than {timeout_s} s (its process group was killed)"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {pmc} failed (rc {r.returncode})"
+            if proc.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {pmc} failed (rc {proc.returncode})"
             n, total = 0, 0.0
             for row in csv.DictReader(open(files[0])):
                 if "tile_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == pmc:
@@ -240,7 +285,7 @@ def _live_traffic(label, steps, timeout_s):
     finally:
         shutil.rmtree(work, ignore_errors=True)
     fetch_kb, nf = got["FETCH_SIZE"]; write_kb, nw = got["WRITE_SIZE"]
-    return int((2.0 * fetch_kb + write_kb) * 1024), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/run_config.py {label}, "
+    return int((2.0 * fetch_kb + write_kb) * 1024), (f"{TRAFFIC_IS}; measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/run_config.py {label}, "
                                                     f"average of {nf} / {nw} dispatches of the tile kernel; FETCH_SIZE {fetch_kb:.0f} KB x 1024 x 2 (gfx950 correction) + WRITE_SIZE {write_kb:.0f} KB x 1024")
 
 
@@ -301,7 +346,45 @@ def config_specs(torch, G, dev, steps):
     ]
 
 
-def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True, live_pmc=True):
+REAL_FILES = {"c3_web": "webbase-1M.mtx", "c3_orkut": "com-Orkut.mtx", "circuit": "circuit5M.mtx"}      # SuiteSparse names (ufl_matrices.txt)
+STANDIN_MARK = "STAND-IN written by tools/make_standin_mtx.py"
+
+
+def load_mtx(torch, G, path, tdt, dev):
+    """A Matrix Market file through the PRODUCT's ingest (libmspmv_host.so: CooMatrix::InitMarket + CsrMatrix::Init, what
+    gpu_spmv --mtx runs; sparse_matrix.h:217-380) -> DeviceCsr.  Returns (A, is_stand_in): a file written by
+    tools/make_standin_mtx.py says so in its first comment line."""
+    import numpy as np
+    H = ctypes.CDLL(os.path.join(ROOT, "merge_spmv_amd", "libmspmv_host.so"))
+    H.mspmv_host_matrix_create.restype = ctypes.c_void_p
+    H.mspmv_host_matrix_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+    H.mspmv_host_matrix_error.restype = ctypes.c_char_p
+    H.mspmv_host_matrix_error.argtypes = [ctypes.c_void_p]
+    H.mspmv_host_matrix_shape.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3
+    H.mspmv_host_matrix_copy.argtypes = [ctypes.c_void_p] * 4
+    H.mspmv_host_matrix_destroy.argtypes = [ctypes.c_void_p]
+    stand_in = False
+    with open(path, "rb") as f:
+        f.readline()
+        stand_in = STANDIN_MARK.encode() in f.readline()
+    st = ctypes.c_int(0)
+    f32 = tdt == torch.float32
+    h = H.mspmv_host_matrix_create(b"market", 0, 0, path.encode(), 1 if f32 else 0, ctypes.byref(st))
+    try:
+        if st.value != 0:
+            raise RuntimeError(f"{path}: {H.mspmv_host_matrix_error(h).decode(errors='replace')}")
+        r, c, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        H.mspmv_host_matrix_shape(h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(n))
+        off = np.empty(r.value + 1, np.int32); col = np.empty(max(n.value, 1), np.int32)[:n.value]
+        val = np.empty(max(n.value, 1), np.float32 if f32 else np.float64)[:n.value]
+        H.mspmv_host_matrix_copy(h, off.ctypes.data, col.ctypes.data, val.ctypes.data)
+    finally:
+        H.mspmv_host_matrix_destroy(h)
+    A = G.DeviceCsr(r.value, c.value, torch.from_numpy(off).to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev))
+    return A, stand_in
+
+
+def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True, live_pmc=True, mtx_dir=None, c5_pmc=True):
     """The `configs` array: every single-GPU configuration of BASELINE.json that the headline does not cover (and the
     circuit5M-shaped matrix of the reference's published number), through the same stateless call.  Generation is on the GPU
     and not timed; a configuration that would start after `budget_s` of this function's wall time is reported as skipped
@@ -316,7 +399,19 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             continue
         t0 = time.perf_counter()
         try:
-            A, x_seed = make()
+            # --mtx-dir / $MSPMV_C3_DIR: the SuiteSparse file itself when it is there (webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx) --
+            # or the stand-in tools/make_standin_mtx.py wrote under that name --, through the product's Matrix Market ingest
+            from_file = False
+            data_label = "synthetic (generated on the GPU)"
+            path = os.path.join(mtx_dir, REAL_FILES[label]) if (mtx_dir and label in REAL_FILES) else None
+            if path and os.path.exists(path):
+                A, stand_in = load_mtx(torch, G, path, tdt, dev)
+                x_seed = G.SEED_C3 + 2
+                from_file = True
+                data_label = (f"stand-in read from {path} through the Matrix Market ingest" if stand_in
+                              else f"suitesparse: {path} (the real matrix), through the Matrix Market ingest")
+            else:
+                A, x_seed = make()
             x = G.uniform_pm1(x_seed, A.cols, tdt, dev)
             torch.cuda.synchronize()
             gen_s = time.perf_counter() - t0
@@ -325,22 +420,20 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             b_alg = algorithmic_bytes(A.rows, A.cols, A.nnz, vb)
             info = M.launch_info(A.rows, A.nnz, vb)
             offered = M.band_passes(A.rows, A.cols, A.nnz, vb)
-            # one-launch calls: the kernel IS the step, and hipEvent records around a 30 us kernel add more than the launch gap
-            # they replace -- the wall clock of K back-to-back calls is the smaller, and by construction an upper bound of the
-            # kernel's duration; three-launch calls (column-band candidates): the tile kernel's own event time
+            # the tile kernel's duration: its hipEvent average on the launch stream (one-launch calls: the kernel IS the step -- the
+            # wall clock per step of K back-to-back calls is reported beside it, not mixed into it)
             one_launch = offered <= 1
-            tile_s = (min(prof["tile_ms"], ms) if one_launch else prof["tile_ms"]) * 1e-3
-            rec = {"config": name, "workload": desc, "dtype": "f32" if vb == 4 else "f64", "rows": A.rows, "cols": A.cols, "nnz": A.nnz,
+            tile_s = prof["tile_ms"] * 1e-3
+            achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
+            rec = {"config": name, "workload": desc, "data": data_label, "dtype": "f32" if vb == 4 else "f64", "rows": A.rows, "cols": A.cols, "nnz": A.nnz,
                    "steps": k, "ms_per_step": round(ms, 5), "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
                    "tile": f"{info['block_threads']}x{info['items_per_thread']}", "generation_s": round(gen_s, 2),
-                   "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap (one launch)" if one_launch else "tile_kernel_vec<.., BAND>",
-                                "achieved": round(b_alg / tile_s / 1e9, 2) if tile_s > 0 else None,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_alg / tile_s / 1e9 / HBM_PEAK_GBS, 4) if tile_s > 0 else None,
+                   "roofline": {"kernel": "tile_kernel_snap (one launch)" if one_launch else "tile_kernel_vec<.., BAND>",
+                                "achieved": round(achieved, 2), **roofline_bound(M, b_alg, achieved),
                                 "algorithmic_bytes_per_launch": b_alg,
                                 "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5), "fixup": round(prof["fixup_ms"], 5)},
-                                "duration_used_ms": round(tile_s * 1e3, 5),
-                                "duration_source": ("min(hipEvent average of the one launch, wall clock per step of K back-to-back calls)" if one_launch
-                                                    else "hipEvent average of the tile kernel"),
+                                "duration_used_ms": round(tile_s * 1e3, 5), "duration_source": "hipEvent average of the tile kernel on the launch stream",
+                                "wall_ms_per_step": round(ms, 5),
                                 "events": f"hipEvents on the launch stream, {prof['calls']} launches"}}
             rec.update(effective_record(A.rows, A.nnz, vb, ms))
             if label == "circuit":
@@ -349,16 +442,27 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             if offered > 1:
                 spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
                 rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
-            rep_tr, src = replayed_traffic(label, "f32" if vb == 4 else "f64")
-            live_tr, live_src = (None, "config 5: rocprofv3 does not survive generating its 36 GB") if (label == "c5" or not live_pmc) else live_traffic(label)
+            rep_tr, src = (None, None) if from_file else replayed_traffic(label, "f32" if vb == 4 else "f64")
+            if not live_pmc or from_file:
+                live_tr, live_src = None, ("skipped (--no-live-pmc)" if not live_pmc else "skipped: the child run regenerates the stand-in, this record is a file")
+            elif label == "c5":
+                # (the child generates the 36 GB matrix again, unprofiled -- the counters are collected for the tile kernel only --: ~40 s per pass)
+                live_tr, live_src = live_traffic(label, steps=5, timeout_s=240) if c5_pmc else (None, "skipped (--no-c5-pmc)")
+            else:
+                live_tr, live_src = live_traffic(label)
             tr = live_tr if live_tr is not None else rep_tr
             if tr is not None:
                 rec["roofline"]["traffic"] = tr
                 rec["roofline"]["traffic_source"] = live_src if live_tr is not None else src + f" [live counters: {live_src}]"
+                rec["roofline"]["traffic_is"] = "l2_fabric_bytes_infinity_cache_hits_included"
                 rec["roofline"]["traffic_over_algorithmic"] = round(tr / b_alg, 3)
                 rec["roofline"]["traffic_replayed_from_committed_passes"] = rep_tr
-            # cheap sanity on the result: finite (parity proper is tests/ -m gpu)
+            # a correctness witness of this very record (parity proper is tests/ -m gpu against the oracle): 2^16 seeded rows + the first,
+            # last and longest recomputed in fp64 with torch gathers, against the stated bound of SURVEY 8d (no oracle import)
             rec["y_finite"] = bool(torch.isfinite(y).all().item())
+            chk = M.sampled_check(A, x, y)
+            rec["sampled_worst_ratio"] = chk["worst_ratio"]
+            rec["sampled_check"] = chk
             rec["gathers_per_s_G"] = round(A.nnz / (ms * 1e-3) / 1e9, 2)
             if label == "c5":
                 rec["roofline"]["note"] = ("x (512 MB) is beyond every cache: a gather that misses moves a whole 128-byte line whatever the load's cache "
@@ -441,7 +545,12 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="N = 1: do not measure the headline's counter traffic with two rocprofv3 --pmc child runs (replay the committed passes instead)")
     ap.add_argument("--no-vendor", action="store_true", help="N = 1: skip the rocSPARSE comparison column (`vendor` sub-records)")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records (the other single-GPU configurations)")
-    ap.add_argument("--configs-budget", type=float, default=150.0, help="seconds the `configs` leg may take before it stops starting new ones")
+    ap.add_argument("--mtx-dir", default=os.environ.get("MSPMV_C3_DIR"),
+                    help="N = 1: a directory that may hold webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx (the SuiteSparse files, or the stand-ins "
+                         "tools/make_standin_mtx.py writes under those names): a file that is there replaces the generated stand-in of its record, read "
+                         "through the product's Matrix Market ingest, and the record's `data` says which it was (default: $MSPMV_C3_DIR)")
+    ap.add_argument("--no-c5-pmc", action="store_true", help="N = 1: do not collect config 5's counter traffic (two child runs that each regenerate the 36 GB matrix: ~80 s)")
+    ap.add_argument("--configs-budget", type=float, default=240.0, help="seconds the `configs` leg may take before it stops starting new ones")
     ap.add_argument("--dist-timeout", type=int, default=900, help="N > 1: seconds a collective may block before the job aborts")
     ap.add_argument("--tune", default=None, help="development: BLOCKxIPT[:flags] passed to mspmv_set_tuning")
     ap.add_argument("--band-passes", type=int, default=0,
@@ -787,9 +896,9 @@ def main():
             "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
             "effective_pct_of_peak": round(100.0 * effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 2),
             "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": "tile_kernel_snap (one launch per part)", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "traffic_over_algorithmic": round(traffic / b_alg, 3) if traffic else None,
+            "roofline": {"kernel": "tile_kernel_snap (one launch per part)", "achieved": round(achieved, 2), **roofline_bound(M, b_alg, achieved),
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_is": "l2_fabric_bytes_infinity_cache_hits_included",
+                         "traffic_over_algorithmic": round(traffic / b_alg, 3) if traffic else None,
                          "traffic_replayed_from_committed_passes": (replayed if not mg else None), "algorithmic_bytes_per_launch": b_alg,
                          "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5),
                                        "fixup": round(prof["fixup_ms"], 5)},
@@ -810,6 +919,11 @@ def main():
             # tile kernel, every other call ONE launch of tile_kernel_snap (its "search" / "fixup" figures are then just the cost of
             # two back-to-back event records)
             out["roofline"]["kernel"] = "tile_kernel_vec<.., BAND>" if offered > 1 else "tile_kernel_snap (one launch: no coordinate pass, no fix-up)"
+        if not mg:
+            chk = M.sampled_check(A, x, y)
+            out["sampled_worst_ratio"] = chk["worst_ratio"]
+            out["sampled_check"] = dict(chk, what="2^16 seeded rows + the first, last and longest recomputed in fp64 with torch gathers against the stated bound "
+                                                  "|y - g| <= 2 (ceil(log2(len + 1)) + depth + 8) eps s (SURVEY 8d); < 1 passes; parity proper: tests/ -m gpu")
         if exchange is not None:
             out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
             if isinstance(exchange.get("exchange"), int):
@@ -832,7 +946,8 @@ def main():
         if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs and not args.tune and not args.band_passes:
             del A, ws, y
             torch.cuda.empty_cache()
-            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget, vendor=not args.no_vendor, live_pmc=not args.no_live_pmc)
+            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget, vendor=not args.no_vendor, live_pmc=not args.no_live_pmc,
+                                            mtx_dir=args.mtx_dir, c5_pmc=not args.no_c5_pmc)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -178,9 +178,11 @@ int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_
  * and runs the ordinary stateless CsrMV on the renumbered indices:
  *     y = alpha * A * x + beta * y        (beta == 0: y is never read).
  * A column permutation only changes where x is read -- every row still sums the same products in the same order -- so y
- * is BIT FOR BIT the result of mspmv_csrmv_* / _axpby_* in its one-sweep form (the plan never takes the column-band passes;
- * a stateless call that does -- x of 5.5-40 MiB under uniformly spread columns -- re-associates the row sums, so compare
- * with mspmv_set_band_passes(vb, -1) there).  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
+ * is BIT FOR BIT the result of mspmv_csrmv_* / _axpby_* in its ONE-LAUNCH form.  The plan's inner call is never a CANDIDATE for
+ * the column-band passes; a stateless call whose sizes make it one (mspmv_get_band_passes > 1: x of 5.5-40 MiB, >= 8 nonzeros
+ * per row, a CSR stream >= 160 MiB) runs the classic three launches -- one carry per tile and a fix-up, another association of
+ * the sums of rows that cross tiles -- whether or not the device-side windows then let the passes run, so compare with
+ * mspmv_set_band_passes(vb, -1) there (bench.py's hot_column_plan records do).  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
  * the band-major plan below (caller-owned storage of mspmv_csrmv_hotcols_size bytes, the same rows / cols / nnz /
  * value_bytes to every call, asynchronous on `stream`); d_values / d_row_offsets passed to _apply must be the arrays
  * the plan was built for.  No reference counterpart (its HYB column is the precedent for set-up timed apart,
@@ -295,7 +297,7 @@ int mspmv_set_record_polls(int32_t polls);
 /* Testing / tuning aid (per HOST THREAD): up to how many tiles a call of the small tile shape runs the one-launch kernel behind its
  * COMPACT FRONT END (csrc/mspmv_kernels.hpp: compact_front -- problems of one block generation; closed lean tiles on good hints take
  * ~200 instructions per wave of straight-line code at the head of the kernel, every other tile the general body of the same kernel).
- * 0 = the library default (1024 tiles: every block resident at once), > 0 = that many, < 0 = never.  y is bit for bit the same
+ * 0 = the library default (1024 tiles in fp64, 1408 in fp32: about one block generation), > 0 = that many, < 0 = never.  y is bit for bit the same
  * either way (tests/test_gpu_parity.py: the `compact` / `no_compact` paths).  Matches the reference's special case for small
  * problems (dispatch_spmv_orig.cuh:674-679, agent_spmv_orig.cuh:867-891). */
 int mspmv_set_compact_tiles(int32_t max_tiles);

@@ -505,7 +505,24 @@ def hotcols_bench_record(A, x, y_stateless, steps: int = 5, warmup: int = 2, pea
             "roofline": {"bound": "hbm", "achieved": round(b_alg / (ms * 1e-3) / 1e9, 2), "peak": peak_gbs, "unit": "GB/s",
                          "frac": round(b_alg / (ms * 1e-3) / 1e9 / peak_gbs, 4),
                          "note": "algorithmic bytes of the ORIGINAL matrix / whole plan SpMV (x permutation + tile kernel)"},
-            "bitwise_equal_to_stateless": bool(torch.equal(y, y_stateless))}
+            "bitwise_equal_to_stateless": bool(torch.equal(y, y_stateless)),
+            "bitwise_equal_to_stateless_one_launch": _equal_to_one_launch(A, x, y),
+            "bitwise_note": "the plan's y is bit for bit the stateless call's in its one-launch form; a stateless call that is a CANDIDATE for the "
+                            "column-band passes (mspmv_get_band_passes > 1) runs the classic three launches, another association: compared "
+                            "with mspmv_set_band_passes(vb, -1) in `bitwise_equal_to_stateless_one_launch`"}
+
+
+def _equal_to_one_launch(A, x, y_plan) -> bool:
+    """y_plan == the stateless call's y with the column-band candidacy switched off (mspmv_set_band_passes(vb, -1))"""
+    import torch
+    vb = A.values.element_size()
+    try:
+        set_band_passes(vb, -1)
+        y = csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols)
+        torch.cuda.synchronize()
+    finally:
+        set_band_passes(vb, 0)
+    return bool(torch.equal(y, y_plan))
 
 
 def plan_bench_record(A, x, y_stateless, steps: int = 50, warmup: int = 5, peak_gbs: float = 8000.0) -> dict:

@@ -30,7 +30,7 @@ constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 constexpr int DEV_FLAG_MASK = 1 | 0xff00 | 0x70000 | 0xf00000;   // selectors of the -DMSPMV_DEV kernel variants
-constexpr int SMALL_MAX_TILES_DEFAULT = 1024;    // fp32: up to this many 256x7 tiles a problem takes that shape, 256x11 beyond
+constexpr int SMALL_MAX_TILES_DEFAULT = 1408;    // fp32: up to this many 256x7 tiles a problem takes that shape, 256x11 beyond (1024 until the compact front end: grid2d-700 fp32, 1366 tiles, 5.48 -> 4.83 us)
 // (MSPMV_SMALL_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
 static int small_max_tiles()
 {
@@ -41,12 +41,14 @@ static int small_max_tiles()
 // Closed tiles of the one-launch kernel whose rows average at most this many nonzeros take the lean row-by-row reduction
 // (mspmv_kernels.hpp: consume_tile_rows); MSPMV_LEAN_AVG in the environment overrides it (read once: a re-tuning aid), 0 = never
 constexpr int LEAN_AVG_DEFAULT = 8;
-// The compact front end serves problems of ONE block generation: every tile resident at once (the compact variant is compiled for 4 blocks
-// per CU).  MSPMV_COMPACT_MAX_TILES in the environment overrides it (read once: a re-tuning aid), 0 = never
-static int compact_max_tiles()
+// The compact front end serves problems of about ONE block generation (the compact variant is compiled for 4 blocks per CU): up to
+// 1024 tiles in fp64, 1408 in fp32 -- measured with the limit lifted (tools/ab_driver, profiles/r05_compact_limit.txt): beyond, the
+// general kernel with its XCD-chunked tile order and 7 resident blocks per CU is ahead (fp64 grid2d-700, 1366 tiles: 7.28 vs 7.75 us;
+// fp32 grid2d-800, 1784 tiles: 6.04 vs 6.25).  MSPMV_COMPACT_MAX_TILES in the environment overrides both (read once: a re-tuning aid), 0 = never
+static int compact_max_tiles(int value_bytes)
 {
-    static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAX_TILES"); const int n = e ? atoi(e) : -1; return n >= 0 ? n : 1024; }();
-    return v;
+    static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAX_TILES"); return e ? atoi(e) : -1; }();
+    return v >= 0 ? v : value_bytes == 8 ? 1024 : 1408;
 }
 static int lean_avg_default()
 {
@@ -75,7 +77,7 @@ static thread_local Tune t_tune[2];
 static inline const Tune &thread_tune(int value_bytes) { return t_tune[value_bytes == 8]; }
 
 // Default shape (measured on MI355X with the one-launch kernel; profiles/r03_small_shapes.txt, r03_sweep_vs_rocsparse.txt):
-//  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (1024) tiles -- more, smaller tiles keep more CUs
+//  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (1408; 1024 until round 5) tiles -- more, smaller tiles keep more CUs
 //    busy on a small matrix: 4.4-5.6 us per call up to 1.4 M nonzeros where 256x11 takes 4.9-5.9 --, 256x11 beyond (the
 //    fastest or within 1 % of the fastest shape on every larger workload tried);
 //  * fp64: 256x7 (7 resident blocks per CU instead of 5) up to 8 M path items, 256x11 beyond (24 M until the large shape
@@ -407,31 +409,44 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         lb.tag_a = (unsigned) (tag >> 32) | 1u; lb.tag_b = (unsigned) tag; lb.error = reinterpret_cast<int *>(base + L.err_off);
         lb.group_base = L.num_tiles;
         lb.call_tag = lb.tag_a; lb.max_polls = ex.tune.record_polls > 0 ? ex.tune.record_polls : ex.tune.record_polls < 0 ? 0 : REC_MAX_POLLS;
-        static std::atomic<int> snap_cache[64];
-        const int chunk_flag = (L.flags >> 24) & 0xf;
-        const int wanted = chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
-        // (ex.tile_map: the band-major plan's one contiguous tile range per XCD -- inside a range a lower-numbered tile sits on an
-        //  earlier block of the same XCD, so a tile that waits for records waits for blocks dispatched before it)
-        const int chunk_log2 = ex.tile_map ? ex.tile_map : safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
         const unsigned long long stream_bytes = (unsigned long long) p.nnz * (sizeof(V) + 4) + 4ull * p.rows;
         const bool nt = (L.flags & MSPMV_TUNE_FORCE_NT) || (!(L.flags & MSPMV_TUNE_FORCE_TEMPORAL) && stream_bytes > (256ull << 20));
         const unsigned grid = (unsigned) L.num_tiles;
         const size_t xl = (size_t) p.x_lds * sizeof(V);
         const int lean_avg = (L.flags & MSPMV_TUNE_NO_LEAN) ? 0 : lean_avg_default();
-#define MSPMV_LAUNCH_SNAP(AX, NTF) hipLaunchKernelGGL((tile_kernel_snap<V, BLOCK, IPT, AX, NTF>), dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, lb.error, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
+        // (every launch below is ONE call into the HIP runtime -- launch_exact: hipLaunchKernel with its status -- and the compact
+        //  variant needs nothing else from it: the reference's timing loop is bound by the enqueueing thread for small problems)
+        hipError_t launched = hipSuccess;
         // problems of one block generation: the same kernel behind its compact front end (kernels: compact_front) -- bit for bit the same y
         bool compact = false;
         if constexpr (BLOCK == COMPACT_BLOCK && IPT == COMPACT_IPT) {
-            compact = !nt && ex.tile_map == 0 && L.num_tiles > 1 && L.num_tiles <= (ex.tune.compact_tiles > 0 ? ex.tune.compact_tiles : ex.tune.compact_tiles < 0 ? 0 : compact_max_tiles()) &&
-                      p.x_lds == 0 && (unsigned long long) ex.num_cols * sizeof(V) < (1ull << 32);      // (32-bit byte offsets in the fast lane)
-            if (compact) launch_snap_compact<V>(axpby, grid, xl, stream, coords, rstart, L.num_tiles, p, carries, lb, lean_avg);
+            compact = !nt && ex.tile_map == 0 && L.num_tiles > 1 && L.num_tiles <= (ex.tune.compact_tiles > 0 ? ex.tune.compact_tiles : ex.tune.compact_tiles < 0 ? 0 : compact_max_tiles((int) sizeof(V))) &&
+                      (unsigned long long) ex.num_cols * sizeof(V) < (1ull << 32);      // (32-bit byte offsets in the fast lane)
+            if (compact) {
+                // (a tiny x is gathered from memory here, not from an LDS copy: the copy pays on matrices that stream from HBM, a problem of
+                //  one block generation has x in its caches anyway -- 3.5 -> 2.8 us per call on a 900-row grid -- and the result is the same
+                //  bit for bit, tests/test_gpu_parity.py::test_tiny_x_is_gathered_from_lds)
+                Params<V> pc = p; pc.x_lds = 0;
+                launched = launch_snap_compact<V>(axpby, grid, 0, stream, coords, rstart, L.num_tiles, pc, carries, lb, lean_avg);
+            }
         }
-        if (compact) { }
-        else if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
-        else if (nt) MSPMV_LAUNCH_SNAP(false, true);
-        else MSPMV_LAUNCH_SNAP(false, false);
+        if (!compact) {
+            static std::atomic<int> snap_cache[64];
+            const int chunk_flag = (L.flags >> 24) & 0xf;
+            const int wanted = chunk_flag == 0 ? 6 : chunk_flag == 15 ? 0 : chunk_flag;
+            // (ex.tile_map: the band-major plan's one contiguous tile range per XCD -- inside a range a lower-numbered tile sits on an
+            //  earlier block of the same XCD, so a tile that waits for records waits for blocks dispatched before it -- EXCEPT the first
+            //  tiles of XCD k's range, which wait for the LAST tiles of XCD k - 1's range: few waiters, a bounded poll, then the sum
+            //  recomputed from the matrix; correct, and slow only for a row longer than HEAD_MAX that crosses a range boundary)
+            const int chunk_log2 = ex.tile_map ? ex.tile_map : safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
+#define MSPMV_LAUNCH_SNAP(AX, NTF) launched = launch_exact(tile_kernel_snap<V, BLOCK, IPT, AX, NTF>, dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, lb.error, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
+            if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
+            else if (nt) MSPMV_LAUNCH_SNAP(false, true);
+            else MSPMV_LAUNCH_SNAP(false, false);
 #undef MSPMV_LAUNCH_SNAP
-        MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_snap", grid, BLOCK, lb.error, lb.tag_a));
+        }
+        MSPMV_CHECK(launched);
+        if (debug_sync) MSPMV_CHECK(after_launch(stream, debug_sync, compact ? "tile_kernel_snap (compact front end)" : "tile_kernel_snap", grid, BLOCK, lb.error, lb.tag_a));
         prof_mark(stream, slot, 2);
         prof_mark(stream, slot, 3);
         return hipSuccess;

@@ -13,14 +13,14 @@
 namespace mspmv {
 
 template <typename V>
-void launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStream_t stream, Coord *coords, int *rstart, int num_tiles,
-                         const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg)
+hipError_t launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStream_t stream, Coord *coords, int *rstart, int num_tiles,
+                               const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg)
 {
     constexpr int B = COMPACT_BLOCK, I = COMPACT_IPT;
-    if (axpby) hipLaunchKernelGGL((tile_kernel_snap<V, B, I, true, false, true>), dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, lb.error, num_tiles, 0, p, carries, lb, lean_avg);
-    else hipLaunchKernelGGL((tile_kernel_snap<V, B, I, false, false, true>), dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, lb.error, num_tiles, 0, p, carries, lb, lean_avg);
+    if (axpby) return launch_exact(tile_kernel_snap<V, B, I, true, false, true>, dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, lb.error, num_tiles, 0, p, carries, lb, lean_avg);
+    return launch_exact(tile_kernel_snap<V, B, I, false, false, true>, dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, lb.error, num_tiles, 0, p, carries, lb, lean_avg);
 }
-template void launch_snap_compact<float>(bool, unsigned, size_t, hipStream_t, Coord *, int *, int, const Params<float> &, Carry<float> *, const LookBack &, int);
-template void launch_snap_compact<double>(bool, unsigned, size_t, hipStream_t, Coord *, int *, int, const Params<double> &, Carry<double> *, const LookBack &, int);
+template hipError_t launch_snap_compact<float>(bool, unsigned, size_t, hipStream_t, Coord *, int *, int, const Params<float> &, Carry<float> *, const LookBack &, int);
+template hipError_t launch_snap_compact<double>(bool, unsigned, size_t, hipStream_t, Coord *, int *, int, const Params<double> &, Carry<double> *, const LookBack &, int);
 
 }  // namespace mspmv

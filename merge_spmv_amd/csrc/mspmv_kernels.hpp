@@ -42,6 +42,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <tuple>
+#include <utility>
 
 namespace mspmv {
 
@@ -1134,6 +1136,76 @@ template <typename V, int IPT> constexpr bool layout_hints() { return IPT <= 7; 
 #define MSPMV_LIKELY(on, c) ((on) ? __builtin_expect(!!(c), 1) : !!(c))      // (on: a constant -- which tile shapes take the hint)
 #define MSPMV_UNLIKELY(on, c) ((on) ? __builtin_expect(!!(c), 0) : !!(c))
 constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one thread
+constexpr int LEAN_GROUP_MAX = 256;    // rows up to this long (and longer than LEAN_SERIAL) are summed by the 16 lanes of one DPP row; longer ones by the wave
+// Rows of a lean tile that are longer than LEAN_SERIAL -- every lane of the wave calls this with ITS row's first product position
+// `pos` (LDS element index), length `len` (0: no row) and running sum `acc`; the owners of such rows get their row's total in `acc`.
+//   * LEAN_SERIAL < len <= LEAN_GROUP_MAX: four rows at a time, each by the 16 lanes of one DPP row -- lane j adds products j, j + 16, ...
+//     from +0.0, the 16 partial sums are folded left to right (row_shr 1, 2, 4, 8): summation depth <= len / 16 + 4 <= 20;
+//   * longer rows (a closed lean tile can hold ONE row of ~2000-3000 nonzeros next to hundreds of empty ones): one at a time by the
+//     whole wave -- lane j keeps FOUR running sums, over products j + 64 u + 256 r (u = 0 .. 3), adds them pairwise, and the 64
+//     totals are folded by row_shr 1, 2, 4, 8, row_bcast 15 and 31: depth <= len / 256 + 2 + 6 <= 20 for any row a tile can hold.
+//     (Until round 5 these rows went to a 16-lane group as well: depth len / 16 + 4, ~150 for such a row -- beyond the
+//      2 (ceil(log2(len + 1)) + items_per_thread + 8) of the stated bound, which the tests then only met statistically.)
+// A fixed order either way; shared by consume_tile_rows and the compact front end, so the two write the same bits.
+template <typename V>
+__device__ __forceinline__ void lean_long_rows(const V *s_prod, int pos, int len, int lane, V &acc)
+{
+    unsigned long long pending = __ballot(len > LEAN_SERIAL && len <= LEAN_GROUP_MAX);
+    while (pending != 0ull) {                                           // wave-uniform
+        int owner[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
+            pending &= pending - 1ull;                                  // (0 stays 0)
+        }
+        const int grp = lane >> 4, j = lane & 15;
+        const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
+        // (both shuffles by ALL lanes, the selection afterwards: a lane switched off by a branch cannot be read from)
+        const int g_pos = __shfl(pos, own < 0 ? 0 : own, WAVE);
+        const int g_len_any = __shfl(len, own < 0 ? 0 : own, WAVE);
+        const int g_len = own < 0 ? 0 : g_len_any;
+        const V *gsrc = s_prod + g_pos;
+        V part = (V) 0;
+        for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
+            V u4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) u4[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part += u4[u];
+        }
+        part += dpp_move<0x111, 0xf>((V) 0, part);                     // row_shr:1
+        part += dpp_move<0x112, 0xf>((V) 0, part);                     // row_shr:2
+        part += dpp_move<0x114, 0xf>((V) 0, part);                     // row_shr:4
+        part += dpp_move<0x118, 0xf>((V) 0, part);                     // row_shr:8  -> lane 15 of every row holds its total
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const V total = __shfl(part, 16 * g + 15, WAVE);
+            if (lane == owner[g]) acc = total;
+        }
+    }
+    pending = __ballot(len > LEAN_GROUP_MAX);
+    while (pending != 0ull) {                                           // wave-uniform: one row per round, by the whole wave
+        const int own = __ffsll((long long) pending) - 1;
+        pending &= pending - 1ull;
+        const int g_pos = __shfl(pos, own, WAVE), g_len = __shfl(len, own, WAVE);
+        const V *gsrc = s_prod + g_pos;
+        V a4[4] = {(V) 0, (V) 0, (V) 0, (V) 0};
+        for (int k = lane; k < g_len; k += 4 * WAVE) {                  // (the lanes leave as the row runs out: no ballot needed, nothing is exchanged inside)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += k + WAVE * u < g_len ? gsrc[k + WAVE * u] : (V) 0;
+        }
+        V part = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        part += dpp_move<0x111, 0xf>((V) 0, part);                     // row_shr:1
+        part += dpp_move<0x112, 0xf>((V) 0, part);                     // row_shr:2
+        part += dpp_move<0x114, 0xf>((V) 0, part);                     // row_shr:4
+        part += dpp_move<0x118, 0xf>((V) 0, part);                     // row_shr:8  -> lane 15 of every row of 16 holds that row's total
+        part += dpp_move<0x142, 0xa>((V) 0, part);                     // row_bcast15 into rows 1 and 3
+        part += dpp_move<0x143, 0xc>((V) 0, part);                     // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
+        const V total = __shfl(part, WAVE - 1, WAVE);
+        if (lane == own) acc = total;
+    }
+}
+
 constexpr int LEAN_BATCH = 8;          // products of a row requested before any is looked at
 template <typename V, int BLOCK, int IPT, bool AXPBY>
 __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coord c0, int tile_rows, const end16_t *s_end,
@@ -1194,41 +1266,9 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
 #pragma unroll
                 for (int j = 0; j < LEAN_SERIAL - LEAN_BATCH; ++j) acc[h] = LEAN_BATCH + j < len[h] ? acc[h] + w[j] : acc[h];
             }
-            // rows longer than that: four at a time, each by the 16 lanes of one DPP row -- lane j adds products j, j + 16, ... from
-            // +0.0, the 16 partial sums are folded left to right (row_shr 1, 2, 4, 8) -- and the total replaces what the owner has
-            unsigned long long pending = __ballot(len[h] > LEAN_SERIAL);
-            while (MSPMV_UNLIKELY((layout_hints<V, IPT>()), pending != 0ull)) {       // wave-uniform
-                int owner[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
-                    pending &= pending - 1ull;                        // (0 stays 0)
-                }
-                const int lane = tid & (WAVE - 1), grp = lane >> 4, j = lane & 15;
-                const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
-                // (both shuffles by ALL lanes, the selection afterwards: a lane switched off by a branch cannot be read from)
-                const int g_e0 = __shfl(e0[h], own < 0 ? 0 : own, WAVE);
-                const int g_len_any = __shfl(len[h], own < 0 ? 0 : own, WAVE);
-                const int g_len = own < 0 ? 0 : g_len_any;
-                const V *gsrc = s_prod_raw + (pshift + g_e0);
-                V part = (V) 0;
-                for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
-                    V u4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) u4[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) part += u4[u];
-                }
-                part += dpp_move<0x111, 0xf>((V) 0, part);           // row_shr:1
-                part += dpp_move<0x112, 0xf>((V) 0, part);           // row_shr:2
-                part += dpp_move<0x114, 0xf>((V) 0, part);           // row_shr:4
-                part += dpp_move<0x118, 0xf>((V) 0, part);           // row_shr:8  -> lane 15 of every row holds its total
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const V total = __shfl(part, 16 * g + 15, WAVE);
-                    if (lane == owner[g]) acc[h] = total;
-                }
-            }
+            // rows longer than that: by 16-lane groups, the longest by the whole wave (lean_long_rows)
+            if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), __ballot(len[h] > LEAN_SERIAL) != 0ull))
+                lean_long_rows<V>(s_prod_raw, pshift + e0[h], len[h], tid & (WAVE - 1), acc[h]);
             if (r0 == 0 && h == 0) MSPMV_LEAN_TR(11);
             if (valid[h]) {
                 const int r = r0 + h * BLOCK + tid;
@@ -2373,6 +2413,7 @@ __device__ __forceinline__ void compact_realign(Vec4<T> &c, int s)
 typedef int int4v_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float float4v_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef double double2v_u __attribute__((ext_vector_type(2), aligned(8)));
+typedef int int2v_u __attribute__((ext_vector_type(2), aligned(4)));
 
 // loads through a 32-bit unsigned BYTE offset from a uniform base (global_load ... v_off, s[base]: one shift, no 64-bit address
 // arithmetic per lane).  The dispatcher takes the compact kernel only when every array is < 4 GB (mspmv_api.hip).
@@ -2406,7 +2447,8 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     // (everything the cold sections at the end touch is declared up here: a goto may not jump past an initialisation)
     Vec4<int> col[CPT]; Vec4<V> val[CPT];
     int rov[RO_ROUNDS];
-    int r0, r, start, len, vre; bool valid; V acc; const V *src;
+    int r0, r, start, len; bool valid; V acc; const V *src;
+    int2v vw0, vw1;
     // ---- hints (scalar cache; the tile index is uniform).  Request and wait in ONE asm statement (see tile_kernel_snap)
     int4v hc; int2v hr;
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
@@ -2418,14 +2460,15 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     const int d0 = tile * TILE, d1 = d0 + TILE < total ? d0 + TILE : total;
     const int y0 = d0 - x0, y1 = d1 - x1;
     const int tile_rows = x1 - x0, tile_nnz = rs1 - rs0;
-    // A closed lean tile whose hints keep every access below inside the arrays and the LDS tile (anything may be in the hints):
-    //   stored y's are the derived ones; both boundaries snap (0 <= y - rs <= HEAD_MAX); 0 <= x0 <= x1 <= rows; 0 <= rs0 <= rs1 <= nnz;
-    //   the tile fits (rows <= TILE, nonzeros <= TILE + HEAD_MAX); nonzeros <= lean_avg * rows (the general kernel's `lean`); x in memory
-    const bool take = (hc.y == y0) & (hc.w == y1) & ((unsigned) (y0 - rs0) <= (unsigned) HEAD_MAX) & ((unsigned) (y1 - rs1) <= (unsigned) HEAD_MAX) &
-                      ((unsigned) x0 <= (unsigned) x1) & ((unsigned) x1 <= (unsigned) p.rows) & ((unsigned) rs0 <= (unsigned) rs1) &
-                      ((unsigned) rs1 <= (unsigned) p.nnz) & ((unsigned) tile_rows <= (unsigned) TILE) &
-                      ((unsigned) tile_nnz <= (unsigned) (TILE + HEAD_MAX)) & ((unsigned) tile_nnz <= (unsigned) lean_avg * (unsigned) tile_rows) &
-                      (p.x_lds == 0) & (num_tiles > 1);
+    // A closed lean tile (exactly the general kernel's `lean`: both boundaries snap, nonzeros <= lean_avg * rows) -- judged on the HINTS,
+    // which may hold anything: what keeps every access before the verdict inside the arrays is 0 <= x0, x1 <= rows and 0 <= rs0 <= nnz
+    // (chunk addresses are clamped from above, row-offset indices lie in [x0, x1], LDS is written at thread positions only); the
+    // verdict then either proves the hints to be THE merge-path points of d0 and d1 -- and with them everything else assumed here:
+    // x0 <= x1, rs0 <= rs1 <= nnz, the tile's sizes -- or sends the block to the general body before LDS is read or y written.
+    // (x in memory and more than one tile: the dispatcher launches this variant only then)
+    const bool take = ((unsigned) (y0 - rs0) <= (unsigned) HEAD_MAX) & ((unsigned) (y1 - rs1) <= (unsigned) HEAD_MAX) &
+                      ((unsigned) x0 <= (unsigned) p.rows) & ((unsigned) x1 <= (unsigned) p.rows) & ((unsigned) rs0 <= (unsigned) p.nnz) &
+                      ((unsigned) tile_nnz <= (unsigned) lean_avg * (unsigned) tile_rows);
     // ONE way out to the general body (the caller's code behind this function): `go` stays 0 when the tile is not taken or its hints
     // fail the verification, and is tested once, after the staging -- two exits would be merged by the compiler through flag
     // variables and a common block at the far end of the kernel, which puts two far jumps into the fast lane
@@ -2436,12 +2479,16 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     const int a0c = a0 < nz4 ? a0 : nz4;
     const int n_ro = tile_rows + 1;
     if (__builtin_expect(!take, 0)) goto staged;
-    // ---- the four row offsets that decide whether (x0, rs0), (x1, rs1) are the points of diagonals d0, d1: requested first
-    vre = 0;
-    if (lane < 4) {
-        int idx = (lane < 2 ? x0 : x1) - 1 + (lane & 1);               // x0 - 1, x0, x1 - 1, x1
-        idx = idx < 0 ? 0 : idx >= p.rows ? p.rows - 1 : idx;           // (rows >= 3 on this path)
-        vre = compact_ld<int>(p.row_end, (unsigned) idx << 2);
+    // ---- the four row offsets that decide whether (x0, rs0), (x1, rs1) are the points of diagonals d0, d1: two scalar loads of the
+    // pairs row_end[x - 1], row_end[x] (uniform addresses; row_end[-1] = row_offsets[0] exists, and a boundary at x == rows reads
+    // the pair one lower), requested first, looked at in the shadow of the gathers
+    {
+        const int b0 = x0 - 1 < p.rows - 2 ? x0 - 1 : p.rows - 2, b1 = x1 - 1 < p.rows - 2 ? x1 - 1 : p.rows - 2;      // (rows >= 3)
+        // (plain loads on uniform addresses of memory the kernel has not written: the compiler makes them s_load_dwordx2 and keeps
+        //  track of them itself -- a hand-issued scalar load whose wait sits in another asm statement leaves its destination
+        //  registers open to copies while the load is in flight)
+        vw0 = *reinterpret_cast<const int2v_u *>(p.row_end + b0);
+        vw1 = *reinterpret_cast<const int2v_u *>(p.row_end + b1);
     }
     // ---- the tile's nonzeros: 4-element chunks aligned in array index space, clamped to the array's last full chunk
 #pragma unroll
@@ -2468,13 +2515,16 @@ aligned:
             for (int i = 0; i < 4; ++i) xv[k][i] = compact_ld<V>(p.x, (unsigned) col[k].get(i) * (unsigned) sizeof(V));
         // ---- the verdict on the hints, in the shadow of the gathers (scalar: v_readlane).  Acted upon after the barrier -- a branch
         // here would hold the gathers back behind it --: until then nothing but registers and LDS is touched
-        const int before0 = __builtin_amdgcn_readlane(vre, 0), at0 = __builtin_amdgcn_readlane(vre, 1);
-        const int before1 = __builtin_amdgcn_readlane(vre, 2), at1 = __builtin_amdgcn_readlane(vre, 3);
+        const int before0 = x0 == p.rows ? vw0.y : vw0.x, at0 = vw0.y, before1 = x1 == p.rows ? vw1.y : vw1.x, at1 = vw1.y;
         // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
-        // (written with integer selects: the tests stay on the scalar unit)
+        // (written with integer selects: the tests stay on the scalar unit); and the stored y's are the derived ones (what
+        //  mspmv_debug_read_tiles reports)
         const int lim0 = x0 < p.rows ? at0 : (d0 == total ? 0x7fffffff : -1);
         const int lim1 = x1 < p.rows ? at1 : (d1 == total ? 0x7fffffff : -1);
-        const bool verdict = ((x0 > 0 ? before0 : 0) == rs0) & (y0 <= lim0) & ((x1 > 0 ? before1 : 0) == rs1) & (y1 <= lim1);
+        const bool verdict = ((x0 > 0 ? before0 : 0) == rs0) & (y0 <= lim0) & ((x1 > 0 ? before1 : 0) == rs1) & (y1 <= lim1) & (hc.y == y0) & (hc.w == y1);
+        // (nothing open at the end of a closed tile: what mspmv_debug_read_tiles reports.  By the last wave, here in the shadow of the
+        //  gathers; a tile that fails the verdict has it overwritten by the general body)
+        if (__builtin_amdgcn_readfirstlane(tid) >= BLOCK - WAVE) { if (tid == BLOCK - 1) { Carry<V> c; c.key = x1; c.value = (V) 0; carries[tile] = c; } }
         // ---- LDS: row offsets as they are, products at their raw positions (element e of the array -> slot e - a0)
         s_ro[tid] = rov[0];
         if (BLOCK < n_ro) s_ro[tid + BLOCK] = rov[1];
@@ -2493,15 +2543,13 @@ staged:
     go = __builtin_amdgcn_readfirstlane(go);
     if (__builtin_expect(go == 0, 0)) return;                          // (every wave alike; the general body starts from scratch)
     // ---- row by row: consume_tile_rows' arithmetic (left to right from +0.0; > LEAN_SERIAL: 16-lane groups), one row per thread and round
-    if (tid == BLOCK - 1) { Carry<V> c; c.key = x1; c.value = (V) 0; carries[tile] = c; }       // (nothing open: what mspmv_debug_read_tiles reports)
-    r0 = 0;
+    r0 = __builtin_amdgcn_readfirstlane(tid) & ~(WAVE - 1);             // (the wave's first row of the round: scalar -- the compiler has to SEE that the test below is wave-uniform)
 next_round:
     // (the wave's program ENDS here -- s_endpgm, not a return: a return value is merged with the general body's exit and the
-    //  reduction then sits behind two far jumps)
-    //  (readfirstlane: the compiler has to SEE that the test is wave-uniform -- an exit it takes for divergent is routed through
-    //   flag variables and a common exit block, with the same effect)
-    if (r0 + (__builtin_amdgcn_readfirstlane(tid) & ~(WAVE - 1)) >= tile_rows) __builtin_amdgcn_endpgm();   // this wave's rows are done
-    r = r0 + tid;
+    //  reduction then sits behind two far jumps.  The test has to be visibly wave-uniform for the same reason: an exit the compiler
+    //  takes for divergent is routed through flag variables and a common exit block)
+    if (r0 >= tile_rows) __builtin_amdgcn_endpgm();                    // this wave's rows are done
+    r = r0 + lane;
     valid = r < tile_rows;
     {
         const int rr = valid ? r : 0;                                   // (row 0 exists: tile_rows > 0 here)
@@ -2550,39 +2598,8 @@ longer_rows:
 #pragma unroll
         for (int j = 0; j < LEAN_BATCH; ++j) w[j] = src[LEAN_BATCH + j];
         CompactChain<V>::add8(acc, w, len, LEAN_BATCH);
-        // rows longer than LEAN_SERIAL: four at a time, each by the 16 lanes of one DPP row (as consume_tile_rows)
-        unsigned long long pending = __ballot(len > LEAN_SERIAL);
-        while (pending != 0ull) {                                       // wave-uniform
-            int owner[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                owner[g] = pending != 0ull ? __ffsll((long long) pending) - 1 : -1;
-                pending &= pending - 1ull;
-            }
-            const int grp = lane_c >> 4, j = lane_c & 15;
-            const int own = grp == 0 ? owner[0] : grp == 1 ? owner[1] : grp == 2 ? owner[2] : owner[3];
-            const int g_start = __shfl(start, own < 0 ? 0 : own, WAVE);
-            const int g_len_any = __shfl(len, own < 0 ? 0 : own, WAVE);
-            const int g_len = own < 0 ? 0 : g_len_any;
-            const V *gsrc = s_prod + (g_start - a0);
-            V part = (V) 0;
-            for (int k = j; __ballot(k < g_len) != 0ull; k += 64) {
-                V u4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) u4[u] = k + 16 * u < g_len ? gsrc[k + 16 * u] : (V) 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) part += u4[u];
-            }
-            part += dpp_move<0x111, 0xf>((V) 0, part);                 // row_shr:1
-            part += dpp_move<0x112, 0xf>((V) 0, part);                 // row_shr:2
-            part += dpp_move<0x114, 0xf>((V) 0, part);                 // row_shr:4
-            part += dpp_move<0x118, 0xf>((V) 0, part);                 // row_shr:8  -> lane 15 of every row holds its total
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const V total_g = __shfl(part, 16 * g + 15, WAVE);
-                if (lane_c == owner[g]) acc = total_g;
-            }
-        }
+        // rows longer than LEAN_SERIAL: the code consume_tile_rows runs for them
+        if (__ballot(len > LEAN_SERIAL) != 0ull) lean_long_rows<V>(s_prod, start - a0, len, lane_c, acc);
     }
     goto store_row;
 }
@@ -2805,9 +2822,27 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const int4v *__restrict
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x5a5a5a5a) g_probe_sink = 1;        // (keeps the loads; practically never true)
 }
 
+// ONE runtime call per launch.  `kernel<<<...>>>(...)` / hipLaunchKernelGGL is three (push the launch configuration, pop it in the stub,
+// hipLaunchKernel) and leaves its status to a fourth (hipGetLastError); every entry into the HIP runtime costs the calling thread
+// 50-100 ns, and the reference's timing loop is bound by the enqueueing thread below a few hundred tiles (tools/ab_driver: host
+// enqueue time per call == loop time per call there).  The arguments are converted to the kernel's exact parameter types.
+template <typename... P, typename... A, size_t... I>
+static inline hipError_t launch_exact_impl(void (*kernel)(P...), dim3 grid, dim3 block, size_t dyn_lds, hipStream_t stream, std::index_sequence<I...>, A &&...a)
+{
+    std::tuple<P...> vals{static_cast<P>(a)...};
+    void *ptrs[] = {static_cast<void *>(&std::get<I>(vals))...};
+    return hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, dyn_lds, stream);
+}
+template <typename... P, typename... A>
+static inline hipError_t launch_exact(void (*kernel)(P...), dim3 grid, dim3 block, size_t dyn_lds, hipStream_t stream, A &&...a)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "one argument per kernel parameter");
+    return launch_exact_impl(kernel, grid, block, dyn_lds, stream, std::index_sequence_for<P...>{}, static_cast<A &&>(a)...);
+}
+
 // host side of the compact variant (defined and instantiated in mspmv_compact.hip, the translation unit compiled for it)
 template <typename V>
-void launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStream_t stream, Coord *coords, int *rstart, int num_tiles,
+hipError_t launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStream_t stream, Coord *coords, int *rstart, int num_tiles,
                          const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg);
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,

@@ -913,16 +913,20 @@ def test_tiny_x_is_gathered_from_lds(M, prec, cols):
         csr = random_csr(rng, rows, cols, rng.integers(0, hi, rows), dtype)
         x = rng.uniform(-1, 1, cols).astype(dtype)
         got = {}
-        for flags in (0, 0x80000, 16, 16 | 0x80000):
+        # ("compact": the default for a problem of one block generation -- the compact front end gathers even a tiny x from memory;
+        #  every other entry runs with it switched off, so that the small-problem kernel's LDS copy is what is compared)
+        for flags in ("compact", 0, 0x80000, 16, 16 | 0x80000):
             try:
-                M.set_tuning(vb, 0, 0, flags)
+                M.set_compact_tiles(0 if flags == "compact" else -1)
+                M.set_tuning(vb, 0, 0, 0 if flags == "compact" else flags)
                 y, ws = run_gpu(M, csr, x)
                 y2, _ = run_gpu(M, csr, x, alpha=1.5, beta=0.0)
             finally:
-                M.set_tuning(vb)
+                M.set_tuning(vb); M.set_compact_tiles(0)
             check_strict(M, csr, x, y)
             got[flags] = (y, y2)
         assert np.array_equal(got[0][0], got[0x80000][0]) and np.array_equal(got[0][1], got[0x80000][1])
+        assert np.array_equal(got["compact"][0], got[0][0]) and np.array_equal(got["compact"][1], got[0][1])
         assert np.array_equal(got[16][0], got[16 | 0x80000][0]) and np.array_equal(got[16][1], got[16 | 0x80000][1])
 
 

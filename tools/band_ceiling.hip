@@ -347,7 +347,7 @@ int main(int argc, char** argv)
 
     printf("## slice: ONE stream of (col, val) + every gather folded into an L2-sized table (the prepared plan's ceiling)\n");
     printf("##        plain | stream(t+1) requested before gathers(t) | gathers(t) first, then stream(t+1), wait for the gathers only\n");
-    for (unsigned mask : {0x3ffffu, 0xfffffu}) for (int per_cu : {2, 4, 8}) {
+    for (unsigned mask : {0x3ffffu, 0x7ffffu, 0xfffffu}) for (int per_cu : {2, 4, 8}) {      // (1.05, 2.10, 4.19 MB: the plan's slices are 3.1 MB at 4 bands, 1.6 MB at 8)
         const int grid = per_cu * cus;
         float a = time_ms([&] { hipLaunchKernelGGL((k_slice<0, true>), dim3(grid), dim3(BLOCK), 0, 0, c4, v4, x, n4, mask, out); });
         float b = time_ms([&] { hipLaunchKernelGGL((k_slice<1, true>), dim3(grid), dim3(BLOCK), 0, 0, c4, v4, x, n4, mask, out); });

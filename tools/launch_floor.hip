@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
+#include <cstring>
+#include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int TRIPS, int LDS_BYTES, bool SCALAR_FIRST>
@@ -48,6 +51,43 @@ float loop_us(int blocks, const int *table, int *out, int mask, int iters)
     return best * 1000.0f / iters;
 }
 
+// ---- the HOST side of a launch: the reference's loop is bound by the enqueueing thread below ~300 tiles (tools/ab_driver: host
+// enqueue time per call == loop time per call there), so what a call costs on the host is what the loop measures.  An empty kernel
+// with the one-launch kernel's argument block (176 bytes), enqueued 2000 times through (a) hipLaunchKernelGGL, (b) hipModuleLaunchKernel
+// on the hipFunction_t of the same kernel (hipGetFuncBySymbol) with the arguments as ONE pre-packed buffer (HIP_LAUNCH_PARAM_BUFFER_POINTER)
+struct BigArgs { void *a[9]; int i[6]; double d[2]; void *b[6]; int j[6]; };
+__global__ __launch_bounds__(256) void big_args_kernel(BigArgs g) { if (g.i[0] == 0x7fffffff) *(int *) g.a[0] = g.j[5]; }
+
+static void host_side()
+{
+    BigArgs g; memset(&g, 0, sizeof(g));
+    printf("\nhost enqueue / loop time (us per call, 2000 calls, best of 5 loops), empty kernel with a %zu-byte argument block, 28 blocks\n", sizeof(g));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipFunction_t fn = nullptr;
+    const hipError_t got = hipGetFuncBySymbol(&fn, (const void *) big_args_kernel);
+    for (int mode = 0; mode < 2; ++mode) {
+        if (mode == 1 && (got != hipSuccess || !fn)) { printf("hipGetFuncBySymbol unavailable (%d)\n", (int) got); break; }
+        double best_host = 1e30; float best_loop = 1e30f;
+        for (int rep = 0; rep < 6; ++rep) {
+            CK(hipEventRecord(a, 0));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 2000; ++i) {
+                if (mode == 0) big_args_kernel<<<28, 256>>>(g);
+                else {
+                    size_t sz = sizeof(g);
+                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &g, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+                    CK(hipModuleLaunchKernel(fn, 28, 1, 1, 256, 1, 1, 0, 0, nullptr, extra));
+                }
+            }
+            const double host = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+            CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            if (rep > 0) { best_host = std::min(best_host, host); best_loop = std::min(best_loop, ms * 1000.0f / 2000); }
+        }
+        printf("%-72s host %.2f  loop %.2f\n", mode == 0 ? "hipLaunchKernelGGL (<<<>>>)" : "hipModuleLaunchKernel(hipGetFuncBySymbol(kernel), packed argument buffer)", best_host, best_loop);
+    }
+}
+
 int main()
 {
     const int n = 1 << 22, mask = n - 1;
@@ -70,5 +110,6 @@ int main()
     ROW("3 trips (first scalar) + store", 3, 0, true);
     ROW("3 trips (first scalar) + LDS exchange/barrier + store, 20.5 KB", 3, 20992, true);
     ROW("4 dependent vector trips + store", 4, 0, false);
+    host_side();
     return 0;
 }
