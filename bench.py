@@ -451,6 +451,9 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             else:
                 live_tr, live_src = live_traffic(label)
             tr = live_tr if live_tr is not None else rep_tr
+            if tr is None:
+                rec["roofline"]["traffic"] = None
+                rec["roofline"]["traffic_source"] = f"not available: live counters: {live_src}; no committed passes for this label"
             if tr is not None:
                 rec["roofline"]["traffic"] = tr
                 rec["roofline"]["traffic_source"] = live_src if live_tr is not None else src + f" [live counters: {live_src}]"
@@ -774,12 +777,24 @@ def main():
     op_sync()
     prof = M.profile_end()
 
-    # ---- N > 1 through the C operator: the same steps with every rank's columns renumbered by reference count ----------------
+    # ---- N > 1 through the C operator: what the step's exchange alone takes (events around it, per rank), and the same steps with the
+    # parts' hot-column plans switched OFF (they are automatic since round 5: the headline above ran with whatever the plan decided)
     hot = None
+    exchange_ms = None
+    if plan is not None:
+        ex = []
+        for _ in range(5):
+            op(); op_sync()
+            try:
+                ex.append(plan.exchange_ms(0))
+            except Exception:  # noqa: BLE001
+                break
+        exchange_ms = sum(ex) / len(ex) if ex else None
     if plan is not None and workload == "c5":
+        hot_parts = int(plan.info().get("hot_parts", 0))
         torch.cuda.synchronize(); th0 = time.perf_counter()
-        plan.hot_columns(True)
-        op_sync(); hot_setup_ms = (time.perf_counter() - th0) * 1e3
+        plan.hot_columns(not hot_parts)            # the other setting: off when the plan chose them, on when it did not
+        op_sync(); switch_ms = (time.perf_counter() - th0) * 1e3
         for _ in range(max(2, min(args.warmup, 5))):
             op()
         barrier()
@@ -787,13 +802,19 @@ def main():
         for _ in range(args.steps):
             op()
         barrier()
-        th = torch.tensor([time.perf_counter() - th0, hot_setup_ms], dtype=torch.float64, device=dev)
+        th = torch.tensor([time.perf_counter() - th0, switch_ms], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(th, op=dist.ReduceOp.MAX)
-        hot_ms = float(th[0].item()) * 1e3 / args.steps
-        hot = {"api": "mspmv_mg_plan_hot_columns (opt-in; every rank renumbers its part's columns by reference count once; x permuted per step, inside the timed loop)",
-               "setup_ms_max_over_ranks": round(float(th[1].item()), 2), "ms_per_step": round(hot_ms, 5),
-               "value": round(2.0 * nnz_total / (hot_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
+        other_ms = float(th[0].item()) * 1e3 / args.steps
+        hot = {"api": "mspmv_mg_plan_hot_columns: AUTOMATIC by default (decided per part when its matrix is attached: x beyond the Infinity Cache and columns "
+                      "that come back, mspmv_csrmv_hotcols_skew); x permuted per step, inside the timed loop; y bit for bit the same either way",
+               "chosen_by_the_plan_on_rank0": bool(hot_parts), "headline_ran_with_hot_columns": bool(hot_parts),
+               "this_record_is": ("the same steps WITHOUT the hot-column plans (switched off for this leg)" if hot_parts
+                                  else "the same steps WITH the hot-column plans forced on (the plan had not chosen them)"),
+               "ms_per_step": round(other_ms, 5), "value": round(2.0 * nnz_total / (other_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
+               ("release_ms" if hot_parts else "setup_ms") + "_max_over_ranks": round(float(th[1].item()), 2)}
+        plan.hot_columns(-1)                       # back to the default for what follows
+        op_sync()
 
     # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
     single = None
@@ -852,8 +873,8 @@ def main():
     per_rank = None
     if dist is not None:
         # per-rank kernel times and what is left of a step after them (launch gaps + the carry exchange + the owner's add)
-        mine = torch.tensor([prof["search_ms"], prof["tile_ms"], prof["fixup_ms"], elapsed_local * 1e3 / args.steps, float(local_nnz)],
-                            dtype=torch.float64, device=dev)
+        mine = torch.tensor([prof["search_ms"], prof["tile_ms"], prof["fixup_ms"], elapsed_local * 1e3 / args.steps, float(local_nnz),
+                             float("nan") if exchange_ms is None else exchange_ms], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rows_ = torch.stack(allr).cpu().numpy()
@@ -863,7 +884,11 @@ def main():
                     "exchange_and_gaps_ms_max": round(float((rows_[:, 3] - kern).max()), 5),
                     "exchange_and_gaps_ms_min": round(float((rows_[:, 3] - kern).min()), 5),
                     "nnz_per_rank_max": int(rows_[:, 4].max()), "nnz_per_rank_min": int(rows_[:, 4].min()),
-                    "note": "per rank: hipEvent averages of its kernels and its own wall time per step; exchange_and_gaps = step - kernels"}
+                    "exchange_ms_max": None if np.isnan(rows_[:, 5]).all() else round(float(np.nanmax(rows_[:, 5])), 5),
+                    "exchange_ms_min": None if np.isnan(rows_[:, 5]).all() else round(float(np.nanmin(rows_[:, 5])), 5),
+                    "note": "per rank: hipEvent averages of its kernels and its own wall time per step; exchange_and_gaps = step - kernels (inferred); "
+                            "exchange_ms = hipEvents on the rank's stream right after its SpMV and right after the all-gather + the owner's add "
+                            "(mspmv_mg_plan_exchange_ms, 5 separate steps): the exchange alone, the wait for slower ranks included"}
         dist.barrier()
     if rank == 0:
         gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9

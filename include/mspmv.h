@@ -187,6 +187,14 @@ int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_
  * value_bytes to every call, asynchronous on `stream`); d_values / d_row_offsets passed to _apply must be the arrays
  * the plan was built for.  No reference counterpart (its HYB column is the precedent for set-up timed apart,
  * gpu_spmv.cu:106-257). ---- */
+/* Would the plan pay?  A cheap look at the column indices (synchronous: one small kernel + a 512-byte copy): 64 windows of 2048
+ * consecutive nonzeros spread over the matrix; *median_lines_per_2048 = the median number of DISTINCT 128-byte lines of x a window
+ * touches (-1: fewer than 2048 nonzeros), *wide_windows = how many windows span >= 3/4 of the columns.  Uniformly spread columns give
+ * ~2000 (nothing to concentrate), stencils and bands < 200 (their gathers hit the caches as they are), scale-free matrices 1200-1850:
+ * columns that come back -- the case the plan is for.  mspmv_mg_plan_* builds the plan by itself when x is beyond the Infinity
+ * Cache and 512 <= median < 1905 with >= 48 wide windows (mspmv_mg_plan_hot_columns). */
+int mspmv_csrmv_hotcols_skew(const int32_t *d_column_indices, int32_t cols, int32_t nnz, int32_t value_bytes, mspmv_stream_t stream,
+                             int32_t *median_lines_per_2048, int32_t *wide_windows);
 int mspmv_csrmv_hotcols_size(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, size_t *plan_bytes);
 int mspmv_csrmv_hotcols_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets,
                               const int32_t *d_column_indices, int32_t rows, int32_t cols, int32_t nnz,
@@ -404,7 +412,7 @@ typedef struct mspmv_mg_plan mspmv_mg_plan_t;
 #define MSPMV_MG_EXCHANGE_IPC  3
 
 typedef struct mspmv_mg_info {
-    int32_t parts, local_parts, exchange /* backend in effect */, value_bytes, replicas, reserved;
+    int32_t parts, local_parts, exchange /* backend in effect */, value_bytes, replicas, hot_parts /* local parts running the hot-column plan */;
     int64_t rows, cols;
     uint64_t carry_bytes_per_step;       /* payload of the carry exchange: parts * value_bytes        */
     uint64_t allgather_bytes_per_step;   /* payload of y -> x: rows * value_bytes to every OTHER GPU  */
@@ -425,12 +433,22 @@ void *mspmv_mg_plan_x(mspmv_mg_plan_t *plan, int32_t local_index);
 void *mspmv_mg_plan_y(mspmv_mg_plan_t *plan, int32_t local_index);
 mspmv_stream_t mspmv_mg_plan_stream(mspmv_mg_plan_t *plan, int32_t local_index);
 int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info);
-/* enable != 0: every local part's columns are renumbered by reference count (the hot-column plan above, built once per
- * part in plan-owned storage of 4 * local_nnz + 16 * cols bytes; every part must be attached) and mspmv_mg_csrmv permutes
- * x into the part's numbering before its SpMV -- for a scale-free matrix with an x far beyond the caches (config 5).
- * Results are bit for bit the ones without it (parts that would take the column-band passes excepted, as above).
- * enable == 0 releases the storage. */
+/* The hot-column plan of the parts (above: columns renumbered by reference count, built once per part in plan-owned storage of
+ * 4 * local_nnz + 16 * cols bytes; mspmv_mg_csrmv permutes x into the part's numbering before its SpMV):
+ *   enable < 0   AUTOMATIC, the default of every plan: decided per part when its matrix is attached (mspmv_mg_plan_set_part) -- a
+ *                part gets the plan when the x replica is beyond the 256 MB Infinity Cache (cols * value_bytes) AND the on-device
+ *                sample of its column indices says the columns come back (mspmv_csrmv_hotcols_skew: 512 <= median distinct lines per
+ *                2048 nonzeros < 1905, >= 48 of 64 windows spanning most of x): config 5, every part 33 -> 21 ms-equivalent.  Uniformly
+ *                spread columns, stencils / bands, an x that fits the cache, or a part that cannot afford the storage: no plan.
+ *   enable > 0   always (every local part; hipErrorOutOfMemory if one cannot)
+ *   enable == 0  never; releases the storage
+ * y is bit for bit the same either way (parts that would take the column-band passes excepted, as above); mspmv_mg_plan_info reports
+ * how many local parts run it (hot_parts).  MSPMV_FAKE_INFINITY_CACHE_MIB in the environment overrides the cache size (tests). */
 int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable);
+/* Milliseconds the EXCHANGE of the last mspmv_mg_csrmv took on local part `local_index` -- hipEvents on the part's stream right after
+ * its SpMV and right after its share of the exchange (the all-gather / the peers' events, the owner's add): what a step costs beyond
+ * its kernels, measured rather than inferred; includes the time this part waited for slower parts.  Synchronises with the step. */
+int mspmv_mg_plan_exchange_ms(mspmv_mg_plan_t *plan, int32_t local_index, float *ms);
 int mspmv_mg_csrmv(mspmv_mg_plan_t *plan);
 int mspmv_mg_allgather_rows(mspmv_mg_plan_t *plan);
 int mspmv_mg_synchronize(mspmv_mg_plan_t *plan);

@@ -2645,6 +2645,7 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
     if (snap_tr && tid == 0) snap_tr[0] = t_entry;
 #endif
     // (epoch_words == lb.error, the same two words under a second name -- hence no __restrict__ on it)
+    static_assert(sizeof(coords) + sizeof(rstart) + sizeof(epoch_words) + sizeof(num_tiles) + sizeof(xcd_chunk_log2) == 32, "the five leading arguments fill the 8 preloaded dwords");
     // THE FIRST FIVE ARGUMENTS -- all the hint request needs -- are in SGPRs when the wave starts (kernel-argument preload, 8 dwords:
     // the Makefile's -amdgpu-kernarg-preload-count=8), the tile index below is branch-free scalar arithmetic on them, and the other
     // arguments are pinned behind the hint request: the block's first memory round trip is the hints AND the rest of the kernel

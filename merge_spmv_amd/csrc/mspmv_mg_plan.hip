@@ -233,6 +233,9 @@ struct Part {
     void **push_table = nullptr;          // device array: this part's row range inside every replica of x
     hipEvent_t done = nullptr, applied = nullptr, pushed = nullptr;
     bool applied_valid = false, pushed_valid = false, done_valid = false;
+    hipEvent_t ex_begin = nullptr, ex_end = nullptr;    // timing events around the step's exchange alone (mspmv_mg_plan_exchange_ms)
+    bool ex_valid = false;
+    int hot_median = -1, hot_wide = 0;                  // what the automatic hot-column decision saw (mspmv_csrmv_hotcols_skew)
     ncclComm_t comm = nullptr;
     void *hot = nullptr; size_t hot_bytes = 0;      // hot-column plan of the part (mspmv_mg_plan_hot_columns): its own temp, indices, x
     // IPC backend
@@ -260,7 +263,11 @@ struct mspmv_mg_plan {
     std::vector<Part> local;
     std::vector<Replica> replicas;
     unsigned long long steps = 0;
+    int hot_mode = -1;                    // mspmv_mg_plan_hot_columns: -1 automatic (default), 0 never, 1 always
 };
+
+static int part_hot(mspmv_mg_plan *plan, Part &q, bool want);
+static int part_hot_auto(mspmv_mg_plan *plan, Part &q);
 
 namespace {
 
@@ -311,6 +318,7 @@ int run_spmv(mspmv_mg_plan *plan)
                                (int32_t) plan->cols, q.local_nnz, (V) 1, (V) 0, false, q.stream, 0, ex);
         if (st != 0) return st;
         MG_HIP(hipEventRecord(q.done, q.stream)); q.done_valid = true;
+        MG_HIP(hipEventRecord(q.ex_begin, q.stream));       // (the exchange of this step begins here on this part's stream ...)
         if (ipc) {
             const int vb = (int) sizeof(V);
             // "my SpMV of this step has read x" -> every peer (a later row all-gather waits for it before overwriting x); this
@@ -325,10 +333,14 @@ int run_spmv(mspmv_mg_plan *plan)
                                    reinterpret_cast<const unsigned long long *const *>(q.ipc_tables + 2 * MSPMV_MG_MAX_PARTS),
                                    reinterpret_cast<unsigned long long *const *>(q.ipc_tables + 3 * MSPMV_MG_MAX_PARTS), q.n_take, step, q.ipc_error);
             MG_HIP(hipGetLastError());
+            MG_HIP(hipEventRecord(q.ex_end, q.stream)); q.ex_valid = true;
         }
     }
     if (ipc) { ++plan->steps; return 0; }
-    if (plan->parts == 1 && plan->exchange != MSPMV_MG_EXCHANGE_RCCL) { ++plan->steps; return 0; }
+    if (plan->parts == 1 && plan->exchange != MSPMV_MG_EXCHANGE_RCCL) {
+        for (Part &q : plan->local) { MG_HIP(hipSetDevice(q.device)); MG_HIP(hipEventRecord(q.ex_end, q.stream)); q.ex_valid = true; }
+        ++plan->steps; return 0;
+    }
     // 2. the one exchange + the owners' adds (a one-part RCCL plan still issues its all-gather: that is how a
     //    single-GPU box exercises the RCCL path end to end)
     if (plan->exchange == MSPMV_MG_EXCHANGE_RCCL) {
@@ -352,6 +364,8 @@ int run_spmv(mspmv_mg_plan *plan)
         MG_HIP(hipGetLastError());
         MG_HIP(hipEventRecord(q.applied, q.stream)); q.applied_valid = true;
     }
+    // (... and ends here: the all-gather / the peers' events and the owner's add, nothing else)
+    for (Part &q : plan->local) { MG_HIP(hipSetDevice(q.device)); MG_HIP(hipEventRecord(q.ex_end, q.stream)); q.ex_valid = true; }
     ++plan->steps;
     return 0;
 }
@@ -425,6 +439,8 @@ int destroy(mspmv_mg_plan *plan)
         (void) hipSetDevice(q.device);
         if (q.comm && rccl().ok) (void) rccl().CommDestroy(q.comm);
         if (q.done) (void) hipEventDestroy(q.done);
+        if (q.ex_begin) (void) hipEventDestroy(q.ex_begin);
+        if (q.ex_end) (void) hipEventDestroy(q.ex_end);
         if (q.applied) (void) hipEventDestroy(q.applied);
         if (q.pushed) (void) hipEventDestroy(q.pushed);
         (void) hipFree(q.temp); (void) hipFree(q.y); (void) hipFree(q.carries); (void) hipFree(q.src_table); (void) hipFree(q.push_table);
@@ -538,7 +554,8 @@ int mspmv_mg_plan_create(mspmv_mg_plan_t **out, int32_t parts, int32_t local_par
         if (hipMemsetAsync(q.y, 0, (size_t) q.local_rows * vb, q.stream) != hipSuccess) return fail(kErrInvalid);
         if (hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q.applied, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&q.pushed, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&q.pushed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&q.ex_begin) != hipSuccess || hipEventCreate(&q.ex_end) != hipSuccess)
             return fail(hipErrorOutOfMemory);
         if (exchange == MSPMV_MG_EXCHANGE_RCCL) {
             if (hipMalloc(&q.carries, std::max<size_t>((size_t) parts * vb, 256)) != hipSuccess) return fail(hipErrorOutOfMemory);
@@ -641,6 +658,8 @@ int mspmv_mg_plan_set_part(mspmv_mg_plan_t *plan, int32_t i, const void *d_value
         st = csrmv_call<double>(q.temp, &tb, nullptr, q.offsets, nullptr, nullptr, nullptr, q.local_rows, 0, q.local_nnz, 1.0, 0.0, false, q.stream, 0, ex);
     if (st == 0) st = (int) hipStreamSynchronize(q.stream);
     q.attached = st == 0;
+    // a new matrix: whatever hot-column plan the part had belonged to the old one; the plan's mode decides about a new one
+    if (q.attached) { (void) part_hot(plan, q, false); st = plan->hot_mode < 0 ? part_hot_auto(plan, q) : plan->hot_mode ? part_hot(plan, q, true) : 0; }
     (void) hipSetDevice(prev);
     return st;
 }
@@ -761,28 +780,77 @@ int mspmv_mg_plan_ipc_import(mspmv_mg_plan_t *plan, const void *blobs, int32_t c
     return 0;
 }
 
+// the Infinity Cache the automatic hot-column decision compares x with (MSPMV_FAKE_INFINITY_CACHE_MIB in the environment overrides it,
+// read once: tests, other parts)
+static long long infinity_cache_bytes()
+{
+    static const long long v = [] { const char *e = getenv("MSPMV_FAKE_INFINITY_CACHE_MIB"); const double m = e ? atof(e) : 0; return m > 0 ? (long long) (m * 1048576.0) : (256LL << 20); }();
+    return v;
+}
+
+// one part's hot-column plan: built (want) or dropped; the part's stream is synchronised on the way
+static int part_hot(mspmv_mg_plan *plan, Part &q, bool want)
+{
+    (void) hipSetDevice(q.device);
+    (void) hipStreamSynchronize(q.stream);
+    if (!want) { (void) hipFree(q.hot); q.hot = nullptr; q.hot_bytes = 0; return 0; }
+    if (q.hot) return 0;
+    size_t bytes = 0;
+    int st = mspmv_csrmv_hotcols_size(q.local_rows, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, &bytes);
+    if (st != 0) return st;
+    if (hipMalloc(&q.hot, bytes) != hipSuccess) { (void) hipGetLastError(); q.hot = nullptr; return hipErrorOutOfMemory; }
+    q.hot_bytes = bytes;
+    st = mspmv_csrmv_hotcols_build(q.hot, bytes, q.offsets, q.cols, q.local_rows, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, q.stream, 0);
+    if (st == 0) st = (int) hipStreamSynchronize(q.stream);
+    if (st != 0) { (void) hipFree(q.hot); q.hot = nullptr; q.hot_bytes = 0; }
+    return st;
+}
+
+// AUTOMATIC (the default): a part whose x replica is beyond the Infinity Cache -- every gather that misses the L2s then moves a
+// 128-byte line from DRAM, 55 G lines/s on MI355X whatever the kernel does -- and whose columns come back (a scale-free matrix:
+// the median window of 2048 nonzeros touches 512 .. 1904 distinct lines of x and spans most of it; mspmv_csrmv_hotcols_skew) gets the
+// plan; a part of uniformly spread columns (nothing to concentrate), of a stencil or a band (already cache-friendly), or with an x
+// that fits the cache does not.  A part that cannot afford the plan's memory runs without it.  y is bit for bit the same either way.
+static int part_hot_auto(mspmv_mg_plan *plan, Part &q)
+{
+    q.hot_median = -1; q.hot_wide = 0;
+    if ((long long) plan->cols * plan->value_bytes <= infinity_cache_bytes() || q.local_nnz < 2048) return part_hot(plan, q, false);
+    (void) hipSetDevice(q.device);
+    int32_t median = -1, wide = 0;
+    const int st = mspmv_csrmv_hotcols_skew(q.cols, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, q.stream, &median, &wide);
+    if (st != 0) return st;
+    q.hot_median = median; q.hot_wide = wide;
+    const bool want = median >= 512 && median < 1905 && wide >= 48;
+    const int built = part_hot(plan, q, want);
+    return built == (int) hipErrorOutOfMemory ? 0 : built;
+}
+
 int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable)
 {
     if (!plan) return kErrInvalid;
     int prev = 0; MG_HIP(hipGetDevice(&prev));
     int st = 0;
+    plan->hot_mode = enable < 0 ? -1 : enable ? 1 : 0;
     for (Part &q : plan->local) {
         if (!q.attached) { st = kErrInvalid; break; }
-        (void) hipSetDevice(q.device);
-        (void) hipStreamSynchronize(q.stream);
-        if (!enable) { (void) hipFree(q.hot); q.hot = nullptr; q.hot_bytes = 0; continue; }
-        if (q.hot) continue;
-        size_t bytes = 0;
-        st = mspmv_csrmv_hotcols_size(q.local_rows, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, &bytes);
+        st = enable < 0 ? part_hot_auto(plan, q) : part_hot(plan, q, enable != 0);
         if (st != 0) break;
-        if (hipMalloc(&q.hot, bytes) != hipSuccess) { (void) hipGetLastError(); q.hot = nullptr; st = hipErrorOutOfMemory; break; }
-        q.hot_bytes = bytes;
-        st = mspmv_csrmv_hotcols_build(q.hot, bytes, q.offsets, q.cols, q.local_rows, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, q.stream, 0);
-        if (st == 0) st = (int) hipStreamSynchronize(q.stream);
-        if (st != 0) { (void) hipFree(q.hot); q.hot = nullptr; q.hot_bytes = 0; break; }
     }
     (void) hipSetDevice(prev);
     return st;
+}
+
+int mspmv_mg_plan_exchange_ms(mspmv_mg_plan_t *plan, int32_t i, float *ms)
+{
+    if (!plan || !ms || i < 0 || i >= (int) plan->local.size()) return kErrInvalid;
+    Part &q = plan->local[(size_t) i];
+    if (!q.ex_valid) return kErrInvalid;
+    int prev = 0; MG_HIP(hipGetDevice(&prev));
+    (void) hipSetDevice(q.device);
+    hipError_t e = hipEventSynchronize(q.ex_end);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, q.ex_begin, q.ex_end);
+    (void) hipSetDevice(prev);
+    return (int) e;
 }
 
 void *mspmv_mg_plan_x(mspmv_mg_plan_t *plan, int32_t i)
@@ -809,6 +877,7 @@ int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info)
     memset(info, 0, sizeof(*info));
     info->parts = plan->parts; info->local_parts = (int32_t) plan->local.size(); info->exchange = plan->exchange;
     info->value_bytes = plan->value_bytes; info->replicas = (int32_t) plan->replicas.size();
+    for (const Part &q : plan->local) info->hot_parts += q.hot ? 1 : 0;
     info->rows = plan->rows; info->cols = plan->cols;
     info->carry_bytes_per_step = (uint64_t) plan->parts * (uint64_t) plan->value_bytes;
     // y -> x: every part's owned rows reach every OTHER replica once

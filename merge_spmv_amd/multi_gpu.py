@@ -48,7 +48,7 @@ def local_offsets(row_offsets_i64: np.ndarray, row_begin: int, row_end: int, nz_
 
 class _MgInfo(ctypes.Structure):
     _fields_ = [("parts", ctypes.c_int32), ("local_parts", ctypes.c_int32), ("exchange", ctypes.c_int32),
-                ("value_bytes", ctypes.c_int32), ("replicas", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("value_bytes", ctypes.c_int32), ("replicas", ctypes.c_int32), ("hot_parts", ctypes.c_int32),
                 ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("carry_bytes_per_step", ctypes.c_uint64),
                 ("allgather_bytes_per_step", ctypes.c_uint64), ("steps", ctypes.c_uint64)]
 
@@ -149,7 +149,7 @@ class MgPlan:
     def info(self) -> dict:
         info = _MgInfo()
         _check(load_library().mspmv_mg_plan_info(self._handle, ctypes.byref(info)), "mspmv_mg_plan_info")
-        return {name: getattr(info, name) for name, _ in _MgInfo._fields_ if name != "reserved"}
+        return {name: getattr(info, name) for name, _ in _MgInfo._fields_}
 
     def ipc_export(self) -> bytes:
         """this process's hipIpc handles (x replicas, mailbox blocks) as one blob (mspmv_mg_plan_ipc_export)"""
@@ -173,9 +173,20 @@ class MgPlan:
         dist.all_gather_object(blobs, mine, group=group)
         self.ipc_import(blobs)
 
-    def hot_columns(self, enable: bool = True):
-        """renumber every local part's columns by reference count (mspmv_mg_plan_hot_columns)"""
-        _check(load_library().mspmv_mg_plan_hot_columns(self._handle, int(bool(enable))), "mspmv_mg_plan_hot_columns")
+    def hot_columns(self, enable=True):
+        """the parts' hot-column plans (mspmv_mg_plan_hot_columns): True / 1 always, False / 0 never, -1 automatic (the default of a new
+        plan: decided per part when its matrix is attached)"""
+        _check(load_library().mspmv_mg_plan_hot_columns(self._handle, -1 if (enable is not True and enable is not False and int(enable) < 0) else int(bool(enable))),
+               "mspmv_mg_plan_hot_columns")
+
+    def exchange_ms(self, local_index: int = 0) -> float:
+        """milliseconds the exchange of the last step took on a local part (mspmv_mg_plan_exchange_ms; synchronises)"""
+        ms = ctypes.c_float(0)
+        lib = load_library()
+        lib.mspmv_mg_plan_exchange_ms.restype = ctypes.c_int
+        lib.mspmv_mg_plan_exchange_ms.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        _check(lib.mspmv_mg_plan_exchange_ms(self._handle, int(local_index), ctypes.byref(ms)), "mspmv_mg_plan_exchange_ms")
+        return float(ms.value)
 
     def csrmv(self):
         _check(load_library().mspmv_mg_csrmv(self._handle), "mspmv_mg_csrmv")

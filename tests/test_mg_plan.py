@@ -297,6 +297,18 @@ def test_ipc_backend_two_processes_sharing_the_device(kind, prec, nproc):
 
 
 @gpu
+def test_hot_columns_are_automatic():
+    """The parts' hot-column plans are AUTOMATIC (mspmv_mg_plan_hot_columns(-1), the default of a new plan): built per part when its
+    matrix is attached iff x is beyond the Infinity Cache and the on-device sample says the columns come back (scale-free), not for
+    uniformly spread columns or a band; y bit for bit the same with, without and forced; mspmv_mg_plan_exchange_ms answers.
+    A process of its own: the cache size is faked through the environment, which the library reads once."""
+    import subprocess, sys
+    env = dict(os.environ); env["MSPMV_FAKE_INFINITY_CACHE_MIB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mg_auto_hot_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "AUTO-HOT-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@gpu
 def test_bench_multi_rank_path_on_one_device():
     """bench.py --gpus N (N > 1 runs BASELINE config 5, one R-MAT matrix cut N ways) end to end on this one-GPU box, at a
     reduced scale: (a) 2 ranks sharing the device, carries over gloo through the Python twin; (b) ONE rank forced through

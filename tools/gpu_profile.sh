@@ -13,6 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 # PROFILE_CMD overrides the profiled command (e.g. tools/plan_bench.py for the prepared plan); the default is the
 # headline bench without its prepared_plan leg (that leg launches the same kernel symbol on another matrix)
 BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-plan --no-configs $*"}
+# PROFILE_INCLUDE (a regex): counters are collected for matching kernels only (--kernel-include-regex) -- what lets a command through
+# that first generates tens of GB with thousands of other kernels (BASELINE config 5: tools/r05_pmc.sh)
+INC=${PROFILE_INCLUDE:+--kernel-include-regex $PROFILE_INCLUDE}
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o bench -- $BENCH > $OUT/bench_trace.log 2>&1
 tail -2 $OUT/bench_trace.log
 for f in $(find $RAW/trace -name "*stats*.csv"); do cp $f $OUT/; done
@@ -20,7 +23,7 @@ KT=$(find $RAW/trace -name "*kernel_trace.csv" | head -1)
 if [ -n "$KT" ]; then head -1 $KT > $OUT/kernel_trace_mspmv.csv; grep -E "${PROFILE_MATCH:-mspmv}" $KT | head -400 >> $OUT/kernel_trace_mspmv.csv; fi
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_READ_SECTORS_sum" "TCP_TCC_READ_REQ_sum"; do
   name=$(echo $pmc | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $RAW/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc $pmc $INC --output-format csv -d $RAW/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1
   CC=$(find $RAW/pmc_$name -name "*counter_collection.csv" | head -1)
   if [ -n "$CC" ]; then
     python3 - "$CC" "$OUT/pmc_$name.summary.csv" "${PROFILE_MATCH:-mspmv}" <<'PY'
