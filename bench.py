@@ -225,16 +225,16 @@ def replayed_traffic(workload, dtype_name):
 _LIVE_PMC = {"ok": True, "why": ""}       # one failure (no rocprofv3, a crash, a time-out) turns the live passes off for the rest of the run
 
 
-def live_traffic(label, steps=24, timeout_s=60):
+def live_traffic(label, steps=24, timeout_s=60, extra_args=()):
     if not _LIVE_PMC["ok"]:
         return None, "live counters switched off after an earlier failure in this run: " + _LIVE_PMC["why"]
-    tr, why = _live_traffic(label, steps, timeout_s)
+    tr, why = _live_traffic(label, steps, timeout_s, extra_args)
     if tr is None:
         _LIVE_PMC["ok"] = False; _LIVE_PMC["why"] = why
     return tr, why
 
 
-def _live_traffic(label, steps, timeout_s):
+def _live_traffic(label, steps, timeout_s, extra_args=()):
     """L2 <-> fabric bytes (Infinity-Cache hits included) per launch of the tile kernel, MEASURED IN THIS RUN on this box: two separate `rocprofv3 --kernel-trace --pmc`
     passes (FETCH_SIZE, then WRITE_SIZE: never combined with other trace domains) over `tools/run_config.py <label>`, which runs
     the same call on the same synthetic matrix in a child process; corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
@@ -259,7 +259,7 @@ def _live_traffic(label, steps, timeout_s):
             #  which is what lets config 5's 36 GB through --; the child in a session of its own, so that a time-out takes the
             #  grandchild python along instead of leaving it on the GPU beside the configurations timed next)
             cmd = [exe, "--kernel-trace", "--pmc", pmc, "--kernel-include-regex", "tile_kernel", "--output-format", "csv", "-d", out, "-o", "b", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "run_config.py"), label, "--steps", str(steps)]
+                   sys.executable, os.path.join(ROOT, "tools", "run_config.py"), label, "--steps", str(steps), *extra_args]
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
                 proc.communicate(timeout=timeout_s)
@@ -446,8 +446,26 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             if not live_pmc or from_file:
                 live_tr, live_src = None, ("skipped (--no-live-pmc)" if not live_pmc else "skipped: the child run regenerates the stand-in, this record is a file")
             elif label == "c5":
-                # (the child generates the 36 GB matrix again, unprofiled -- the counters are collected for the tile kernel only --: ~40 s per pass)
-                live_tr, live_src = live_traffic(label, steps=5, timeout_s=240) if c5_pmc else (None, "skipped (--no-c5-pmc)")
+                # (rocprofv3 --pmc dies -- SIGSEGV inside the tool -- while a child GENERATES the 2e9 edges, counters restricted or not;
+                #  so the matrix this record was timed on is parked as a raw image in RAM-backed /dev/shm and the two child passes load it)
+                live_tr, live_src = None, "skipped (--no-c5-pmc)"
+                if c5_pmc:
+                    img = f"/dev/shm/mspmv_bench_c5_{os.getpid()}.img"
+                    try:
+                        import shutil
+                        need = A.nnz * (vb + 4) + 4 * (A.rows + 1) + (1 << 30)
+                        if shutil.disk_usage("/dev/shm").free < need:
+                            live_src = "skipped: /dev/shm has no room for the CSR image"
+                        else:
+                            G.save_csr_image(A, x_seed, img)
+                            live_tr, live_src = live_traffic(label, steps=5, timeout_s=180, extra_args=("--load", img))
+                    except Exception as e:  # noqa: BLE001
+                        live_tr, live_src = None, f"{type(e).__name__}: {e}"[:200]
+                    finally:
+                        try:
+                            os.remove(img)
+                        except OSError:
+                            pass
             else:
                 live_tr, live_src = live_traffic(label)
             tr = live_tr if live_tr is not None else rep_tr
@@ -552,7 +570,7 @@ def main():
                     help="N = 1: a directory that may hold webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx (the SuiteSparse files, or the stand-ins "
                          "tools/make_standin_mtx.py writes under those names): a file that is there replaces the generated stand-in of its record, read "
                          "through the product's Matrix Market ingest, and the record's `data` says which it was (default: $MSPMV_C3_DIR)")
-    ap.add_argument("--no-c5-pmc", action="store_true", help="N = 1: do not collect config 5's counter traffic (two child runs that each regenerate the 36 GB matrix: ~80 s)")
+    ap.add_argument("--no-c5-pmc", action="store_true", help="N = 1: do not collect config 5's counter traffic (its CSR image parked in /dev/shm, two child runs that load it: ~40 s)")
     ap.add_argument("--configs-budget", type=float, default=240.0, help="seconds the `configs` leg may take before it stops starting new ones")
     ap.add_argument("--dist-timeout", type=int, default=900, help="N > 1: seconds a collective may block before the job aborts")
     ap.add_argument("--tune", default=None, help="development: BLOCKxIPT[:flags] passed to mspmv_set_tuning")

@@ -1135,6 +1135,52 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
 template <typename V, int IPT> constexpr bool layout_hints() { return IPT <= 7; }
 #define MSPMV_LIKELY(on, c) ((on) ? __builtin_expect(!!(c), 1) : !!(c))      // (on: a constant -- which tile shapes take the hint)
 #define MSPMV_UNLIKELY(on, c) ((on) ? __builtin_expect(!!(c), 0) : !!(c))
+// acc += v[j] for j < len - base, j = 0 .. 7, left to right, under a SHRINKING EXEC MASK: v_cmpx + v_add per product -- the lanes
+// leave as their row ends -- instead of compare + select(s) + add (3 instructions per product in fp32, 4 in fp64).  The same additions
+// in the same order as `acc = j < len ? acc + v[j] : acc`; EXEC is restored.  (The lean reductions of short-row tiles are bound by
+// VALU issue, not bytes: profiles/r04_short_rows/.)
+template <typename V> struct CompactChain;
+template <> struct CompactChain<double> {
+    // acc (+0.0 on entry) += v[j] for j < len, left to right, lanes leaving as their row ends (EXEC restored)
+    static __device__ __forceinline__ void add8(double &acc, const double (&v)[8], int len, int base)
+    {
+        unsigned long long sv;
+        const int l = len - base;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f64 %[a], %[a], %[v0]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f64 %[a], %[a], %[v1]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f64 %[a], %[a], %[v2]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f64 %[a], %[a], %[v3]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 4, %[l]\n\tv_add_f64 %[a], %[a], %[v4]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 5, %[l]\n\tv_add_f64 %[a], %[a], %[v5]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 6, %[l]\n\tv_add_f64 %[a], %[a], %[v6]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 7, %[l]\n\tv_add_f64 %[a], %[a], %[v7]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(sv)
+                     : [l] "v"(l), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+                     : "vcc");
+    }
+};
+template <> struct CompactChain<float> {
+    static __device__ __forceinline__ void add8(float &acc, const float (&v)[8], int len, int base)
+    {
+        unsigned long long sv;
+        const int l = len - base;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v0]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v1]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v2]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v3]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 4, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v4]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 5, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v5]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 6, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v6]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 7, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v7]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(sv)
+                     : [l] "v"(l), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+                     : "vcc");
+    }
+};
 constexpr int LEAN_SERIAL = 16;        // rows up to this long are summed by one thread
 constexpr int LEAN_GROUP_MAX = 256;    // rows up to this long (and longer than LEAN_SERIAL) are summed by the 16 lanes of one DPP row; longer ones by the wave
 // Rows of a lean tile that are longer than LEAN_SERIAL -- every lane of the wave calls this with ITS row's first product position
@@ -1250,10 +1296,9 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
         // (what lies beyond the row becomes +0.0 first -- independent selects -- and is then added like the rest: the running sum is
         //  never -0.0 (it starts from +0.0), so adding +0.0 leaves every bit of it, and the dependent chain is the additions alone)
         V acc[2] = {(V) 0, (V) 0};
+        static_assert(LEAN_BATCH == 8, "CompactChain adds eight");
 #pragma unroll
-        for (int j = 0; j < LEAN_BATCH; ++j)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[h] = j < len[h] ? acc[h] + v[h][j] : acc[h];
+        for (int h = 0; h < 2; ++h) CompactChain<V>::add8(acc[h], v[h], len[h], 0);
         if (r0 == 0) MSPMV_LEAN_TR(10);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1263,8 +1308,7 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
                 V w[LEAN_SERIAL - LEAN_BATCH];
 #pragma unroll
                 for (int j = 0; j < LEAN_SERIAL - LEAN_BATCH; ++j) w[j] = src[LEAN_BATCH + j];
-#pragma unroll
-                for (int j = 0; j < LEAN_SERIAL - LEAN_BATCH; ++j) acc[h] = LEAN_BATCH + j < len[h] ? acc[h] + w[j] : acc[h];
+                CompactChain<V>::add8(acc[h], w, len[h], LEAN_BATCH);
             }
             // rows longer than that: by 16-lane groups, the longest by the whole wave (lean_long_rows)
             if (MSPMV_UNLIKELY((layout_hints<V, IPT>()), __ballot(len[h] > LEAN_SERIAL) != 0ull))
@@ -1449,6 +1493,11 @@ __device__ __forceinline__ WirePos wire_pos(int q, int tid)
     return w;
 }
 
+// (A wave-uniform skip of chunks that lie past the tile altogether -- one or two of the four waves of a short-row tile -- was built for
+//  the interior staging in round 5 and not kept: every branch around a group of loads makes the compiler wait at the join, and the
+//  result was mixed -- grid3d-200 -2.3 %, band5 -3 %, but the circuit-shaped matrix +8 %, dense32 fp64 +3.5 %, dense5 +2 %:
+//  profiles/r05_ab_wave_skip_general_kernel.txt.  The compact front end, whose loads are few and whose tiles share a CU in small
+//  numbers, keeps it.)
 template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
                                                     TileRegs<V, BLOCK, IPT> &r, int tid_in = -1)
@@ -2353,48 +2402,6 @@ constexpr int snap_head_max()
 //     writes (tests/test_gpu_parity.py: the `compact` paths; tools/fuzz.py).
 // ---------------------------------------------------------------------------
 constexpr int COMPACT_BLOCK = 256, COMPACT_IPT = 7;
-template <typename V> struct CompactChain;
-template <> struct CompactChain<double> {
-    // acc (+0.0 on entry) += v[j] for j < len, left to right, lanes leaving as their row ends (EXEC restored)
-    static __device__ __forceinline__ void add8(double &acc, const double (&v)[8], int len, int base)
-    {
-        unsigned long long sv;
-        const int l = len - base;
-        asm volatile("s_mov_b64 %[sv], exec\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f64 %[a], %[a], %[v0]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f64 %[a], %[a], %[v1]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f64 %[a], %[a], %[v2]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f64 %[a], %[a], %[v3]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 4, %[l]\n\tv_add_f64 %[a], %[a], %[v4]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 5, %[l]\n\tv_add_f64 %[a], %[a], %[v5]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 6, %[l]\n\tv_add_f64 %[a], %[a], %[v6]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 7, %[l]\n\tv_add_f64 %[a], %[a], %[v7]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [a] "+v"(acc), [sv] "=&s"(sv)
-                     : [l] "v"(l), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
-                     : "vcc");
-    }
-};
-template <> struct CompactChain<float> {
-    static __device__ __forceinline__ void add8(float &acc, const float (&v)[8], int len, int base)
-    {
-        unsigned long long sv;
-        const int l = len - base;
-        asm volatile("s_mov_b64 %[sv], exec\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v0]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v1]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v2]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v3]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 4, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v4]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 5, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v5]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 6, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v6]\n\t"
-                     "v_cmpx_lt_i32_e32 vcc, 7, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v7]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [a] "+v"(acc), [sv] "=&s"(sv)
-                     : [l] "v"(l), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
-                     : "vcc");
-    }
-};
 // element i of a chunk that was loaded `s` elements too early (the last, ragged chunk of an array is fetched at n - 4): what
 // belongs at position i is what was loaded at position i + s (positions that fall off the end are never used)
 template <typename T>
@@ -2478,6 +2485,8 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     const int nz4 = p.nnz - 4;                                          // (nnz >= 4 on this path)
     const int a0c = a0 < nz4 ? a0 : nz4;
     const int n_ro = tile_rows + 1;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid) & ~(WAVE - 1);
+    const bool live1 = a0 + 4 * (wave_base + BLOCK) < rs1;             // wave-uniform (scalar): see the nonzero loads below
     if (__builtin_expect(!take, 0)) goto staged;
     // ---- the four row offsets that decide whether (x0, rs0), (x1, rs1) are the points of diagonals d0, d1: two scalar loads of the
     // pairs row_end[x - 1], row_end[x] (uniform addresses; row_end[-1] = row_offsets[0] exists, and a boundary at x == rows reads
@@ -2490,13 +2499,21 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
         vw0 = *reinterpret_cast<const int2v_u *>(p.row_end + b0);
         vw1 = *reinterpret_cast<const int2v_u *>(p.row_end + b1);
     }
-    // ---- the tile's nonzeros: 4-element chunks aligned in array index space, clamped to the array's last full chunk
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int e = a0 + 4 * (tid + k * BLOCK);
+    // ---- the tile's nonzeros: 4-element chunks aligned in array index space, clamped to the array's last full chunk.
+    // A WAVE whose second chunk lies past the tile altogether (a tile of 5-point rows fills 1500 of the 2048 slots: waves 2 and 3)
+    // issues nothing for it -- no stream loads, no gathers, no products: a redirected load costs no bytes, but it costs the CU's
+    // vector-memory pipeline the same cycles, and that pipeline is what several tiles on one CU queue on
+    {
+        const int e = a0 + 4 * tid;
         const int ee = e < rs1 ? (e < nz4 ? e : nz4) : a0c;             // (a chunk past the tile re-reads the tile's first: no bytes for data it does not use)
-        col[k] = compact_ld4(p.cols, ee);
-        val[k] = compact_ld4(p.values, ee);
+        col[0] = compact_ld4(p.cols, ee);
+        val[0] = compact_ld4(p.values, ee);
+    }
+    if (live1) {
+        const int e = a0 + 4 * (tid + BLOCK);
+        const int ee = e < rs1 ? (e < nz4 ? e : nz4) : a0c;
+        col[1] = compact_ld4(p.cols, ee);
+        val[1] = compact_ld4(p.values, ee);
     }
     // ---- row offsets x0 .. x1 (a row's start and end both come from here), one per lane and round: no alignment, no ragged end
     rov[0] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid < n_ro ? tid : 0)) << 2);
@@ -2510,9 +2527,11 @@ aligned:
         // ---- x gathers
         V xv[CPT][4];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k)
+        for (int i = 0; i < 4; ++i) xv[0][i] = compact_ld<V>(p.x, (unsigned) col[0].get(i) * (unsigned) sizeof(V));
+        if (live1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xv[k][i] = compact_ld<V>(p.x, (unsigned) col[k].get(i) * (unsigned) sizeof(V));
+            for (int i = 0; i < 4; ++i) xv[1][i] = compact_ld<V>(p.x, (unsigned) col[1].get(i) * (unsigned) sizeof(V));
+        }
         // ---- the verdict on the hints, in the shadow of the gathers (scalar: v_readlane).  Acted upon after the barrier -- a branch
         // here would hold the gathers back behind it --: until then nothing but registers and LDS is touched
         const int before0 = x0 == p.rows ? vw0.y : vw0.x, at0 = vw0.y, before1 = x1 == p.rows ? vw1.y : vw1.x, at1 = vw1.y;
@@ -2529,12 +2548,13 @@ aligned:
         s_ro[tid] = rov[0];
         if (BLOCK < n_ro) s_ro[tid + BLOCK] = rov[1];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            V prod[4];
+        for (int k = 0; k < CPT; ++k)
+            if (k == 0 || live1) {                                      // (slots of a chunk nobody staged are never a row's products: reads past a row's end are discarded)
+                V prod[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) prod[i] = val[k].get(i) * xv[k][i];
-            st_lds4(&s_prod[4 * (tid + k * BLOCK)], prod);
-        }
+                for (int i = 0; i < 4; ++i) prod[i] = val[k].get(i) * xv[k][i];
+                st_lds4(&s_prod[4 * (tid + k * BLOCK)], prod);
+            }
         __syncthreads();
         go = verdict;
     }
@@ -2543,7 +2563,7 @@ staged:
     go = __builtin_amdgcn_readfirstlane(go);
     if (__builtin_expect(go == 0, 0)) return;                          // (every wave alike; the general body starts from scratch)
     // ---- row by row: consume_tile_rows' arithmetic (left to right from +0.0; > LEAN_SERIAL: 16-lane groups), one row per thread and round
-    r0 = __builtin_amdgcn_readfirstlane(tid) & ~(WAVE - 1);             // (the wave's first row of the round: scalar -- the compiler has to SEE that the test below is wave-uniform)
+    r0 = wave_base;                                                    // (the wave's first row of the round: scalar -- the compiler has to SEE that the test below is wave-uniform)
 next_round:
     // (the wave's program ENDS here -- s_endpgm, not a return: a return value is merged with the general body's exit and the
     //  reduction then sits behind two far jumps.  The test has to be visibly wave-uniform for the same reason: an exit the compiler
@@ -2583,11 +2603,12 @@ more_row_offsets:                                                      // tiles 
     goto have_row_offsets;
 ragged_end:
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int e = a0 + 4 * (tid + k * BLOCK);
-        const int s = (e < rs1 && e > nz4) ? e - nz4 : 0;
-        if (__ballot(s != 0) != 0ull) { compact_realign(col[k], s); compact_realign(val[k], s); }
-    }
+    for (int k = 0; k < CPT; ++k)
+        if (k == 0 || live1) {
+            const int e = a0 + 4 * (tid + k * BLOCK);
+            const int s = (e < rs1 && e > nz4) ? e - nz4 : 0;
+            if (__ballot(s != 0) != 0ull) { compact_realign(col[k], s); compact_realign(val[k], s); }
+        }
     goto aligned;
 longer_rows:
     {

@@ -322,3 +322,36 @@ def circuit_csr(rows: int = CIRCUIT5M_ROWS, nnz: int = CIRCUIT5M_NNZ, dtype=torc
     col = col[order].to(torch.int32)
     vals = (uniform01(seed + 4, k[order]) * 2.0 - 1.0).to(dtype)
     return DeviceCsr(rows, cols, offsets.to(torch.int32), col, vals)
+
+
+def save_csr_image(A, x_seed, path):
+    """A DeviceCsr as a raw image (a JSON header, then row offsets, column indices, values) -- what lets a profiled child process load
+    BASELINE config 5 instead of generating it (rocprofv3 --pmc dies in the generation of its 2e9 edges): tools/run_config.py --save /
+    --load, bench.py's live counter passes.  RAM-backed /dev/shm is the place for the 24 GB."""
+    import json, numpy as np
+    with open(path, "wb") as f:
+        head = json.dumps({"rows": A.rows, "cols": A.cols, "nnz": A.nnz, "dtype": str(A.values.dtype), "x_seed": x_seed}).encode()
+        f.write(len(head).to_bytes(8, "little")); f.write(head)
+        for t in (A.row_offsets, A.column_indices, A.values):
+            for a in range(0, t.numel(), 1 << 28):                      # 1-2 GB at a time through the host
+                f.write(t[a:a + (1 << 28)].cpu().numpy().tobytes())
+
+
+def load_csr_image(path, dev):
+    """(DeviceCsr, x_seed) from save_csr_image's file: host reads and host-to-device copies only, no kernels."""
+    import json, numpy as np
+    with open(path, "rb") as f:
+        n = int.from_bytes(f.read(8), "little"); head = json.loads(f.read(n)); base = 8 + n
+    tdt = {"torch.float32": torch.float32, "torch.float64": torch.float64}[head["dtype"]]
+    ndt = np.float32 if tdt == torch.float32 else np.float64
+
+    def read(count, dtype_np, dtype_t, offset):
+        out = torch.empty(count, dtype=dtype_t, device=dev)
+        mm = np.memmap(path, dtype=dtype_np, mode="r", offset=offset, shape=(count,))
+        for a in range(0, count, 1 << 28):
+            out[a:a + (1 << 28)].copy_(torch.from_numpy(np.ascontiguousarray(mm[a:a + (1 << 28)])))
+        return out
+    off = read(head["rows"] + 1, np.int32, torch.int32, base)
+    col = read(head["nnz"], np.int32, torch.int32, base + 4 * (head["rows"] + 1))
+    val = read(head["nnz"], ndt, tdt, base + 4 * (head["rows"] + 1) + 4 * head["nnz"])
+    return DeviceCsr(head["rows"], head["cols"], off, col, val), head["x_seed"]

@@ -120,3 +120,34 @@ def test_strict_check_behaviour():
     assert not O.strict_check(csr, bad, g, s)[0]
     nan = g.astype(np.float32).copy(); nan[3] = np.nan
     assert not O.strict_check(csr, nan, g, s)[0]
+
+
+REF_SEARCH = os.path.join(ROOT, "oracle", "_ref", "ref_search")
+
+
+@pytest.mark.skipif(not os.access(REF_SEARCH, os.X_OK), reason="oracle/_ref/ref_search (the reference's cub::MergePathSearch compiled here by oracle/Makefile) is not present")
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_search_against_the_compiled_reference_on_fresh_inputs(tmp_path, seed):
+    """Beyond the committed golden vectors: the oracle's MergePathSearch against the REFERENCE's own cub::MergePathSearch
+    (cub/thread/thread_search.cuh:53-84, compiled from /root/reference by oracle/Makefile into oracle/_ref/ref_search -- a binary that
+    travels with the snapshot, not a source) on freshly drawn row-length patterns: every diagonal of every matrix, clamped ones included.
+    Runs wherever the binary is (the authoring container, the GPU box); skipped where it is not."""
+    import subprocess
+    rng = np.random.default_rng(1000 + seed)
+    rows = int(rng.integers(1, 400))
+    kind = seed % 3
+    lens = (rng.integers(0, 6, rows) if kind == 0 else
+            np.where(rng.random(rows) < 0.03, rng.integers(50, 900, rows), 0) if kind == 1 else
+            np.minimum((rng.pareto(1.0, rows) * 2).astype(np.int64), 500))
+    off = np.zeros(rows + 1, np.int64); np.cumsum(lens, out=off[1:])
+    nnz = int(off[-1])
+    path = tmp_path / "offsets.txt"
+    path.write_text(f"{rows} {nnz}\n" + " ".join(map(str, off)) + "\n")
+    out = subprocess.run([REF_SEARCH, str(path)], check=True, capture_output=True, text=True).stdout
+    row_end = off[1:].astype(np.int32)
+    n = 0
+    for line in out.splitlines():
+        d, x, y = map(int, line.split())
+        assert O.merge_path_search(d, row_end, rows, nnz) == (x, y), (seed, d)
+        n += 1
+    assert n == rows + nnz + 4

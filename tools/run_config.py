@@ -15,9 +15,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("label")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--mode", default="stateless", choices=["stateless", "plan", "hotcols"])
+ap.add_argument("--save", default=None, help="generate the configuration's matrix, write its CSR image to this file (raw arrays) and exit")
+ap.add_argument("--load", default=None, help="read the CSR image --save wrote instead of generating (host reads + copies, no kernels: what lets "
+                                             "config 5 through rocprofv3 --pmc, which dies in the generation of its 2e9 edges)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
-if args.label == "c2_f32":
+if args.load:
+    A, x_seed = G.load_csr_image(args.load, dev)
+elif args.label == "c2_f32":
     A = G.uniform_csr(bench.C2_ROWS_PER_GPU, bench.C2_ROWS_PER_GPU, bench.C2_NPR, dtype=torch.float32, device=dev); x_seed = G.SEED_C2 + 2
 elif args.label == "rmat24":
     A = G.rmat_csr(24, 250_000_000, dtype=torch.float64, device=dev, seed=G.SEED_C5); x_seed = G.SEED_C5 + 2
@@ -26,6 +31,10 @@ else:
     if not spec:
         raise SystemExit(f"unknown label {args.label}")
     A, x_seed = spec[0][5]()
+if args.save:
+    G.save_csr_image(A, x_seed, args.save)
+    print(f"{args.label}: CSR image written to {args.save} ({os.path.getsize(args.save) / 1e9:.1f} GB)")
+    raise SystemExit(0)
 x = G.uniform_pm1(x_seed, A.cols, A.values.dtype, dev)
 y = torch.empty(A.rows, dtype=A.values.dtype, device=dev)
 if args.mode == "plan":
