@@ -231,8 +231,10 @@ typedef struct mspmv_launch_info {
     uint64_t coords_offset;    /* byte offsets of regions inside temp         */
     uint64_t carries_offset;
     uint64_t diag_offset;      /* two int32: [0] = tag of the last one-launch call in which a tile gave up waiting for another
-                                  workgroup's record and computed the sum itself (debug_sync reports it), [1] = the epoch such
-                                  a tile moves on (mixed into the record tags); neither is ever needed for a result */
+                                  workgroup's record and computed the sum itself (debug_sync reports it), [1] = how many such
+                                  episodes this temp storage has seen; neither is ever needed for a result */
+    uint64_t records_offset;   /* the tagged records of the one-launch kernel: 16 bytes per tile + per group of 64 tiles; every slot is
+                                  (0, 0) again once a launch has ended (tests/test_forward_progress.py)                          */
 } mspmv_launch_info_t;
 
 /* value_bytes = 4 (float) or 8 (double). */

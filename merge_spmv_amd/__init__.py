@@ -45,7 +45,7 @@ class _LaunchInfo(ctypes.Structure):
                 ("fixup_chunk", ctypes.c_int32), ("fixup_levels", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("snap_head_max", ctypes.c_int32),
                 ("temp_bytes", ctypes.c_uint64), ("coords_offset", ctypes.c_uint64),
-                ("carries_offset", ctypes.c_uint64), ("diag_offset", ctypes.c_uint64)]
+                ("carries_offset", ctypes.c_uint64), ("diag_offset", ctypes.c_uint64), ("records_offset", ctypes.c_uint64)]
 
 
 def load_library() -> ctypes.CDLL:

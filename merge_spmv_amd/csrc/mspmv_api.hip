@@ -138,7 +138,7 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
     L.band_next_off = off; off = align256(off + uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) * sizeof(int));
     // row start of every boundary (4 bytes): with the coordinates, the hints of tile_kernel_snap
     L.rstart_off = off; off = align256(off + uint64_t(L.num_tiles + 1) * sizeof(int));
-    L.err_off = off; off = align256(off + 8);           // [0]: receives the call's tag when a bounded poll ran out and the consumer computed the sum itself (diagnostic), [1]: the epoch of the record tags
+    L.err_off = off; off = align256(off + 8);           // [0]: receives the call's tag when a bounded poll ran out and the consumer computed the sum itself (diagnostic), [1]: counts such episodes (until round 5: an epoch mixed into the record tags)
     // fix-up levels: n -> 2*ceil(n/CHUNK) until one block suffices
     L.fix_n[0] = L.num_tiles; L.fix_levels = 0;
     if (L.num_tiles > 1) {
@@ -439,7 +439,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             //  tiles of XCD k's range, which wait for the LAST tiles of XCD k - 1's range: few waiters, a bounded poll, then the sum
             //  recomputed from the matrix; correct, and slow only for a row longer than HEAD_MAX that crosses a range boundary)
             const int chunk_log2 = ex.tile_map ? ex.tile_map : safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
-#define MSPMV_LAUNCH_SNAP(AX, NTF) launched = launch_exact(tile_kernel_snap<V, BLOCK, IPT, AX, NTF>, dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, lb.error, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
+#define MSPMV_LAUNCH_SNAP(AX, NTF) launched = launch_exact(tile_kernel_snap<V, BLOCK, IPT, AX, NTF>, dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
             if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
             else if (nt) MSPMV_LAUNCH_SNAP(false, true);
             else MSPMV_LAUNCH_SNAP(false, false);
@@ -968,6 +968,7 @@ int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_
     info->coords_offset = L.coords_off;
     info->carries_offset = L.carries_off;
     info->diag_offset = L.err_off;
+    info->records_offset = L.pub_off;
     return hipSuccess;
 }
 

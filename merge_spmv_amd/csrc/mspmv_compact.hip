@@ -17,8 +17,8 @@ hipError_t launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStr
                                const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg)
 {
     constexpr int B = COMPACT_BLOCK, I = COMPACT_IPT;
-    if (axpby) return launch_exact(tile_kernel_snap<V, B, I, true, false, true>, dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, lb.error, num_tiles, 0, p, carries, lb, lean_avg);
-    return launch_exact(tile_kernel_snap<V, B, I, false, false, true>, dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, lb.error, num_tiles, 0, p, carries, lb, lean_avg);
+    if (axpby) return launch_exact(tile_kernel_snap<V, B, I, true, false, true>, dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, num_tiles, 0, p, carries, lb, lean_avg);
+    return launch_exact(tile_kernel_snap<V, B, I, false, false, true>, dim3(grid), dim3(B), dyn_lds, stream, coords, rstart, num_tiles, 0, p, carries, lb, lean_avg);
 }
 template hipError_t launch_snap_compact<float>(bool, unsigned, size_t, hipStream_t, Coord *, int *, int, const Params<float> &, Carry<float> *, const LookBack &, int);
 template hipError_t launch_snap_compact<double>(bool, unsigned, size_t, hipStream_t, Coord *, int *, int, const Params<double> &, Carry<double> *, const LookBack &, int);

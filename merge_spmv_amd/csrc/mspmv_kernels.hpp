@@ -84,24 +84,51 @@ struct Params {
 // Tagged records: how blocks of ONE launch hand each other 64 bits (tile_kernel_snap).  A record is two
 // 64-bit words, each carrying half of a per-call tag beside 32 bits of payload, written and read with relaxed agent-scope
 // atomics (visible across the XCDs' L2s without a cache flush).  A word is valid when its tag half matches, so no ordering
-// between the two is needed, stale or uninitialised memory is told apart by the 63 tag bits, and the ONE consumer every
-// record has clears it -- none outlives the call, which also makes a captured call replayable with the same tags, even
-// after the matrix changed.
-// NOTHING DEPENDS ON A RECORD ARRIVING.  Polling is bounded; a consumer whose poll runs out -- the awaited block has not
-// been dispatched: possible only when far fewer blocks are resident than mspmv_api.hip assumed (a CU-masked stream, a
-// long kernel beside this one, several processes on the device) AND the resident ones are all waiting -- computes the
-// missing sum itself from the matrix (recompute_row_head) and bumps the EPOCH word of the temp storage, which is mixed into
-// the tags: records that may then arrive late and stay uncleared can never look valid to a later launch that replays the
-// same call tag (a captured graph).  The reference's fp64 fix-up spins without bound on the same assumption
-// (single_pass_scan_operators.cuh:620-639); here a broken assumption costs time, never the result.
+// between the two is needed, and stale or uninitialised memory is told apart by the 63 tag bits.
+// EVERY RECORD SLOT IS CLEAN (0, 0) WHEN THE LAUNCH ENDS -- whoever acts on a slot LAST leaves it clean -- so no record outlives
+// its call and a captured call replays with the same tags, even after the matrix changed.  A slot goes through
+//     (anything) --publisher ANNOUNCES--> PENDING --publisher stores the record--> RECORD --consumer takes it--> (0, 0)
+//   * a publisher ANNOUNCES itself as soon as it knows it will publish -- an atomic exchange of a marker into word 0, issued before
+//     the tile's reduction, its answer looked at only when the sum is there: nothing waits for it -- and later stores the record
+//     with two plain atomic stores;
+//   * the one consumer every record has takes it (both tags match) and clears it;
+//   * NOTHING DEPENDS ON ANOTHER WORKGROUP BEING DISPATCHED.  Polling is bounded; a consumer whose poll runs out -- the awaited block
+//     has not been dispatched: possible only when far fewer blocks are resident than mspmv_api.hip assumed (a CU-masked stream, a
+//     long kernel beside this one, several processes on the device) AND the resident ones are all waiting -- CANCELS the slot by an
+//     atomic exchange.  What comes back decides: the RECORD (it arrived between the last look and now) -> taken like any other;
+//     PENDING -> the publisher is RUNNING (it announced itself) and publishers never wait for anything, so the record comes in
+//     finite time whatever else the device does: the consumer goes on polling for it; anything else -> the publisher has not
+//     started: the cancellation stays, the block computes the missing sum itself from the matrix (recompute_row_head), and the
+//     publisher, whose announcement brings the cancellation back, wipes the slot instead of publishing.
+// (Until round 5 a cancelled slot's late record stayed where it was and an EPOCH word, bumped by the recomputing consumer and mixed
+//  into the tags, was to keep a replayed launch from mistaking it for its own.  That left two holes: a publisher dispatched AFTER the
+//  bump tagged its record with the NEW epoch -- the one the next replay reads at its start --, and blocks of one launch that read the
+//  epoch before and after a bump disagreed about every tag between them, each such pair costing a full poll budget.  A publisher
+//  that EXCHANGES its record in and cleans up when it finds a cancellation was measured first: correct, but the answer of the
+//  exchange sits on the critical path of a tile that does nothing after publishing -- BASELINE config 4, 23 800 such tiles: +7.5 %.)
+// The reference's fp64 fix-up spins without bound on the same residency assumption (single_pass_scan_operators.cuh:620-639);
+// here a broken assumption costs time, never the result.
 // ---------------------------------------------------------------------------
 constexpr int REC_MAX_POLLS = 1 << 17;      // x ~1 us: ~0.1 s before a consumer gives up on a record and computes the sum itself
-__device__ __forceinline__ void rec_store(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned p0, unsigned p1)
+// (markers carry the call's tag with its low bit CLEARED: never a valid record tag, tag_a | 1)
+__device__ __forceinline__ unsigned long long rec_cancel_word(unsigned tag_a) { return ((unsigned long long) (tag_a & ~1u) << 32) | 0x0CA9CE11ull; }
+__device__ __forceinline__ unsigned long long rec_pending_word(unsigned tag_a) { return ((unsigned long long) (tag_a & ~1u) << 32) | 0x9E0D1D61ull; }
+// the publisher's announcement; the returned word goes to rec_store when the sum is there
+__device__ __forceinline__ unsigned long long rec_announce(unsigned long long *rec, unsigned tag_a)
 {
-    __hip_atomic_store(rec, ((unsigned long long) tag_a << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(rec + 1, ((unsigned long long) tag_b << 32) | p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_exchange(rec, rec_pending_word(tag_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// waits (bounded) until both words carry this call's tag, clears the record; false = timed out (payload undefined)
+__device__ __forceinline__ void rec_store(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned p0, unsigned p1, unsigned long long announced)
+{
+    if (announced == rec_cancel_word(tag_a)) {      // the one consumer of this slot gave up before this block started: nobody will take the record
+        __hip_atomic_store(rec, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __hip_atomic_store(rec + 1, ((unsigned long long) tag_b << 32) | p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec, ((unsigned long long) tag_a << 32) | p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits (bounded) until both words carry this call's tag, clears the record; false = the slot is cancelled (payload undefined)
 __device__ __forceinline__ bool rec_take(unsigned long long *rec, unsigned tag_a, unsigned tag_b, unsigned &p0, unsigned &p1, int max_polls)
 {
     for (int polls = 0; polls < max_polls; ++polls) {
@@ -115,7 +142,25 @@ __device__ __forceinline__ bool rec_take(unsigned long long *rec, unsigned tag_a
         }
         __builtin_amdgcn_s_sleep(2);
     }
-    return false;
+    // give up on this slot: cancel it -- unless its publisher has at least started
+    unsigned long long w0 = __hip_atomic_exchange(rec, rec_cancel_word(tag_a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned) (w0 >> 32) != tag_a && w0 != rec_pending_word(tag_a)) return false;       // not started: the publisher will find the cancellation
+    // The record's word 0 (its word 1 was stored before it by the same thread and is on its way), or the announcement of a publisher
+    // that is running and waits for nothing (its record overwrites the cancellation): a wait for stores of a block that HAS started
+    // (the exchange REPLACED word 0: a record's word 0 is the one it brought back; after an announcement the publisher's store will
+    //  overwrite the cancellation)
+    const bool have_w0 = (unsigned) (w0 >> 32) == tag_a;
+    unsigned long long w1;
+    for (;;) {
+        if (!have_w0) w0 = __hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1 = __hip_atomic_load(rec + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned) (w0 >> 32) == tag_a && (unsigned) (w1 >> 32) == tag_b) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(rec, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p0 = (unsigned) w0; p1 = (unsigned) w1;
+    return max_polls > 0;                   // (max_polls == 0, the "never look" testing aid: the slot is cleaned, the record discarded -- every such tile recomputes)
 }
 
 // Where a coordinate pass puts what it finds about tile boundary t -- the merge-path point (x, y) of diagonal t * TILE:
@@ -751,7 +796,7 @@ struct LookBack {
     unsigned long long *rec;      // 2 words per tile; nullptr = off (the fix-up launch adds the carries)
     unsigned tag_a, tag_b;        // tag_a is never 0 (a cleared word is never valid)
     int *error;                   // two words of the call's temp storage: [0] receives call_tag when a poll ran out and the consumer computed the
-                                  // sum itself (a diagnostic: debug_sync reports it), [1] is the epoch mixed into the tags
+                                  // sum itself (a diagnostic: debug_sync reports it), [1] counts such episodes (was: an epoch mixed into the tags)
     unsigned call_tag;            // what the host compares word [0] with
     int max_polls;                // how often a consumer looks for a record before it computes the sum itself (REC_MAX_POLLS; tests: 1, or 0 = never looks)
     int group_base;               // record index of the first GROUP record (= the launch's number of tiles): see LB_GROUP
@@ -767,13 +812,6 @@ struct LookBack {
 // additions is fixed by the tile indices alone; and nothing depends on a record arriving -- a leader whose poll runs out
 // computes its group's sum from the matrix, like any consumer.
 constexpr int LB_GROUP = 64;
-// the tags of this launch: the call's tag and the epoch word as the block found it
-__device__ __forceinline__ LookBack with_epoch(LookBack lb, unsigned epoch)
-{
-    lb.tag_a = (lb.tag_a ^ (epoch * 0x9E3779B9u)) | 1u;
-    lb.tag_b = lb.tag_b + epoch * 0x85EBCA6Bu;
-    return lb;
-}
 template <typename V> struct LbBits;
 template <> struct LbBits<float> {
     static __device__ __forceinline__ void split(float v, unsigned &p0, unsigned &p1) { p0 = __builtin_bit_cast(unsigned, v); p1 = 0u; }
@@ -786,11 +824,12 @@ template <> struct LbBits<double> {
     { return __builtin_bit_cast(double, ((unsigned long long) p0 << 32) | p1); }
 };
 template <typename V>
-__device__ __forceinline__ void lb_publish(const LookBack &lb, int tile, V value)
+__device__ __forceinline__ void lb_publish(const LookBack &lb, int slot, V value, unsigned long long announced)
 {
     unsigned p0, p1; LbBits<V>::split(value, p0, p1);
-    rec_store(lb.rec + 2 * (size_t) tile, lb.tag_a, lb.tag_b, p0, p1);
+    rec_store(lb.rec + 2 * (size_t) slot, lb.tag_a, lb.tag_b, p0, p1, announced);
 }
+__device__ __forceinline__ unsigned long long lb_announce(const LookBack &lb, int slot) { return rec_announce(lb.rec + 2 * (size_t) slot, lb.tag_a); }
 // the carry tile s published: waits (bounded) until both words carry this call's tag, then clears the record
 template <typename V>
 __device__ __forceinline__ V lb_take(const LookBack &lb, int s, bool &ok)
@@ -999,6 +1038,18 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
     static_assert(NPT <= 16 && FLAG_WORDS <= BLOCK, "flag word handling");
     const int tid = tid_in < 0 ? (int) threadIdx.x : tid_in;
 
+    // one-launch path: a tile that will publish ANNOUNCES itself now -- the thread that will store the record exchanges a marker into
+    // the slot; the answer is looked at when the sum is there (rec_store), by then it has long arrived ("EVERY RECORD SLOT IS CLEAN")
+    // (a group leader -- "GROUP RECORDS"; first_row_tile < tile only when the tile begins inside a row that began in an earlier one --
+    //  publishes the group's slot, by thread 0; a piece without a row end its own, by the thread that holds its last nonzero; a tile
+    //  with row ends its own, by the last thread)
+    const bool leader = lb != nullptr && publish && tile_rows == 0 && tile % LB_GROUP == LB_GROUP - 1 && first_row_tile <= tile - (LB_GROUP - 1);
+    unsigned long long announced = 0ull;
+    if (lb != nullptr && publish) {
+        const int pub_thread = tile_rows > 0 ? BLOCK - 1 : leader ? 0 : tile_nnz > 0 ? (pshift + tile_nnz - 1) / NPT : 0;
+        if (tid == pub_thread) announced = lb_announce(*lb, leader ? lb->group_base + tile / LB_GROUP : tile);
+    }
+
     // ---- nonzero phase
     V s[NPT];
 #pragma unroll
@@ -1021,8 +1072,6 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         // block-uniform: no row ends in this tile (a slice of one long row): only the running sum
         // at the tile's last nonzero is needed -- the carry.  No write-back, no third barrier.
         if (tid < FLAG_WORDS) s_flag[tid] = 0u;
-        // a group leader ("GROUP RECORDS"; first_row_tile < tile only when the tile begins inside a row that began in an earlier one)
-        const bool leader = lb != nullptr && publish && tile % LB_GROUP == LB_GROUP - 1 && first_row_tile <= tile - (LB_GROUP - 1);
         const int last = pshift + tile_nnz - 1;
         if (tile_nnz > 0 ? tid == last / NPT : tid == 0) {
             V v = 0;
@@ -1031,7 +1080,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
             Carry<V> c; c.key = c0.x; c.value = v;
             if (p.band_pass > 0) c.value += carry_out->value;      // later column-band pass: same tile, same key
             *carry_out = c;
-            if (lb && publish && !leader) lb_publish<V>(*lb, tile, v);              // (only when some tile will take it)
+            if (lb && publish && !leader) lb_publish<V>(*lb, tile, v, announced);   // (only when some tile will take it)
             if (leader) s_wave_val[0] = v;
         }
         if (leader) {
@@ -1051,7 +1100,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
                     __hip_atomic_fetch_add(lb->error + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (tid == 0) lb_publish<V>(*lb, lb->group_base + tile / LB_GROUP, before + own);
+            if (tid == 0) lb_publish<V>(*lb, lb->group_base + tile / LB_GROUP, before + own, announced);
         }
         return;
     }
@@ -1069,7 +1118,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
         c.value = tile_nnz > e_last ? s_prod_raw[prod_slot<V, CPT>(pshift + tile_nnz - 1)] : (V) 0;
         if (p.band_pass > 0) c.value += carry_out->value;
         *carry_out = c;
-        if (lb && publish) lb_publish<V>(*lb, tile, c.value);
+        if (lb && publish) lb_publish<V>(*lb, tile, c.value, announced);
     }
     // single-launch path: the pieces of this tile's first row held by tiles [first_row_tile, tile) (thread 0 stores row 0).
     // Up to 64 of them: wave 0 alone, while the other waves go on with the row phase; more: the whole block.
@@ -1089,7 +1138,7 @@ __device__ __forceinline__ void consume_tile_flags(const Params<V> &p, const Coo
             } else if (pieces > WAVE) first_row_carry = lb_take_block<V, BLOCK, TAKE_BATCH>(*lb, pieces, s_wave_val, ok, [=](int i) { return tile - 1 - i; });
             else if (tid < WAVE) first_row_carry = lb_take_wave<V>(*lb, tile, pieces, ok);
             // a poll ran out (see "NOTHING DEPENDS ON A RECORD ARRIVING" above): the whole block computes the sum from the
-            // matrix -- the row's nonzeros before this tile -- and moves the epoch on
+            // matrix -- the row's nonzeros before this tile (its cancelled slots are wiped by their publishers when those come)
             if (__syncthreads_or(ok ? 0 : 1)) {
                 first_row_carry = recompute_row_head<V, BLOCK>(p, first_row_start, c0.y, s_wave_val);
                 if (tid == 0 && lb->error) {
@@ -2455,7 +2504,8 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     Vec4<int> col[CPT]; Vec4<V> val[CPT];
     int rov[RO_ROUNDS];
     int r0, r, start, len; bool valid; V acc; const V *src;
-    int2v vw0, vw1;
+    int2v vw0 = {0, 0}, vw1 = {0, 0};
+    __shared__ int s_verdict;
     // ---- hints (scalar cache; the tile index is uniform).  Request and wait in ONE asm statement (see tile_kernel_snap)
     int4v hc; int2v hr;
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
@@ -2491,7 +2541,9 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     // ---- the four row offsets that decide whether (x0, rs0), (x1, rs1) are the points of diagonals d0, d1: two scalar loads of the
     // pairs row_end[x - 1], row_end[x] (uniform addresses; row_end[-1] = row_offsets[0] exists, and a boundary at x == rows reads
     // the pair one lower), requested first, looked at in the shadow of the gathers
-    {
+    // (by the block's FIRST WAVE alone: its verdict reaches the others through one LDS word behind the staging barrier that is there
+    //  anyway -- two vector-memory requests and ~25 scalar instructions fewer in three of the four waves)
+    if (wave_base == 0) {
         const int b0 = x0 - 1 < p.rows - 2 ? x0 - 1 : p.rows - 2, b1 = x1 - 1 < p.rows - 2 ? x1 - 1 : p.rows - 2;      // (rows >= 3)
         // (plain loads on uniform addresses of memory the kernel has not written: the compiler makes them s_load_dwordx2 and keeps
         //  track of them itself -- a hand-issued scalar load whose wait sits in another asm statement leaves its destination
@@ -2534,6 +2586,7 @@ aligned:
         }
         // ---- the verdict on the hints, in the shadow of the gathers (scalar: v_readlane).  Acted upon after the barrier -- a branch
         // here would hold the gathers back behind it --: until then nothing but registers and LDS is touched
+        if (wave_base == 0) {
         const int before0 = x0 == p.rows ? vw0.y : vw0.x, at0 = vw0.y, before1 = x1 == p.rows ? vw1.y : vw1.x, at1 = vw1.y;
         // (x, rs) is the point of diagonal d  <=>  rs == row_offsets[x] <= y = d - x  and  (x == rows ? d == total : y <= row_offsets[x + 1])
         // (written with integer selects: the tests stay on the scalar unit); and the stored y's are the derived ones (what
@@ -2541,6 +2594,8 @@ aligned:
         const int lim0 = x0 < p.rows ? at0 : (d0 == total ? 0x7fffffff : -1);
         const int lim1 = x1 < p.rows ? at1 : (d1 == total ? 0x7fffffff : -1);
         const bool verdict = ((x0 > 0 ? before0 : 0) == rs0) & (y0 <= lim0) & ((x1 > 0 ? before1 : 0) == rs1) & (y1 <= lim1) & (hc.y == y0) & (hc.w == y1);
+        if (lane == 0) s_verdict = verdict ? 1 : 0;
+        }
         // (nothing open at the end of a closed tile: what mspmv_debug_read_tiles reports.  By the last wave, here in the shadow of the
         //  gathers; a tile that fails the verdict has it overwritten by the general body)
         if (__builtin_amdgcn_readfirstlane(tid) >= BLOCK - WAVE) { if (tid == BLOCK - 1) { Carry<V> c; c.key = x1; c.value = (V) 0; carries[tile] = c; } }
@@ -2556,7 +2611,7 @@ aligned:
                 st_lds4(&s_prod[4 * (tid + k * BLOCK)], prod);
             }
         __syncthreads();
-        go = verdict;
+        go = s_verdict;
     }
 staged:
     asm volatile("" : "+v"(go));                                       // (opaque: the test below is not threaded back into the two places `go` comes from)
@@ -2627,7 +2682,7 @@ longer_rows:
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT, bool COMPACT = false>
 __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK, IPT, true>())) void tile_kernel_snap(Coord *__restrict__ coords, int *__restrict__ rstart,
-                                                           const int *epoch_words, int num_tiles, int xcd_chunk_log2,
+                                                           int num_tiles, int xcd_chunk_log2,
                                                            Params<V> p, Carry<V> *__restrict__ carries, LookBack lb, int lean_avg)
 {
     constexpr int TILE = BLOCK * IPT;
@@ -2665,14 +2720,13 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
 #ifdef MSPMV_DEV
     if (snap_tr && tid == 0) snap_tr[0] = t_entry;
 #endif
-    // (epoch_words == lb.error, the same two words under a second name -- hence no __restrict__ on it)
-    static_assert(sizeof(coords) + sizeof(rstart) + sizeof(epoch_words) + sizeof(num_tiles) + sizeof(xcd_chunk_log2) == 32, "the five leading arguments fill the 8 preloaded dwords");
-    // THE FIRST FIVE ARGUMENTS -- all the hint request needs -- are in SGPRs when the wave starts (kernel-argument preload, 8 dwords:
+    static_assert(sizeof(coords) + sizeof(rstart) + sizeof(num_tiles) + sizeof(xcd_chunk_log2) <= 32, "the four leading arguments lie inside the 8 preloaded dwords");
+    // THE FIRST FOUR ARGUMENTS -- all the hint request needs -- are in SGPRs when the wave starts (kernel-argument preload, 8 dwords:
     // the Makefile's -amdgpu-kernarg-preload-count=8), the tile index below is branch-free scalar arithmetic on them, and the other
     // arguments are pinned behind the hint request: the block's first memory round trip is the hints AND the rest of the kernel
     // arguments together, where the arguments (in three batches, as the compiler sank them to their uses) came first.
     const int tile = COMPACT ? (int) blockIdx.x : xcd_chunked_tile_flat((int) blockIdx.x, num_tiles, xcd_chunk_log2);
-    // the hints: the tile's two boundaries (x, y), their row starts, and the epoch of the record tags, read THROUGH THE SCALAR
+    // the hints: the tile's two boundaries (x, y) and their row starts, read THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
     // same-box A/B in profiles/r03_scalar_hints.txt), and since round 4 in the small tile shape as well (two lanes' vector
@@ -2684,9 +2738,8 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
     // requesting a tiny x -- comes first; the block has nothing else to do until its hints are there anyway.
     const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
     int4v hint_c; int2v hint_r;
-    unsigned epoch = 0u;                                            // (mixed into the record tags: "NOTHING DEPENDS ON A RECORD ARRIVING")
-    asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x4\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(hint_c), "=&s"(hint_r), "=&s"(epoch) : "s"(coords + tile), "s"(rstart + tile), "s"(epoch_words) : "memory");
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(hint_c), "=&s"(hint_r) : "s"(coords + tile), "s"(rstart + tile) : "memory");
     // (uses in this very basic block: the loads of these arguments stay up here, requested before the wait above)
     asm volatile("" :: "s"(p.row_end), "s"(p.cols), "s"(p.values), "s"(p.x), "s"(p.y), "s"(p.rows), "s"(p.nnz), "s"(p.x_lds), "s"(lean_avg),
                  "s"(carries), "s"(lb.rec), "s"(lb.tag_a), "s"(lb.tag_b), "s"(lb.error), "s"(lb.call_tag), "s"(lb.max_polls), "s"(p.band_pass));
@@ -2700,7 +2753,7 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
     //  place, by 1-2 %)
     const bool late_barrier = s_x != nullptr;                       // block-uniform
     if constexpr (!layout_hints<V, IPT>()) { if (!late_barrier) __syncthreads(); }      // (the large shapes: see below)
-    const LookBack lbe = with_epoch(lb, epoch);
+    const LookBack &lbe = lb;
     MSPMV_SNAP_TR(1);
     const int total = p.rows + p.nnz;                               // < 2^31
     // (32-bit: tile < num_tiles = ceil(total / TILE), so tile * TILE < total <= 2^31 - 65537 and adding TILE cannot overflow)

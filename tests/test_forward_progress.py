@@ -67,20 +67,31 @@ def _check(M, csr, x, y, extra=2):
     assert ok, worst
 
 
+def _records_are_clean(M, csr, ws):
+    """every record slot of the temp storage is (0, 0) once a launch has ended (mspmv_kernels.hpp: "EVERY RECORD SLOT IS CLEAN")"""
+    info = M.launch_info(csr.rows, csr.nnz, csr.values.dtype.itemsize)
+    torch.cuda.synchronize()
+    lo, n = info["records_offset"], (info["num_tiles"] + info["num_tiles"] // 64 + 1) * 16
+    assert int(ws.buffer[lo: lo + n].view(torch.int64).count_nonzero().item()) == 0
+
+
 @pytest.mark.parametrize("kind", ["giant", "many_long", "power_law"])
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_one_look_poll_budget_recomputes_and_stays_right(M, kind, prec):
     """mspmv_set_record_polls(1 / -1): a tile in which a long row ends looks ONCE for each record, or not at all, and otherwise
-    adds up the row's earlier nonzeros itself.  Every row within the strict bound of the oracle; afterwards (epoch moved on, records of the
-    recomputing calls left uncleared in the temp storage) the default call gives bit for bit what it gave before."""
+    adds up the row's earlier nonzeros itself.  Every row within the strict bound of the oracle; afterwards (every record slot clean again: a
+    cancelled slot's late record is wiped by its publisher) the default call gives bit for bit what it gave before, and the record region of
+    the temp storage holds nothing but zeros."""
     dtype = np.float32 if prec == "f32" else np.float64
     csr, x = _matrix(kind, dtype, np.random.default_rng(len(kind) + (prec == "f64")))
     _run.d = (dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x))
     ws = M.CsrMVWorkspace(csr.rows, csr.nnz, torch.float32 if prec == "f32" else torch.float64)
+    ws.buffer.zero_()                         # (slots no tile of this matrix ever publishes to keep whatever the allocation held: zeros here)
     y_ref = _run(M, csr, x, ws)
     _check(M, csr, x, y_ref)
+    _records_are_clean(M, csr, ws)
     diag = M.launch_info(csr.rows, csr.nnz, csr.values.dtype.itemsize)["diag_offset"]
-    epoch = lambda: int(ws.buffer[diag + 4: diag + 8].view(torch.int32).item())
+    epoch = lambda: int(ws.buffer[diag + 4: diag + 8].view(torch.int32).item())          # (the episode counter)
     e0 = epoch()
     assert epoch() == e0                      # (ordinary calls never touch it)
     try:
@@ -92,13 +103,15 @@ def test_one_look_poll_budget_recomputes_and_stays_right(M, kind, prec):
     finally:
         M.set_record_polls(0)
     assert epoch() != e0                      # the recomputing path was taken
+    _records_are_clean(M, csr, ws)
     for _ in range(3):
         assert torch.equal(_run(M, csr, x, ws), y_ref)
+    _records_are_clean(M, csr, ws)
 
 
 def test_captured_call_replays_correctly_after_a_recomputing_episode(M):
-    """A captured call replays the tags it was captured with.  Calls that recomputed may leave records uncleared; the epoch word
-    they bump is mixed into the tags, so the replay -- same call tag, NEW x -- cannot take a stale record for its own."""
+    """A captured call replays the tags it was captured with.  No record outlives its launch -- a slot whose consumer gave up is
+    cancelled and its late record wiped by the publisher -- so the replay -- same call tag, NEW x -- finds nothing to mistake for its own."""
     rng = np.random.default_rng(5)
     csr, x = _matrix("many_long", np.float64, rng)
     _run.d = (dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x))

@@ -46,6 +46,7 @@ def main():
     torch.manual_seed(seed)
     t_end = time.time() + budget
     cases = 0
+    compact_pairs = 0
     worst = 0.0
     while time.time() < t_end:
         f32 = bool(rng.integers(0, 2))
@@ -79,7 +80,8 @@ def main():
         try:
             M.set_tuning(vb, shape[0], shape[1], flags)
             M.set_band_passes(vb, passes)
-            M.set_record_polls(int(rng.choice([0, 0, 0, 1, -1])))       # default / one look / never look at the published records: the recomputing path
+            polls = int(rng.choice([0, 0, 0, 1, -1]))
+            M.set_record_polls(polls)       # default / one look / never look at the published records: the recomputing path
             mode = rng.integers(0, 5)
             if mode == 3:                              # prepared band-major plan (mspmv_csrmv_plan_*)
                 x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
@@ -133,6 +135,21 @@ def main():
                 if rng.random() < 0.3: ws.prepare(off_v)
                 M.csrmv(val_v, off_v, col_v, x, y=y, num_cols=cols, workspace=ws,
                         alpha=None if mode == 0 else alpha, beta=None if mode == 0 else beta)
+                # the compact front end (problems of one block generation; its fast lane needs right hints: the SECOND call on a workspace)
+                # against the general kernel of the same library: bit for bit, whatever the flags make of the call
+                if rng.random() < 0.5 and polls != 1 and not (flags & 2):          # (not with the atomic fix-up, whose order varies from run to run; one look: whether a record is there at that look depends on timing -- the last bits of a long row may differ from call to call)
+                    ys = []
+                    for ct in (0, -1, int(rng.choice([0, 3, 100000]))):
+                        M.set_compact_tiles(ct)
+                        yc = y0.clone()
+                        M.csrmv(val_v, off_v, col_v, x, y=yc, num_cols=cols, workspace=ws,
+                                alpha=None if mode == 0 else alpha, beta=None if mode == 0 else beta)
+                        ys.append(yc)
+                    M.set_compact_tiles(0)
+                    if not (torch.equal(ys[0], ys[1]) and torch.equal(ys[2], ys[1]) and torch.equal(y, ys[1])):
+                        print(f"COMPACT != GENERAL seed={seed} case={cases}: f32={f32} rows={rows} cols={cols} nnz={nnz} flags={flags:#x} shape={shape} mode={mode}", flush=True)
+                        sys.exit(1)
+                    compact_pairs += 1
                 prod = val.double() * x.double()[col.long()]
                 g = segsum(prod)
                 s = segsum(prod.abs())
@@ -163,9 +180,11 @@ def main():
             M.set_tuning(vb)
             M.set_band_passes(vb, 0)
             M.set_record_polls(0)
+            M.set_compact_tiles(0)
         cases += 1
     torch.cuda.synchronize()
-    print(f"fuzz: {cases} cases in {budget:.0f} s, all within tolerance (worst |err|/bound = {worst:.3f})")
+    print(f"fuzz: {cases} cases in {budget:.0f} s, all within tolerance (worst |err|/bound = {worst:.3f}); {compact_pairs} of them also run with the "
+          f"compact front end on / off / at a random limit: bit for bit the same y")
 
 
 if __name__ == "__main__":
