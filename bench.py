@@ -29,8 +29,14 @@ the line is self-contained for an efficiency figure.
 
 value           = 2 * nnz_total / t  (GFLOP/s, whole job; reference formula gpu_spmv.cu:451-465)
 roofline        = algorithmic (compulsory) bytes of one tile_kernel launch / its average duration from
-                  hipEvents recorded on the launch stream (mspmv_profile_begin/_end), against the 8 TB/s
-                  HBM3E peak
+                  hipEvents recorded on the launch stream (mspmv_profile_begin/_end).  `bound` / `resident` say what that rate is
+                  read against: "hbm" -- the 8 TB/s HBM3E spec peak -- when the call's arrays are beyond the 256 MB Infinity Cache;
+                  "infinity_cache" when they fit it (they then stay there between SpMVs): `peak` is then the rate of a bare
+                  16-byte-per-lane read stream over a buffer of the same size MEASURED IN THIS RUN (mspmv_probe_read_stream),
+                  `frac_of_hbm_spec_peak` kept beside it.  `traffic` = L2 <-> fabric bytes of the tile kernel from two live
+                  rocprofv3 --pmc child runs (Infinity-Cache hits included: fabric traffic, not HBM traffic, for a resident record)
+sampled_check   = an untimed correctness witness of the very record: 2^16 seeded rows + the first, last and longest recomputed in fp64
+                  with torch gathers against the stated bound (no oracle import; parity proper is tests/ -m gpu); < 1 passes
 configs         = (N = 1, default workload) one sub-record per remaining single-GPU configuration of BASELINE.json, each
                   timed the same way on its own synthetic matrix -- config 1's --dense=5 matrix in fp64 with the product's
                   cpu_spmv kernel on the host cores beside it (`cpu`), C2 in fp64 (the reference's default precision,
@@ -38,7 +44,11 @@ configs         = (N = 1, default workload) one sub-record per remaining single-
                   config 3's two matrices as size-matched R-MAT stand-ins (the SuiteSparse files cannot be fetched
                   offline), config 4, config 5 on ONE GPU, and the reference's own --dense=32 streaming input -- with
                   ms_per_step, GFLOP/s, the reference's effective-bandwidth share of peak (gpu_spmv.cu:452-465), the tile
-                  kernel's roofline fraction, replayed counter traffic, and rocSPARSE csrmv on the same arrays (`vendor`).
+                  kernel's roofline fraction, live counter traffic (config 5 too: its CSR image is parked in /dev/shm for the two
+                  child runs), the sampled check, and rocSPARSE csrmv on the same arrays (`vendor`).  --mtx-dir DIR (default
+                  $MSPMV_C3_DIR): webbase-1M.mtx / com-Orkut.mtx / circuit5M.mtx found there replace the generated stand-ins,
+                  through the product's Matrix Market ingest; `data` says whether a record ran on the SuiteSparse file, on a
+                  stand-in file (tools/make_standin_mtx.py) or on a generated stand-in.
 cpu_baseline    = the PRODUCT's OpenMP merge-path kernel (merge_spmv_amd/host/merge_csrmv.hpp, what cpu_spmv
                   runs; pinned bit for bit against the oracle by tests/test_cpu_product_parity.py) on the
                   same matrix on this box's host cores: private first-touched arrays, threads = the cgroup

@@ -187,14 +187,17 @@ int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_
  * value_bytes to every call, asynchronous on `stream`); d_values / d_row_offsets passed to _apply must be the arrays
  * the plan was built for.  No reference counterpart (its HYB column is the precedent for set-up timed apart,
  * gpu_spmv.cu:106-257). ---- */
-/* Would the plan pay?  A cheap look at the column indices (synchronous: one small kernel + a 512-byte copy): 64 windows of 2048
- * consecutive nonzeros spread over the matrix; *median_lines_per_2048 = the median number of DISTINCT 128-byte lines of x a window
- * touches (-1: fewer than 2048 nonzeros), *wide_windows = how many windows span >= 3/4 of the columns.  Uniformly spread columns give
- * ~2000 (nothing to concentrate), stencils and bands < 200 (their gathers hit the caches as they are), scale-free matrices 1200-1850:
- * columns that come back -- the case the plan is for.  mspmv_mg_plan_* builds the plan by itself when x is beyond the Infinity
- * Cache and 512 <= median < 1905 with >= 48 wide windows (mspmv_mg_plan_hot_columns). */
+/* Would the plan pay?  A cheap look at the column indices (synchronous: a bitmap of one bit per 128-byte line of x, one small kernel,
+ * a 12-byte copy): 512 windows of 2048 consecutive nonzeros spread over the matrix (~1 M references); *distinct_permille_of_uniform =
+ * 1000 x the number of DISTINCT lines of x the sample touches / what as many uniformly drawn references would touch (-1: fewer than
+ * 2048 nonzeros), *wide_windows = how many of the 512 windows span >= 3/4 of the columns.  Uniformly spread columns give ~1000
+ * (nothing to concentrate), stencils and bands < 100 (their gathers hit the caches as they are), scale-free matrices 400-700: lines
+ * that keep coming back -- the case the plan is for.  mspmv_mg_plan_* builds the plan by itself when x is beyond the Infinity Cache
+ * and 150 <= the figure < 800 with >= 256 wide windows (mspmv_mg_plan_hot_columns).  Measured (profiles/r05_skew_probe.txt):
+ * uniform columns 1000 / 512 wide, a band 48 / 0, a 5-point grid 206 / 0, R-MAT scale 22-26 289-374 / 370-450 (config 5: 351 / 372),
+ * a circuit-shaped matrix 634 / 492, a small R-MAT (scale 18: every line of its 2 MB x referenced) 842 / 456. */
 int mspmv_csrmv_hotcols_skew(const int32_t *d_column_indices, int32_t cols, int32_t nnz, int32_t value_bytes, mspmv_stream_t stream,
-                             int32_t *median_lines_per_2048, int32_t *wide_windows);
+                             int32_t *distinct_permille_of_uniform, int32_t *wide_windows);
 int mspmv_csrmv_hotcols_size(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, size_t *plan_bytes);
 int mspmv_csrmv_hotcols_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets,
                               const int32_t *d_column_indices, int32_t rows, int32_t cols, int32_t nnz,
@@ -439,8 +442,8 @@ int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info);
  * 4 * local_nnz + 16 * cols bytes; mspmv_mg_csrmv permutes x into the part's numbering before its SpMV):
  *   enable < 0   AUTOMATIC, the default of every plan: decided per part when its matrix is attached (mspmv_mg_plan_set_part) -- a
  *                part gets the plan when the x replica is beyond the 256 MB Infinity Cache (cols * value_bytes) AND the on-device
- *                sample of its column indices says the columns come back (mspmv_csrmv_hotcols_skew: 512 <= median distinct lines per
- *                2048 nonzeros < 1905, >= 48 of 64 windows spanning most of x): config 5, every part 33 -> 21 ms-equivalent.  Uniformly
+ *                sample of its column indices says the columns come back (mspmv_csrmv_hotcols_skew: ~1 M sampled references touch 15-80 % of
+ *                the distinct lines of x a uniform draw would, >= 256 of 512 windows spanning most of x): config 5, every part 33 -> 21 ms-equivalent.  Uniformly
  *                spread columns, stencils / bands, an x that fits the cache, or a part that cannot afford the storage: no plan.
  *   enable > 0   always (every local part; hipErrorOutOfMemory if one cannot)
  *   enable == 0  never; releases the storage

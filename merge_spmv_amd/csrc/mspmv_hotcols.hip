@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -208,28 +209,29 @@ int hot_apply(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t 
                          alpha, beta, !(alpha == (V) 1 && beta == (V) 0), stream, debug_sync, ex);
 }
 
-// ---- would the hot-column plan pay?  A cheap on-device look at the column indices (the pattern of band_detect_block): SKEW_WINDOWS
-// windows of SKEW_WINDOW consecutive nonzeros spread over the matrix; per window the number of DISTINCT 128-byte lines of x it touches
-// (a 65 536-bit map in LDS) and whether its columns span most of x.  Uniformly spread columns touch ~0.98 lines per nonzero (no reuse
-// a renumbering could concentrate), stencils and bands a few percent (their gathers hit the caches as they are), a scale-free matrix
-// 0.6-0.9: some columns come back again and again -- the hot ones the plan packs together.
-constexpr int SKEW_WINDOWS = 64, SKEW_WINDOW = 2048, SKEW_BITMAP_WORDS = 2048;
-__global__ __launch_bounds__(HC_BLOCK) void hot_skew_kernel(const int *__restrict__ cols, int nnz, int num_cols, int line_shift, int *__restrict__ out)
+// ---- would the hot-column plan pay?  A cheap on-device look at the column indices: SKEW_WINDOWS windows of SKEW_WINDOW consecutive
+// nonzeros spread over the matrix (~1 M references), every referenced 128-byte line of x marked in ONE bitmap over all lines of x;
+// the number of DISTINCT lines the sample touches, against what the same number of uniformly drawn references would touch
+// (L (1 - exp(-n / L)) of L lines).  Uniformly spread columns: ~1.0 (nothing to concentrate); a scale-free matrix: 0.4-0.7 -- part of
+// the references keeps coming back to the same lines, the hot ones the plan packs together (BASELINE config 5, R-MAT scale 26: 62 % of
+// the references go to 4 MB of x); stencils and bands: a few percent (their gathers hit the caches as they are).  Also: how many
+// windows span most of x (a band does not).  (A first version counted distinct lines per WINDOW of 2048 nonzeros: short-range reuse,
+// which a hot set of 4 MB does not show -- config 5 looked uniform to it.)
+constexpr int SKEW_WINDOWS = 512, SKEW_WINDOW = 2048;
+__global__ __launch_bounds__(HC_BLOCK) void hot_skew_kernel(const int *__restrict__ cols, int nnz, int num_cols, int line_shift, unsigned *__restrict__ bitmap,
+                                                           unsigned *__restrict__ out /* [0] distinct lines, [1] wide windows, [2] samples */)
 {
-    __shared__ unsigned s_bits[SKEW_BITMAP_WORDS];
     __shared__ int s_red[3][HC_BLOCK / 64];
     const int tid = threadIdx.x, w = blockIdx.x;
-    for (int i = tid; i < SKEW_BITMAP_WORDS; i += HC_BLOCK) s_bits[i] = 0u;
-    __syncthreads();
     const long long start = nnz > SKEW_WINDOW ? (long long) w * (nnz - SKEW_WINDOW) / (SKEW_WINDOWS - 1) : 0;
     const int len = nnz < SKEW_WINDOW ? nnz : SKEW_WINDOW;
     int fresh = 0, lo = 0x7fffffff, hi = -1;
     for (int j = tid; j < len; j += HC_BLOCK) {
         const int c = cols[start + j];
         lo = c < lo ? c : lo; hi = c > hi ? c : hi;
-        const unsigned line = ((unsigned) c >> line_shift) & (SKEW_BITMAP_WORDS * 32u - 1u);
+        const unsigned line = (unsigned) c >> line_shift;
         const unsigned bit = 1u << (line & 31u);
-        fresh += (atomicOr(&s_bits[line >> 5], bit) & bit) ? 0 : 1;
+        fresh += (atomicOr(&bitmap[line >> 5], bit) & bit) ? 0 : 1;
     }
     for (int d = 32; d > 0; d >>= 1) {
         fresh += __shfl_xor(fresh, d, 64);
@@ -240,8 +242,9 @@ __global__ __launch_bounds__(HC_BLOCK) void hot_skew_kernel(const int *__restric
     __syncthreads();
     if (tid == 0) {
         for (int k = 1; k < HC_BLOCK / 64; ++k) { fresh += s_red[0][k]; lo = s_red[1][k] < lo ? s_red[1][k] : lo; hi = s_red[2][k] > hi ? s_red[2][k] : hi; }
-        out[2 * w] = len == SKEW_WINDOW ? fresh : -1;
-        out[2 * w + 1] = 4LL * ((long long) hi - lo) >= 3LL * num_cols ? 1 : 0;
+        atomicAdd(&out[0], (unsigned) fresh);
+        if (4LL * ((long long) hi - lo) >= 3LL * num_cols) atomicAdd(&out[1], 1u);
+        atomicAdd(&out[2], (unsigned) len);
     }
 }
 
@@ -293,27 +296,32 @@ const int32_t *mspmv_csrmv_hotcols_columns(const void *d_plan, int32_t rows, int
 
 
 int mspmv_csrmv_hotcols_skew(const int32_t *d_column_indices, int32_t cols, int32_t nnz, int32_t value_bytes, mspmv_stream_t stream_,
-                             int32_t *median_lines_per_2048, int32_t *wide_windows)
+                             int32_t *distinct_permille_of_uniform, int32_t *wide_windows)
 {
-    if (!d_column_indices || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8) || !median_lines_per_2048) return hipErrorInvalidValue;
-    *median_lines_per_2048 = -1;
+    if (!d_column_indices || cols < 0 || nnz < 0 || (value_bytes != 4 && value_bytes != 8) || !distinct_permille_of_uniform) return hipErrorInvalidValue;
+    *distinct_permille_of_uniform = -1;
     if (wide_windows) *wide_windows = 0;
-    if (nnz < SKEW_WINDOW) return hipSuccess;                         // too small to say (and far too small to need the plan)
+    if (nnz < SKEW_WINDOW || cols < 1) return hipSuccess;            // too small to say (and far too small to need the plan)
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    int *d_out = nullptr;
-    hipError_t e = hipMalloc(&d_out, sizeof(int) * 2 * SKEW_WINDOWS);
+    const int line_shift = value_bytes == 4 ? 5 : 4;
+    const long long lines = (((long long) cols - 1) >> line_shift) + 1;
+    const size_t words = (size_t) ((lines + 31) / 32) + 4;            // bitmap, then the three result words
+    unsigned *d_map = nullptr;
+    hipError_t e = hipMalloc(&d_map, words * sizeof(unsigned));
     if (e != hipSuccess) return (int) e;
-    hipLaunchKernelGGL(hot_skew_kernel, dim3(SKEW_WINDOWS), dim3(HC_BLOCK), 0, stream, d_column_indices, nnz, cols, value_bytes == 4 ? 5 : 4, d_out);
-    int h[2 * SKEW_WINDOWS];
-    e = hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, stream);
+    e = hipMemsetAsync(d_map, 0, words * sizeof(unsigned), stream);
+    unsigned h[3] = {0, 0, 0};
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(hot_skew_kernel, dim3(SKEW_WINDOWS), dim3(HC_BLOCK), 0, stream, d_column_indices, nnz, cols, line_shift, d_map, d_map + words - 4);
+        e = hipMemcpyAsync(h, d_map + words - 4, sizeof(h), hipMemcpyDeviceToHost, stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void) hipFree(d_out);
+    (void) hipFree(d_map);
     if (e != hipSuccess) return (int) e;
-    int fresh[SKEW_WINDOWS], wide = 0;
-    for (int w = 0; w < SKEW_WINDOWS; ++w) { fresh[w] = h[2 * w]; wide += h[2 * w + 1]; }
-    std::nth_element(fresh, fresh + SKEW_WINDOWS / 2, fresh + SKEW_WINDOWS);
-    *median_lines_per_2048 = fresh[SKEW_WINDOWS / 2];
-    if (wide_windows) *wide_windows = wide;
+    // what h[2] uniformly drawn references would touch of `lines` lines (windows may overlap on a small matrix: an upper bound then)
+    const double expect = (double) lines * (1.0 - exp(-(double) h[2] / (double) lines));
+    *distinct_permille_of_uniform = expect > 0 ? (int32_t) (1000.0 * (double) h[0] / expect + 0.5) : -1;
+    if (wide_windows) *wide_windows = (int32_t) h[1];
     return hipSuccess;
 }
 

@@ -808,7 +808,7 @@ static int part_hot(mspmv_mg_plan *plan, Part &q, bool want)
 
 // AUTOMATIC (the default): a part whose x replica is beyond the Infinity Cache -- every gather that misses the L2s then moves a
 // 128-byte line from DRAM, 55 G lines/s on MI355X whatever the kernel does -- and whose columns come back (a scale-free matrix:
-// the median window of 2048 nonzeros touches 512 .. 1904 distinct lines of x and spans most of it; mspmv_csrmv_hotcols_skew) gets the
+// a sample of ~1 M references touches 15 .. 80 % of the distinct lines a uniform draw would, and spans x; mspmv_csrmv_hotcols_skew) gets the
 // plan; a part of uniformly spread columns (nothing to concentrate), of a stencil or a band (already cache-friendly), or with an x
 // that fits the cache does not.  A part that cannot afford the plan's memory runs without it.  y is bit for bit the same either way.
 static int part_hot_auto(mspmv_mg_plan *plan, Part &q)
@@ -820,7 +820,7 @@ static int part_hot_auto(mspmv_mg_plan *plan, Part &q)
     const int st = mspmv_csrmv_hotcols_skew(q.cols, (int32_t) plan->cols, q.local_nnz, plan->value_bytes, q.stream, &median, &wide);
     if (st != 0) return st;
     q.hot_median = median; q.hot_wide = wide;
-    const bool want = median >= 512 && median < 1905 && wide >= 48;
+    const bool want = median >= 150 && median < 800 && wide >= 256;        // (distinct lines per mille of a uniform draw; 512 windows: profiles/r05_skew_probe.txt)
     const int built = part_hot(plan, q, want);
     return built == (int) hipErrorOutOfMemory ? 0 : built;
 }

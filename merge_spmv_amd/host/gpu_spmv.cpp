@@ -84,14 +84,16 @@ void ChunkTimes(int iterations, Call &&call)
     HIP_OK(hipEventSynchronize(ev[(size_t) chunks]));
     printf("\tchunk times (us per call, %d calls per chunk):", g_chunk);
     float lo = 1e30f, hi = 0;
+    std::vector<float> all;
     for (int k = 0, it = 0; k < chunks; ++k) {
         const int n = std::min(g_chunk, iterations - it); it += n;
         float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t) k], ev[(size_t) k + 1]));
         const float us = ms * 1000.0f / n;
-        lo = std::min(lo, us); hi = std::max(hi, us);
+        lo = std::min(lo, us); hi = std::max(hi, us); all.push_back(us);
         printf(" %.2f", us);
     }
-    printf("\n\tchunk min %.2f us, max %.2f us\n", lo, hi);
+    std::sort(all.begin(), all.end());
+    printf("\n\tchunk min %.2f us, max %.2f us, median %.2f us\n", lo, hi, all[all.size() / 2]);
     for (auto &e : ev) (void) hipEventDestroy(e);
 }
 

@@ -35,9 +35,9 @@ def y_of(plan, row_split):
     return torch.cat([plan.y(g)[: int(row_split[g + 1] - row_split[g])] for g in range(parts)]).clone()
 
 
-n = 1 << 18                                                      # x = 2 MiB > the faked 1 MiB cache
+n = 1 << 18                                                      # x = 2 MiB (uniform) ... 16 MiB (scale-free) > the faked 1 MiB cache
 cases = {
-    "scale_free": G.rmat_csr(18, 6_000_000, dtype=torch.float64, device=dev, seed=G.SEED_C5),
+    "scale_free": G.rmat_csr(21, 12_000_000, dtype=torch.float64, device=dev, seed=G.SEED_C5),      # (x = 16 MiB: lines that keep coming back)
     "uniform": G.uniform_csr(n, n, 16, dtype=torch.float64, device=dev),
     "band": G.grid2d_csr(512, torch.float64, device=dev),
 }
@@ -49,7 +49,7 @@ for name, A in cases.items():
         x = G.uniform_pm1(7, A.cols, torch.float64, dev)
         plan.x(0).copy_(x); torch.cuda.synchronize()
         chosen = plan.info()["hot_parts"]
-        print(f"{name}: median distinct lines per 2048 nonzeros {median.value}, wide windows {wide.value}, parts with the plan {chosen}", flush=True)
+        print(f"{name}: distinct lines {median.value} per mille of a uniform draw, wide windows {wide.value} / 512, parts with the plan {chosen}", flush=True)
         assert chosen == (parts if name == "scale_free" else 0), (name, chosen, median.value, wide.value)
         y_auto = y_of(plan, row_split)
         assert plan.exchange_ms(0) >= 0.0

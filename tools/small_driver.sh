@@ -11,11 +11,11 @@
 cd "$(dirname "$0")/../merge_spmv_amd" || exit 1
 CPU=${CPU:-192}; nproc_all=$(nproc --all); [ "$CPU" -ge "$nproc_all" ] && CPU=0
 PIN="taskset -c $CPU"
-echo "## part 1: gpu_spmv --grid2d=<w> --i=2000, bound to CPU $CPU; us per call: loop average (steady level = the fastest chunk of 100 calls)"
+echo "## part 1: gpu_spmv --grid2d=<w> --i=2000, bound to CPU $CPU; us per call: loop average (steady level = the MEDIAN chunk of 100 calls)"
 for w in ${SIZES:-30 100 300 500 600 700 800 900 1000 1200 2000}; do
   $PIN ./gpu_spmv --grid2d=$w --no-strict --no-hyb --i=2000 --chunk-times=100 2>&1 | awk -v w=$w '
     /num_nonzeros:/ {nz=$2} /^Merge-based CsrMV/ {name="ours"} /^rocSPARSE CsrMV/ {name="rocSPARSE"}
-    /^fp64: / { t[name]=$5*1000 } /chunk min/ { mn[name]=$3 }
+    /^fp64: / { t[name]=$5*1000 } /chunk min/ { mn[name]=$9 }
     END { printf "grid2d_%-5d nnz %9d:  ours %.2f (%.2f)  rocSPARSE %.2f (%.2f)  -> %s\n", w, nz, t["ours"], mn["ours"], t["rocSPARSE"], mn["rocSPARSE"], (mn["ours"] <= mn["rocSPARSE"] * 1.01 ? "ours <= rocSPARSE" : "rocSPARSE ahead") }'
 done
 if [ -x ../tools/ab_driver ]; then
