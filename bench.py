@@ -379,7 +379,7 @@ def load_mtx(torch, G, path, tdt, dev):
         stand_in = STANDIN_MARK.encode() in f.readline()
     st = ctypes.c_int(0)
     f32 = tdt == torch.float32
-    h = H.mspmv_host_matrix_create(b"market", 0, 0, path.encode(), 1 if f32 else 0, ctypes.byref(st))
+    h = H.mspmv_host_matrix_create(b"mtx", 0, 0, path.encode(), 1 if f32 else 0, ctypes.byref(st))
     try:
         if st.value != 0:
             raise RuntimeError(f"{path}: {H.mspmv_host_matrix_error(h).decode(errors='replace')}")

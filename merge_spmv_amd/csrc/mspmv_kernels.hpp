@@ -2569,7 +2569,8 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     }
     // ---- row offsets x0 .. x1 (a row's start and end both come from here), one per lane and round: no alignment, no ragged end
     rov[0] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid < n_ro ? tid : 0)) << 2);
-    if (BLOCK < n_ro) rov[1] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid + BLOCK < n_ro ? tid + BLOCK : 0)) << 2);      // block-uniform
+    // (a round is taken by the waves that have entries in it: a tile of 300 rows has 45 in the second round, all in the first wave)
+    if (wave_base + BLOCK < n_ro) rov[1] = compact_ld<int>(row_offsets, (unsigned) (x0 + (tid + BLOCK < n_ro ? tid + BLOCK : 0)) << 2);      // wave-uniform
     if (__builtin_expect(2 * BLOCK < n_ro, 0)) goto more_row_offsets;
 have_row_offsets:
     // the one ragged chunk the nonzero arrays can end with was fetched at nnz - 4: its elements are put where they belong
@@ -2601,7 +2602,7 @@ aligned:
         if (__builtin_amdgcn_readfirstlane(tid) >= BLOCK - WAVE) { if (tid == BLOCK - 1) { Carry<V> c; c.key = x1; c.value = (V) 0; carries[tile] = c; } }
         // ---- LDS: row offsets as they are, products at their raw positions (element e of the array -> slot e - a0)
         s_ro[tid] = rov[0];
-        if (BLOCK < n_ro) s_ro[tid + BLOCK] = rov[1];
+        if (wave_base + BLOCK < n_ro) s_ro[tid + BLOCK] = rov[1];
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
             if (k == 0 || live1) {                                      // (slots of a chunk nobody staged are never a row's products: reads past a row's end are discarded)
