@@ -421,7 +421,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         bool compact = false;
         if constexpr (BLOCK == COMPACT_BLOCK && IPT == COMPACT_IPT) {
             compact = !nt && ex.tile_map == 0 && L.num_tiles > 1 && L.num_tiles <= (ex.tune.compact_tiles > 0 ? ex.tune.compact_tiles : ex.tune.compact_tiles < 0 ? 0 : compact_max_tiles((int) sizeof(V))) &&
-                      (unsigned long long) ex.num_cols * sizeof(V) < (1ull << 32);      // (32-bit byte offsets in the fast lane)
+                      (unsigned long long) ex.num_cols * sizeof(V) < (1ull << 32) && (unsigned long long) p.nnz * sizeof(V) < (1ull << 32) &&
+                      (unsigned long long) p.rows * 4ull < (1ull << 32) - 8;      // (32-bit byte offsets in the fast lane: every array < 4 GB)
             if (compact) {
                 // (a tiny x is gathered from memory here, not from an LDS copy: the copy pays on matrices that stream from HBM, a problem of
                 //  one block generation has x in its caches anyway -- 3.5 -> 2.8 us per call on a 900-row grid -- and the result is the same
