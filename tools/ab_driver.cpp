@@ -87,14 +87,25 @@ static void run(const char *pa, const char *pb, bool f32, int loops, int calls, 
         CK(hipMemcpy(d_off, off.data(), (rows + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_col, col.data(), nnz * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_val, val.data(), nnz * sizeof(V), hipMemcpyHostToDevice)); CK(hipMemcpy(d_x, x.data(), rows * sizeof(V), hipMemcpyHostToDevice));
         size_t ta = 0, tb = 0; void *wa, *wb;
-        CK((hipError_t) A.csrmv(nullptr, &ta, d_val, d_off, d_col, d_x, d_y[0], rows, rows, nnz, nullptr, 0)); CK(hipMalloc(&wa, ta));
-        CK((hipError_t) B.csrmv(nullptr, &tb, d_val, d_off, d_col, d_x, d_y[1], rows, rows, nnz, nullptr, 0)); CK(hipMalloc(&wb, tb));
+        // (the temp storages sit between guard zones of GUARD bytes of 0xA5, checked after the loops: a write outside [wa, wa + ta) shows)
+        const size_t GUARD = 4096; char *ga, *gb;
+        CK((hipError_t) A.csrmv(nullptr, &ta, d_val, d_off, d_col, d_x, d_y[0], rows, rows, nnz, nullptr, 0)); CK(hipMalloc(&ga, ta + 2 * GUARD));
+        CK((hipError_t) B.csrmv(nullptr, &tb, d_val, d_off, d_col, d_x, d_y[1], rows, rows, nnz, nullptr, 0)); CK(hipMalloc(&gb, tb + 2 * GUARD));
+        CK(hipMemset(ga, 0xA5, ta + 2 * GUARD)); CK(hipMemset(gb, 0xA5, tb + 2 * GUARD));
+        wa = ga + GUARD; wb = gb + GUARD;
+        std::vector<V> yh((size_t) rows);                      // the sequential definition on the host
+        for (int r = 0; r < rows; ++r) { V t = 0; for (int k = off[r]; k < off[r + 1]; ++k) t += val[k] * x[col[k]]; yh[r] = t; }
         rocsparse_mat_descr descr; rocsparse_mat_info info; RK(rocsparse_create_mat_descr(&descr)); RK(rocsparse_create_mat_info(&info));
         RK(Roc<V>::analysis(handle, rocsparse_operation_none, rows, rows, nnz, descr, d_val, d_off, d_col, info));
         const V one = 1, zero = 0;
         auto fa = [&] { A.csrmv(wa, &ta, d_val, d_off, d_col, d_x, d_y[0], rows, rows, nnz, nullptr, 0); };
         auto fb = [&] { B.csrmv(wb, &tb, d_val, d_off, d_col, d_x, d_y[1], rows, rows, nnz, nullptr, 0); };
         auto fr = [&] { Roc<V>::csrmv(handle, rocsparse_operation_none, rows, rows, nnz, &one, descr, d_val, d_off, d_col, info, d_x, &zero, d_y[2]); };
+        {   // rocSPARSE BEFORE any call of ours has run on this matrix
+            fr(); std::vector<V> y0(rows); CK(hipMemcpy(y0.data(), d_y[2], rows * sizeof(V), hipMemcpyDeviceToHost));
+            for (int i = 0; i < rows; ++i) if (std::abs((double) y0[i] - (double) yh[i]) > 1e-3 * std::abs((double) yh[i])) {
+                printf("# rocSPARSE's FIRST call after its analysis, before any call of ours: row %d = %.6g, the sequential sum is %.6g\n", i, (double) y0[i], (double) yh[i]); break; }
+        }
         for (int i = 0; i < 50; ++i) { fa(); fb(); fr(); }
         CK(hipDeviceSynchronize());
         std::vector<float> va, vb, vr;
@@ -111,13 +122,24 @@ static void run(const char *pa, const char *pb, bool f32, int loops, int calls, 
         CK(hipMemcpy(ya.data(), d_y[0], rows * sizeof(V), hipMemcpyDeviceToHost)); CK(hipMemcpy(yb.data(), d_y[1], rows * sizeof(V), hipMemcpyDeviceToHost));
         CK(hipMemcpy(yr.data(), d_y[2], rows * sizeof(V), hipMemcpyDeviceToHost));
         const bool same = memcmp(ya.data(), yb.data(), rows * sizeof(V)) == 0;
-        double dmax = 0; for (int i = 0; i < rows; ++i) dmax = std::max(dmax, (double) std::abs(ya[i] - yr[i]));
+        double dmax = 0; int imax = 0;
+        for (int i = 0; i < rows; ++i) { const double d = std::abs((double) ya[i] - (double) yr[i]); if (d > dmax) { dmax = d; imax = i; } }
+        {
+            std::vector<unsigned char> g(ta + 2 * GUARD); CK(hipMemcpy(g.data(), ga, g.size(), hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t i = 0; i < GUARD; ++i) bad += (g[i] != 0xA5) + (g[GUARD + ta + i] != 0xA5);
+            std::vector<unsigned char> h(tb + 2 * GUARD); CK(hipMemcpy(h.data(), gb, h.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < GUARD; ++i) bad += (h[i] != 0xA5) + (h[GUARD + tb + i] != 0xA5);
+            if (bad) printf("# GUARD ZONES AROUND THE TEMP STORAGE TOUCHED: %zu bytes\n", bad);
+            double ea = 0, er = 0; for (int i = 0; i < rows; ++i) { ea = std::max(ea, (double) std::abs(ya[i] - yh[i])); er = std::max(er, (double) std::abs(yr[i] - yh[i])); }
+            if (ea > 1e-3 || er > 1e-3) printf("# against the sequential sum on the host: max |A - host| %.3g, max |R - host| %.3g\n", ea, er);
+        }
+        if (dmax > 1e-3) printf("# LARGE DIFFERENCE at row %d of %d: A %.6g  B %.6g  R %.6g\n", imax, rows, (double) ya[imax], (double) yb[imax], (double) yr[imax]);
         float ma, na, mb, nb, mr, nr; stats(va, ma, na); stats(vb, mb, nb); stats(vr, mr, nr);
         printf("grid2d_%-5d nnz %9d: A %.2f (%.2f)  B %.2f (%.2f)  R %.2f (%.2f)   host enqueue A %.2f B %.2f R %.2f   A == B bitwise: %s, max |A - R| %.2g\n", w, nnz, ma, na, mb, nb, mr, nr, ha, hb, hr, same ? "yes" : "NO", dmax);
         fflush(stdout);
         RK(rocsparse_destroy_mat_info(info)); RK(rocsparse_destroy_mat_descr(descr));
         if (tune_b && B.set_compact) B.set_compact(0);
-        CK(hipFree(d_off)); CK(hipFree(d_col)); CK(hipFree(d_val)); CK(hipFree(d_x)); for (auto p : d_y) CK(hipFree(p)); CK(hipFree(wa)); CK(hipFree(wb));
+        CK(hipFree(d_off)); CK(hipFree(d_col)); CK(hipFree(d_val)); CK(hipFree(d_x)); for (auto p : d_y) CK(hipFree(p)); CK(hipFree(ga)); CK(hipFree(gb));
     }
     RK(rocsparse_destroy_handle(handle));
 }
