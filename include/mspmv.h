@@ -308,9 +308,9 @@ int mspmv_probe_read_stream(const void *d_buf, size_t bytes, int32_t nontemporal
  * re-association, the last bits of such a row do. */
 int mspmv_set_record_polls(int32_t polls);
 /* Testing / tuning aid (per HOST THREAD): up to how many tiles a call of the small tile shape runs the one-launch kernel behind its
- * COMPACT FRONT END (csrc/mspmv_kernels.hpp: compact_front -- problems of one block generation; closed lean tiles on good hints take
+ * COMPACT FRONT END (csrc/mspmv_kernels.hpp: compact_front -- small problems, one contiguous tile range per XCD; closed lean tiles on good hints take
  * ~200 instructions per wave of straight-line code at the head of the kernel, every other tile the general body of the same kernel).
- * 0 = the library default (1024 tiles in fp64, 1408 in fp32: about one block generation), > 0 = that many, < 0 = never.  y is bit for bit the same
+ * 0 = the library default (2304 tiles: the sizes at which the matrix stays in the XCDs' L2s between calls), > 0 = that many, < 0 = never.  y is bit for bit the same
  * either way (tests/test_gpu_parity.py: the `compact` / `no_compact` paths).  Matches the reference's special case for small
  * problems (dispatch_spmv_orig.cuh:674-679, agent_spmv_orig.cuh:867-891). */
 int mspmv_set_compact_tiles(int32_t max_tiles);

@@ -30,7 +30,8 @@ constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
 constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 constexpr int DEV_FLAG_MASK = 1 | 0xff00 | 0x70000 | 0xf00000;   // selectors of the -DMSPMV_DEV kernel variants
-constexpr int SMALL_MAX_TILES_DEFAULT = 1408;    // fp32: up to this many 256x7 tiles a problem takes that shape, 256x11 beyond (1024 until the compact front end: grid2d-700 fp32, 1366 tiles, 5.48 -> 4.83 us)
+constexpr int SMALL_MAX_TILES_DEFAULT = 2304;    // fp32: up to this many 256x7 tiles a problem takes that shape, 256x11 beyond (1024 until the compact front end, 1408 until its
+                                                 // launches took one contiguous tile range per XCD: grid2d-900 fp32, 2258 tiles, 7.5 -> 6.7 us)
 // (MSPMV_SMALL_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
 static int small_max_tiles()
 {
@@ -41,14 +42,26 @@ static int small_max_tiles()
 // Closed tiles of the one-launch kernel whose rows average at most this many nonzeros take the lean row-by-row reduction
 // (mspmv_kernels.hpp: consume_tile_rows); MSPMV_LEAN_AVG in the environment overrides it (read once: a re-tuning aid), 0 = never
 constexpr int LEAN_AVG_DEFAULT = 8;
-// The compact front end serves problems of about ONE block generation (the compact variant is compiled for 4 blocks per CU): up to
-// 1024 tiles in fp64, 1408 in fp32 -- measured with the limit lifted (tools/ab_driver, profiles/r05_compact_limit.txt): beyond, the
-// general kernel with its XCD-chunked tile order and 7 resident blocks per CU is ahead (fp64 grid2d-700, 1366 tiles: 7.28 vs 7.75 us;
-// fp32 grid2d-800, 1784 tiles: 6.04 vs 6.25).  MSPMV_COMPACT_MAX_TILES in the environment overrides both (read once: a re-tuning aid), 0 = never
+// The compact front end serves problems of up to 2304 tiles of the small shape (both precisions): about the sizes at which the matrix
+// stays in the XCDs' L2s from one call to the next -- each XCD works on ONE CONTIGUOUS RANGE of the tiles (compact_tile), the same range in
+// every call, 6 (fp64) / 8 (fp32) blocks per CU.  Measured with the limit lifted (tools/ab_driver, profiles/r05_compact_limit.txt): 5-point
+// grids in fp64 at 1366 / 1784 / 2258 / 2788 / 4014 tiles 6.1 / 8.4 / 10.8 / 12.8 / 16.3 us against the general kernel's 7.1 / 8.9 / 11.0 /
+// 12.7 / 16.8; fp32 at 1784 / 2258 / 2516 / 2788 tiles 5.3 / 6.7 / 7.8 / 9.1 against 5.9 / 7.0 / 7.8 / 9.1; small R-MAT and circuit-shaped
+// matrices, most of whose tiles run the general body behind the front end, within +-3 % (tools/compact_other_matrices.py).  With tile =
+// block index (the first form, round 5) the limit was one block generation.  MSPMV_COMPACT_MAX_TILES in the environment overrides it (read
+// once: a re-tuning aid), 0 = never
 static int compact_max_tiles(int value_bytes)
 {
     static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAX_TILES"); return e ? atoi(e) : -1; }();
-    return v >= 0 ? v : value_bytes == 8 ? 1024 : 1408;
+    (void) value_bytes;
+    return v >= 0 ? v : 2304;
+}
+// block -> tile map of the compact launches (mspmv_kernels.hpp: compact_tile): 1 = one contiguous tile range per XCD, 0 = tile = block;
+// MSPMV_COMPACT_MAP in the environment overrides it (read once: a re-tuning aid)
+static int compact_tile_map()
+{
+    static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAP"); return e ? (atoi(e) != 0) : 1; }();
+    return v;
 }
 static int lean_avg_default()
 {
@@ -77,7 +90,7 @@ static thread_local Tune t_tune[2];
 static inline const Tune &thread_tune(int value_bytes) { return t_tune[value_bytes == 8]; }
 
 // Default shape (measured on MI355X with the one-launch kernel; profiles/r03_small_shapes.txt, r03_sweep_vs_rocsparse.txt):
-//  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (1408; 1024 until round 5) tiles -- more, smaller tiles keep more CUs
+//  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (2304; 1024 until round 5) tiles -- more, smaller tiles keep more CUs
 //    busy on a small matrix: 4.4-5.6 us per call up to 1.4 M nonzeros where 256x11 takes 4.9-5.9 --, 256x11 beyond (the
 //    fastest or within 1 % of the fastest shape on every larger workload tried);
 //  * fp64: 256x7 (7 resident blocks per CU instead of 5) up to 8 M path items, 256x11 beyond (24 M until the large shape
@@ -417,7 +430,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
         // (every launch below is ONE call into the HIP runtime -- launch_exact: hipLaunchKernel with its status -- and the compact
         //  variant needs nothing else from it: the reference's timing loop is bound by the enqueueing thread for small problems)
         hipError_t launched = hipSuccess;
-        // problems of one block generation: the same kernel behind its compact front end (kernels: compact_front) -- bit for bit the same y
+        // small problems (compact_max_tiles): the same kernel behind its compact front end (kernels: compact_front) -- bit for bit the same y
         bool compact = false;
         if constexpr (BLOCK == COMPACT_BLOCK && IPT == COMPACT_IPT) {
             compact = !nt && ex.tile_map == 0 && L.num_tiles > 1 && L.num_tiles <= (ex.tune.compact_tiles > 0 ? ex.tune.compact_tiles : ex.tune.compact_tiles < 0 ? 0 : compact_max_tiles((int) sizeof(V))) &&
@@ -425,10 +438,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                       (unsigned long long) p.rows * 4ull < (1ull << 32) - 8;      // (32-bit byte offsets in the fast lane: every array < 4 GB)
             if (compact) {
                 // (a tiny x is gathered from memory here, not from an LDS copy: the copy pays on matrices that stream from HBM, a problem of
-                //  one block generation has x in its caches anyway -- 3.5 -> 2.8 us per call on a 900-row grid -- and the result is the same
+                //  this size has x in its caches anyway -- 3.5 -> 2.8 us per call on a 900-row grid -- and the result is the same
                 //  bit for bit, tests/test_gpu_parity.py::test_tiny_x_is_gathered_from_lds)
                 Params<V> pc = p; pc.x_lds = 0;
-                launched = launch_snap_compact<V>(axpby, grid, 0, stream, coords, rstart, L.num_tiles, pc, carries, lb, lean_avg);
+                launched = launch_snap_compact<V>(axpby, grid, 0, stream, coords, rstart, L.num_tiles, pc, carries, lb, lean_avg, compact_tile_map());
             }
         }
         if (!compact) {

@@ -1947,6 +1947,23 @@ __device__ __forceinline__ int xcd_chunked_tile_flat(int b, int num_tiles, int c
     return chunk_log2 == TILE_MAP_CONTIGUOUS ? contiguous : chunk_log2 > 0 ? chunked : b;
 }
 
+// The compact launches (small problems: up to 2304 tiles): ONE CONTIGUOUS TILE RANGE PER XCD (map != 0), the same range in every call.
+// Blocks are dealt round-robin to the XCDs (block b -> XCD b % 8), so with tile = block index neighbouring tiles sit on eight different
+// XCDs and each fetches the x window of its rows for itself (a 5-point grid of 500^2: 10.9 KB of x beside the 17 KB of the tile's own
+// streams); with one range per XCD the window is fetched once per XCD, the lines that straddle tile boundaries once instead of twice
+// -- and a matrix of up to ~4 MB per XCD appears to be still in that XCD's L2 at the next call of a solver's loop (where the advantage
+// ends: 2300-2800 tiles, 4-6 MB per XCD; mspmv_api.hip: compact_max_tiles).  Measured (tools/ab_driver, interleaved with the block-index map, fp64 / fp32 5-point grids):
+// 697 tiles 4.35 -> 4.13 / 3.29 -> 3.27 us per call, 1003 tiles 5.31 -> 4.69 / 3.75 -> 3.53, 1366 tiles 7.05 -> 6.09 / 4.64 -> 4.07.
+// Forward progress is not a matter of order here either: a tile that needs another workgroup's record (a long row ending in it) polls a
+// bounded number of times and then computes the sum itself; inside a range a lower-numbered tile sits on an earlier block, only the
+// first tiles of a range (and group leaders at a range's edge) look at blocks dispatched after them.
+__device__ __forceinline__ int compact_tile(int b, int num_tiles, int map)
+{
+    const int q8 = num_tiles >> 3, r8 = num_tiles & 7, xcd = b & 7;
+    const int contiguous = xcd * q8 + (xcd < r8 ? xcd : r8) + (b >> 3);
+    return map ? contiguous : b;                  // (scalar arithmetic and a select: nothing between the wave's start and its hint request)
+}
+
 // What the tile kernel needs to know about them (BAND variants of tile_kernel_vec; verdict == nullptr otherwise)
 struct BandArgs {
     const int *verdict;        // BAND_WINDOWS verdicts of band_detect_block
@@ -2491,7 +2508,7 @@ __device__ __forceinline__ Vec4<double> compact_ld4(const double *base, int e)
 // of more than 511 rows, rows of more than 8 nonzeros) behind it, reached by `goto` and left by `goto`.
 template <typename V, bool AXPBY>
 __device__ __forceinline__ void compact_front(const Coord *coords, const int *rstart, int num_tiles, const Params<V> &p,
-                                              Carry<V> *__restrict__ carries, int lean_avg, int tile, V *s_prod, int *s_ro)
+                                              Carry<V> *__restrict__ carries, int lean_avg, int tile, V *s_prod, int *s_ro, int4v &hc, int2v &hr)
 {
     constexpr int BLOCK = COMPACT_BLOCK, IPT = COMPACT_IPT, TILE = BLOCK * IPT, CPT = IPT / 4 + 1;
     constexpr int HEAD_MAX = snap_head_max<BLOCK, IPT>();
@@ -2506,8 +2523,8 @@ __device__ __forceinline__ void compact_front(const Coord *coords, const int *rs
     int r0, r, start, len; bool valid; V acc; const V *src;
     int2v vw0 = {0, 0}, vw1 = {0, 0};
     __shared__ int s_verdict;
-    // ---- hints (scalar cache; the tile index is uniform).  Request and wait in ONE asm statement (see tile_kernel_snap)
-    int4v hc; int2v hr;
+    // ---- hints (scalar cache; the tile index is uniform).  Request and wait in ONE asm statement (see tile_kernel_snap).  They go
+    // back to the caller: a tile that is not taken runs the general body on THESE registers instead of waiting for the same 24 bytes again
     asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(hc), "=&s"(hr) : "s"(coords + tile), "s"(rstart + tile) : "memory");
     // (used in this very basic block: the kernel-argument loads are requested before the wait above)
@@ -2692,20 +2709,23 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
     constexpr int SLOTS = CPT * BLOCK * 4;
     constexpr int HEAD_MAX = snap_head_max<BLOCK, IPT>();
     static_assert(HEAD_MAX >= 64 && TILE + HEAD_MAX + 16 <= SLOTS, "room for the snapped rows");
-    __shared__ __attribute__((aligned(16))) end16_t s_end_raw[SLOTS];
+    // (COMPACT: the fast lane's 32-bit row offsets and the general body's 16-bit row ends share one array -- a block uses one of the two)
+    __shared__ __attribute__((aligned(16))) int s_end_words[COMPACT ? SLOTS : SLOTS / 2];
+    end16_t *const s_end_raw = reinterpret_cast<end16_t *>(s_end_words);
     __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
     __shared__ unsigned s_flag[SLOTS / 32 + 1];
     __shared__ int s_wave_key[NW];
     __shared__ V s_wave_val[NW];
     __shared__ int s_bnd[6];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];     // x, when it is tiny (p.x_lds)
-    // COMPACT (problems of one block generation): the fast lane for closed lean tiles on good hints comes first -- its own LDS layout
+    // COMPACT (small problems, mspmv_api.hip: compact_max_tiles): the fast lane for closed lean tiles on good hints comes first -- its own LDS layout
     // (32-bit row offsets) in an array of its own, the product array shared --; a tile it does not take runs the general body below
-    // from the start.  tile = block index in both.
+    // from the start, on the hints the front end loaded.  Same tile (compact_tile) in both.
+    int4v front_hc = {0, 0, 0, 0}; int2v front_hr = {0, 0};
     if constexpr (COMPACT) {
         static_assert(BLOCK == COMPACT_BLOCK && IPT == COMPACT_IPT && !NT, "the compact front end is written for the small tile shape");
-        __shared__ __attribute__((aligned(16))) int s_ro32[SLOTS];
-        compact_front<V, AXPBY>(coords, rstart, num_tiles, p, carries, lean_avg, (int) blockIdx.x, s_prod_raw, s_ro32);      // (a tile it takes ends there)
+        compact_front<V, AXPBY>(coords, rstart, num_tiles, p, carries, lean_avg, compact_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2), s_prod_raw, s_end_words,
+                                front_hc, front_hr);      // (a tile it takes ends there)
     }
 
     const int tid = threadIdx.x;
@@ -2726,7 +2746,7 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
     // the Makefile's -amdgpu-kernarg-preload-count=8), the tile index below is branch-free scalar arithmetic on them, and the other
     // arguments are pinned behind the hint request: the block's first memory round trip is the hints AND the rest of the kernel
     // arguments together, where the arguments (in three batches, as the compiler sank them to their uses) came first.
-    const int tile = COMPACT ? (int) blockIdx.x : xcd_chunked_tile_flat((int) blockIdx.x, num_tiles, xcd_chunk_log2);
+    const int tile = COMPACT ? compact_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2) : xcd_chunked_tile_flat((int) blockIdx.x, num_tiles, xcd_chunk_log2);
     // the hints: the tile's two boundaries (x, y) and their row starts, read THROUGH THE SCALAR
     // CACHE -- the tile index is uniform, and a scalar load neither queues behind the vector-memory traffic of the CU's other
     // blocks nor needs an LDS hop to reach every wave: 2-6 % on matrices streamed from HBM (grid2d-4096, dense32, band5, C4;
@@ -2739,8 +2759,9 @@ __global__ __launch_bounds__(BLOCK, (COMPACT ? 4 : tile_waves_per_simd<V, BLOCK,
     // requesting a tiny x -- comes first; the block has nothing else to do until its hints are there anyway.
     const bool single = num_tiles == 1;                             // one tile: its boundaries are (0, 0) and (rows, nnz)
     int4v hint_c; int2v hint_r;
-    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(hint_c), "=&s"(hint_r) : "s"(coords + tile), "s"(rstart + tile) : "memory");
+    if constexpr (COMPACT) { hint_c = front_hc; hint_r = front_hr; }          // (the compact front end's: it requested them)
+    else asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                      : "=&s"(hint_c), "=&s"(hint_r) : "s"(coords + tile), "s"(rstart + tile) : "memory");
     // (uses in this very basic block: the loads of these arguments stay up here, requested before the wait above)
     asm volatile("" :: "s"(p.row_end), "s"(p.cols), "s"(p.values), "s"(p.x), "s"(p.y), "s"(p.rows), "s"(p.nnz), "s"(p.x_lds), "s"(lean_avg),
                  "s"(carries), "s"(lb.rec), "s"(lb.tag_a), "s"(lb.tag_b), "s"(lb.error), "s"(lb.call_tag), "s"(lb.max_polls), "s"(p.band_pass));
@@ -2919,7 +2940,7 @@ static inline hipError_t launch_exact(void (*kernel)(P...), dim3 grid, dim3 bloc
 // host side of the compact variant (defined and instantiated in mspmv_compact.hip, the translation unit compiled for it)
 template <typename V>
 hipError_t launch_snap_compact(bool axpby, unsigned grid, size_t dyn_lds, hipStream_t stream, Coord *coords, int *rstart, int num_tiles,
-                         const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg);
+                         const Params<V> &p, Carry<V> *carries, const LookBack &lb, int lean_avg, int tile_map);
 
 // Single-launch alternative (MSPMV_TUNE_ATOMIC_FIX): one atomicAdd per carry,
 // like the reference's fp32 path (agent_segment_fixup.cuh:226-260); order of

@@ -71,13 +71,14 @@ def test_tuning_rejects_unknown_shapes():
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 11
     M.set_tuning(4)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
-    # default shapes: fp32 256x7 while that keeps the problem within 1408 tiles (1024 until round 5), 256x11 beyond; fp64 256x7 up to
+    # default shapes: fp32 256x7 while that keeps the problem within 2304 tiles (1024 until round 5), 256x11 beyond; fp64 256x7 up to
     # 8 M path items, 256x11 beyond.  Always ONE launch of row-snapped tiles (tile_kernel_snap, no fix-up) unless
     # MSPMV_TUNE_TWO_LAUNCH asks for the classic three
     assert M.launch_info(300_000, 1_000_000, 4)["items_per_thread"] == 7         # 1.3M items / 1792 = 726 tiles
     assert M.launch_info(300_000, 1_500_000, 4)["items_per_thread"] == 7         # 1005 tiles
     assert M.launch_info(300_000, 2_200_000, 4)["items_per_thread"] == 7         # 1396 tiles
-    assert M.launch_info(300_000, 2_300_000, 4)["items_per_thread"] == 11        # 1451 tiles of 256x7: the large-problem shape
+    assert M.launch_info(300_000, 3_700_000, 4)["items_per_thread"] == 7         # 2233 tiles
+    assert M.launch_info(300_000, 4_000_000, 4)["items_per_thread"] == 11        # 2400 tiles of 256x7: the large-problem shape
     info = M.launch_info(1_000_000, 3_500_000, 4)
     assert info["items_per_thread"] == 11 and info["fixup_levels"] == 0 and info["snap_head_max"] == 192
     M.set_tuning(4, 0, 0, 0x40000000)                                            # the classic three launches: one fix-up launch

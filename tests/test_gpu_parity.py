@@ -224,7 +224,7 @@ COMPACT_SHAPES.update({
 @pytest.mark.parametrize("shape", sorted(COMPACT_SHAPES))
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_compact_front_end_is_bitwise_the_general_kernel(M, shape, prec):
-    """Problems of one block generation run tile_kernel_snap behind its compact front end (mspmv_kernels.hpp: compact_front;
+    """Small problems (up to 2304 tiles) run tile_kernel_snap behind its compact front end (mspmv_kernels.hpp: compact_front;
     reference: the small-problem special case of dispatch_spmv_orig.cuh:674-679 / agent_spmv_orig.cuh:867-891): closed lean tiles
     on verified hints take a fast lane of ~200 instructions, every other tile the general body of the same kernel.  Same y, bit
     for bit, as the general kernel (mspmv_set_compact_tiles(-1)) -- on the first call (garbage hints: every tile falls through
@@ -913,7 +913,7 @@ def test_tiny_x_is_gathered_from_lds(M, prec, cols):
         csr = random_csr(rng, rows, cols, rng.integers(0, hi, rows), dtype)
         x = rng.uniform(-1, 1, cols).astype(dtype)
         got = {}
-        # ("compact": the default for a problem of one block generation -- the compact front end gathers even a tiny x from memory;
+        # ("compact": the default for a small problem -- the compact front end gathers even a tiny x from memory;
         #  every other entry runs with it switched off, so that the small-problem kernel's LDS copy is what is compared)
         for flags in ("compact", 0, 0x80000, 16, 16 | 0x80000):
             try:

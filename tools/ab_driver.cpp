@@ -4,7 +4,7 @@
 // reported.  Boxes differ by 0.1-0.3 us on these figures and single loops catch 10 ms stalls of the box (profiles/r05_small_chunk_times*):
 // a change of 0.1 us can only be read from interleaved loops in one process.
 //   build: make -C tools ab_driver
-//   run:   tools/ab_driver <libA.so> <libB.so> [--fp32] [--loops=9] [--calls=2000] [--tune-b=<compact tiles for B: -1 never>] [sizes ...]
+//   run:   tools/ab_driver <libA.so> <libB.so> [--fp32] [--loops=9] [--calls=2000] [--tune-b=<compact tiles for B: -1 never>] [--env-a=N=V] [--env-b=N=V] [sizes ...]
 // With <libB.so> = <libA.so> and --tune-b=-1 it compares the compact front end with the general kernel inside one library.
 #include <hip/hip_runtime.h>
 #include <rocsparse/rocsparse.h>
@@ -58,12 +58,13 @@ static float loop_us(int calls, F &&f)
 static void stats(std::vector<float> v, float &med, float &mn) { std::sort(v.begin(), v.end()); med = v[v.size() / 2]; mn = v[0]; }
 
 template <typename V>
-static void run(const char *pa, const char *pb, bool f32, int loops, int calls, int tune_b, int ipt_b, const std::vector<int> &sizes)
+static void run(const char *pa, const char *pb, bool f32, int loops, int calls, int tune_b, int ipt_b, const std::vector<int> &sizes, const char *env_a, const char *env_b)
 {
     Api<V> A = load<V>(pa, f32), B = load<V>(pb, f32);
     // --ipt-b=<n>: B runs the 256 x n tile shape whatever the size (mspmv_set_tuning; B must be another FILE than A: the tuning is per library instance)
     if (ipt_b > 0 && B.set_tuning && strcmp(pa, pb) != 0) B.set_tuning((int) sizeof(V), 256, ipt_b, 0);
     rocsparse_handle handle; RK(rocsparse_create_handle(&handle));
+    if (env_a || env_b) printf("# environment at first use: A %s | B %s\n", env_a ? env_a : "-", env_b ? env_b : "-");
     printf("# A = %s | B = %s%s | R = rocSPARSE csrmv after analysis; %s, %d loops of %d calls each, interleaved; us per call: median (min)\n", pa, pb,
            tune_b ? (std::string(" with mspmv_set_compact_tiles(") + std::to_string(tune_b) + ")").c_str() : "", f32 ? "fp32" : "fp64", loops, calls);
     for (int w : sizes) {
@@ -106,6 +107,10 @@ static void run(const char *pa, const char *pb, bool f32, int loops, int calls, 
             for (int i = 0; i < rows; ++i) if (std::abs((double) y0[i] - (double) yh[i]) > 1e-3 * std::abs((double) yh[i])) {
                 printf("# rocSPARSE's FIRST call after its analysis, before any call of ours: row %d = %.6g, the sequential sum is %.6g\n", i, (double) y0[i], (double) yh[i]); break; }
         }
+        // --env-a=NAME=VALUE / --env-b=...: put into the environment right before that library's FIRST launching call (the libraries
+        // read their re-tuning variables once, at first use; A and B must be two FILES then -- two instances)
+        auto put = [](const char *kv) { if (!kv) return; std::string t(kv); const size_t eq = t.find('='); if (eq != std::string::npos) setenv(t.substr(0, eq).c_str(), t.substr(eq + 1).c_str(), 1); };
+        put(env_a); fa(); put(env_b); fb();
         for (int i = 0; i < 50; ++i) { fa(); fb(); fr(); }
         CK(hipDeviceSynchronize());
         std::vector<float> va, vb, vr;
@@ -147,16 +152,18 @@ static void run(const char *pa, const char *pb, bool f32, int loops, int calls, 
 int main(int argc, char **argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: %s <libA.so> <libB.so> [--fp32] [--loops=9] [--calls=2000] [--tune-b=<n>] [sizes ...]\n", argv[0]); return 1; }
-    bool f32 = false; int loops = 9, calls = 2000, tune_b = 0, ipt_b = 0; std::vector<int> sizes;
+    bool f32 = false; int loops = 9, calls = 2000, tune_b = 0, ipt_b = 0; std::vector<int> sizes; const char *env_a = nullptr, *env_b = nullptr;
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--fp32")) f32 = true;
         else if (!strncmp(argv[i], "--loops=", 8)) loops = atoi(argv[i] + 8);
         else if (!strncmp(argv[i], "--calls=", 8)) calls = atoi(argv[i] + 8);
         else if (!strncmp(argv[i], "--tune-b=", 9)) tune_b = atoi(argv[i] + 9);
         else if (!strncmp(argv[i], "--ipt-b=", 8)) ipt_b = atoi(argv[i] + 8);
+        else if (!strncmp(argv[i], "--env-a=", 8)) env_a = argv[i] + 8;
+        else if (!strncmp(argv[i], "--env-b=", 8)) env_b = argv[i] + 8;
         else sizes.push_back(atoi(argv[i]));
     }
     if (sizes.empty()) sizes = {30, 100, 300, 500, 600, 700, 800, 900, 1000, 1200, 2000};
-    if (f32) run<float>(argv[1], argv[2], true, loops, calls, tune_b, ipt_b, sizes); else run<double>(argv[1], argv[2], false, loops, calls, tune_b, ipt_b, sizes);
+    if (f32) run<float>(argv[1], argv[2], true, loops, calls, tune_b, ipt_b, sizes, env_a, env_b); else run<double>(argv[1], argv[2], false, loops, calls, tune_b, ipt_b, sizes, env_a, env_b);
     return 0;
 }

@@ -135,7 +135,7 @@ def main():
                 if rng.random() < 0.3: ws.prepare(off_v)
                 M.csrmv(val_v, off_v, col_v, x, y=y, num_cols=cols, workspace=ws,
                         alpha=None if mode == 0 else alpha, beta=None if mode == 0 else beta)
-                # the compact front end (problems of one block generation; its fast lane needs right hints: the SECOND call on a workspace)
+                # the compact front end (small problems; its fast lane needs right hints: the SECOND call on a workspace)
                 # against the general kernel of the same library: bit for bit, whatever the flags make of the call
                 if rng.random() < 0.5 and polls != 1 and not (flags & 2):          # (not with the atomic fix-up, whose order varies from run to run; one look: whether a record is there at that look depends on timing -- the last bits of a long row may differ from call to call)
                     ys = []
