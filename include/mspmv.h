@@ -240,16 +240,24 @@ typedef struct mspmv_launch_info {
                                   (0, 0) again once a launch has ended (tests/test_forward_progress.py)                          */
 } mspmv_launch_info_t;
 
-/* value_bytes = 4 (float) or 8 (double). */
+/* value_bytes = 4 (float) or 8 (double).  The layout of a call of these sizes under the default choice of tile shape; temp_bytes is
+ * large enough for any column count (one family of calls picks its shape by the column count too: see mspmv_get_launch_info_cols). */
 int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes,
                           mspmv_launch_info_t *info);
+/* The same with the column count, i.e. exactly what mspmv_csrmv_f32 / _f64 (and _axpby_*) run for these sizes when given at least
+ * info->temp_bytes of temp storage: a large fp64 matrix (more than 8 M rows + nonzeros, at most 256 MB of CSR arrays) of at most 8
+ * nonzeros per row on average over an x of at most 4 KB -- the reference's --dense=<cols> inputs, cpu_spmv.cpp:581-587 -- takes the
+ * small tile shape behind the compact front end (csrc/mspmv_api.hip: skinny_rule); y is bit for bit the same either way. */
+int mspmv_get_launch_info_cols(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes,
+                               mspmv_launch_info_t *info);
 
 /* Copy the tile coordinates ((num_tiles+1) x {row, nonzero}) and the per-tile
  * carry pairs (num_tiles keys + values of value_bytes each) that the last
  * csrmv call left in d_temp back to HOST arrays (synchronises `stream`).
  * They correspond to d_tile_coordinates / d_tile_carry_pairs of
  * dispatch_spmv_orig.cuh:643-646 and are what the parity tests pin against
- * the oracle.  Any output pointer may be NULL. */
+ * the oracle.  Any output pointer may be NULL.  (Laid out as mspmv_get_launch_info says: not for the calls that pick their
+ * tile shape by the column count, mspmv_get_launch_info_cols.) */
 int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
                            int32_t value_bytes, int32_t *h_coords,
                            int32_t *h_carry_keys, void *h_carry_values,

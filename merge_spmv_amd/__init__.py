@@ -93,6 +93,8 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_version.restype = ctypes.c_int
     lib.mspmv_get_launch_info.restype = ctypes.c_int
     lib.mspmv_get_launch_info.argtypes = [i32, i32, i32, ctypes.POINTER(_LaunchInfo)]
+    lib.mspmv_get_launch_info_cols.restype = ctypes.c_int
+    lib.mspmv_get_launch_info_cols.argtypes = [i32, i32, i32, i32, ctypes.POINTER(_LaunchInfo)]
     lib.mspmv_debug_read_tiles.restype = ctypes.c_int
     lib.mspmv_debug_read_tiles.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     lib.mspmv_set_tuning.restype = ctypes.c_int
@@ -560,10 +562,16 @@ def plan_bench_record(A, x, y_stateless, steps: int = 50, warmup: int = 5, peak_
             "max_abs_diff_vs_stateless": diff, "max_abs_y": scale}
 
 
-def launch_info(num_rows: int, num_nonzeros: int, value_bytes: int) -> dict:
+def launch_info(num_rows: int, num_nonzeros: int, value_bytes: int, num_cols: Optional[int] = None) -> dict:
+    """mspmv_get_launch_info; with `num_cols` mspmv_get_launch_info_cols: exactly the layout a stateless call of these sizes runs (one
+    family of calls -- large fp64 matrices of short rows over a tiny x -- picks its tile shape by the column count too)."""
     info = _LaunchInfo()
-    _check(load_library().mspmv_get_launch_info(int(num_rows), int(num_nonzeros), int(value_bytes),
-                                                ctypes.byref(info)), "mspmv_get_launch_info")
+    if num_cols is None:
+        _check(load_library().mspmv_get_launch_info(int(num_rows), int(num_nonzeros), int(value_bytes),
+                                                    ctypes.byref(info)), "mspmv_get_launch_info")
+    else:
+        _check(load_library().mspmv_get_launch_info_cols(int(num_rows), int(num_cols), int(num_nonzeros), int(value_bytes),
+                                                         ctypes.byref(info)), "mspmv_get_launch_info_cols")
     return {name: getattr(info, name) for name, _ in _LaunchInfo._fields_}
 
 

@@ -126,12 +126,12 @@ struct Layout {
                            // passes on offer); the regions of the classic pipeline are laid out all the same
 };
 
-static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune)
+static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune, bool small_shape = false)
 {
     Layout L; memset(&L, 0, sizeof(L));
     const long long total = (long long) rows + nnz;
     L.flags = tune.flags;
-    L.shape = pick_shape(value_bytes, total, tune);
+    L.shape = small_shape ? Shape{COMPACT_BLOCK, COMPACT_IPT} : pick_shape(value_bytes, total, tune);
     const int tile = L.shape.block * L.shape.ipt;
     L.num_tiles = (int) ((total + tile - 1) / tile);
     const uint64_t pair = value_bytes == 8 ? 16 : 8;
@@ -452,7 +452,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             //  earlier block of the same XCD, so a tile that waits for records waits for blocks dispatched before it -- EXCEPT the first
             //  tiles of XCD k's range, which wait for the LAST tiles of XCD k - 1's range: few waiters, a bounded poll, then the sum
             //  recomputed from the matrix; correct, and slow only for a row longer than HEAD_MAX that crosses a range boundary)
-            const int chunk_log2 = ex.tile_map ? ex.tile_map : safe_chunk_log2(wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
+            // (MSPMV_SNAP_MAP in the environment, read once: 30 = one contiguous tile range per XCD for every one-launch call, 0 .. 8 = that run length; a re-tuning aid)
+            static const int env_map = [] { const char *e = getenv("MSPMV_SNAP_MAP"); return e ? atoi(e) : -1; }();
+            const int chunk_log2 = ex.tile_map ? ex.tile_map : env_map == TILE_MAP_CONTIGUOUS_CODE ? env_map
+                                 : safe_chunk_log2(env_map >= 0 && env_map <= 8 ? env_map : wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
 #define MSPMV_LAUNCH_SNAP(AX, NTF) launched = launch_exact(tile_kernel_snap<V, BLOCK, IPT, AX, NTF>, dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
             if (axpby) { if (nt) MSPMV_LAUNCH_SNAP(true, true); else MSPMV_LAUNCH_SNAP(true, false); }
             else if (nt) MSPMV_LAUNCH_SNAP(false, true);
@@ -661,6 +664,22 @@ hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<do
     return hipErrorInvalidValue;
 }
 
+// LARGE fp64 MATRICES OF SHORT ROWS OVER A TINY x (the reference's --dense=<cols> inputs: cpu_spmv.cpp:581-587 is --dense=5, BASELINE config 1's
+// matrix) take the SMALL tile shape behind the compact front end at any size that still streams with ordinary loads (<= 256 MB): every
+// tile of such a matrix is a closed lean tile, and the fast lane's 234 instructions per wave beat the large shape's general kernel --
+// --dense=5 at full size (16.8 M nonzeros, 11 235 tiles instead of 7 150) 35.8 -> 34.1 us per call (rocSPARSE: 35.5), 5-point grids of
+// 16 M nonzeros 39.8 -> 39.3 (tools/compact_other_matrices.py, profiles/r05_compact_other_matrices.txt).  Judged on what the host knows:
+// 8-byte values, the default tuning, a size that would take the large shape, x within the 4 KB that otherwise go to LDS, at most 8
+// nonzeros per row on average.  (Matrices with long rows among the short ones lose in the small shape's general body at these sizes --
+// R-MAT, 3400 tiles: +6...16 % -- and the host cannot tell them from grids unless x is tiny: a row over x of <= 512 entries is short.)
+// y does not depend on it: closed lean tiles sum every row left to right whatever the tile shape.
+static bool skinny_rule(int rows, int cols, int nnz, int value_bytes, const Tune &t, const Layout &L)
+{
+    return value_bytes == 8 && t.block == 0 && t.flags == 0 && t.compact_tiles == 0 && L.snap && L.shape.ipt != COMPACT_IPT &&
+           cols > 0 && (size_t) cols * 8u <= (size_t) X_LDS_MAX_BYTES && (long long) nnz <= 8LL * rows &&
+           (unsigned long long) nnz * 12ull + 4ull * (unsigned long long) rows <= (256ull << 20);      // (the dispatcher's `nt` threshold: ordinary loads)
+}
+
 template <typename V>
 int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_t *d_row_offsets, const int32_t *d_cols,
                const V *d_x, V *d_y, int32_t rows, int32_t cols, int32_t nnz, V alpha, V beta, bool axpby,
@@ -668,7 +687,15 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
     if ((long long) rows + nnz > MAX_ITEMS) return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, (int) sizeof(V), ex.tune);
+    Layout L = make_layout(rows, nnz, (int) sizeof(V), ex.tune);
+    bool skinny = false;
+    if (ex.allow_skinny && skinny_rule(rows, cols, nnz, (int) sizeof(V), ex.tune, L)) {
+        // (the size query asks for the larger of the two layouts; a caller that sized its storage without the column count --
+        //  mspmv_get_launch_info -- and brings less runs the default shape)
+        const Layout S = make_layout(rows, nnz, (int) sizeof(V), ex.tune, true);
+        if (d_temp == nullptr) { *temp_bytes = (size_t) (S.total > L.total ? S.total : L.total); return hipSuccess; }
+        if (*temp_bytes >= S.total) { L = S; skinny = true; }
+    }
     if (d_temp == nullptr) {                      // size query (dispatch_spmv_orig.cuh:651-655)
         *temp_bytes = (size_t) L.total;
         return hipSuccess;
@@ -687,6 +714,7 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
     p.x_lds = (cols > 0 && (size_t) cols * sizeof(V) <= (size_t) X_LDS_MAX_BYTES && !(L.flags & MSPMV_TUNE_NO_XLDS)) ? cols : 0;
     p.band_lo = 0; p.band_len = 0; p.band_pass = 0;
     CallExtra ex2 = ex;
+    if (skinny) ex2.tune.compact_tiles = 0x7fffffff;          // (the compact front end whatever the tile count)
     ex2.band_passes = band_passes_for(L, (long long) cols * (long long) sizeof(V), (int) sizeof(V), rows, nnz, ex, &ex2.band_force);
     ex2.band_cols = ex2.band_passes > 1 ? (cols + ex2.band_passes - 1) / ex2.band_passes : 0;
     ex2.num_cols = cols;
@@ -705,6 +733,7 @@ static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const
                       V beta, bool axpby, mspmv_stream_t stream_, int debug_sync, int phase = PHASE_ALL)
 {
     CallExtra ex; ex.phase = phase; ex.tune = thread_tune((int) sizeof(V));
+    ex.allow_skinny = phase == PHASE_ALL;
     return csrmv_call<V>(d_temp, temp_bytes, d_values, d_row_offsets, d_cols, d_x, d_y, rows, cols, nnz, alpha, beta, axpby,
                          reinterpret_cast<hipStream_t>(stream_), debug_sync, ex);
 }
@@ -963,12 +992,24 @@ int mspmv_csrmm_f64(void *d_temp, size_t *temp_bytes, const double *d_values, co
                               alpha, beta, stream, debug_sync);
 }
 
-int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)
+static int launch_info_impl(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)
 {
     if (!info || (value_bytes != 4 && value_bytes != 8) || rows < 0 || nnz < 0 ||
         (long long) rows + nnz > MAX_ITEMS)
         return hipErrorInvalidValue;
-    const Layout L = make_layout(rows, nnz, value_bytes, thread_tune(value_bytes));
+    const Tune &tune = thread_tune(value_bytes);
+    Layout L = make_layout(rows, nnz, value_bytes, tune);
+    // cols < 0 (mspmv_get_launch_info: the column count is not known): the default layout, with temp_bytes large enough for the small
+    // shape a large fp64 matrix of short rows over a tiny x takes (skinny_rule) -- a buffer sized from here serves either;
+    // cols >= 0 (mspmv_get_launch_info_cols): the layout a stateless call of exactly these sizes runs
+    uint64_t temp_bytes = L.total;
+    if (cols < 0) {
+        if (skinny_rule(rows, 1, nnz, value_bytes, tune, L))      // (the rule holds for SOME column count)
+            temp_bytes = std::max<uint64_t>(temp_bytes, make_layout(rows, nnz, value_bytes, tune, true).total);
+    } else if (skinny_rule(rows, cols, nnz, value_bytes, tune, L)) {
+        L = make_layout(rows, nnz, value_bytes, tune, true);
+        temp_bytes = std::max<uint64_t>(L.total, make_layout(rows, nnz, value_bytes, tune).total);
+    }
     memset(info, 0, sizeof(*info));
     info->block_threads = L.shape.block;
     info->items_per_thread = L.shape.ipt;
@@ -978,12 +1019,17 @@ int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_
     info->fixup_levels = L.snap ? 0 : L.fix_levels;     // (fix-up launches; 0: the tiles add the carries themselves)
     info->flags = L.flags;
     info->snap_head_max = L.snap ? snap_head_max_host(L.shape.block, L.shape.ipt) : 0;
-    info->temp_bytes = L.total;
+    info->temp_bytes = temp_bytes;
     info->coords_offset = L.coords_off;
     info->carries_offset = L.carries_off;
     info->diag_offset = L.err_off;
     info->records_offset = L.pub_off;
     return hipSuccess;
+}
+int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info) { return launch_info_impl(rows, -1, nnz, value_bytes, info); }
+int mspmv_get_launch_info_cols(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info)
+{
+    return cols < 0 ? hipErrorInvalidValue : launch_info_impl(rows, cols, nnz, value_bytes, info);
 }
 
 int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes, int32_t *h_coords,

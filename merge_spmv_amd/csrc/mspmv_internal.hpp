@@ -29,6 +29,7 @@ struct CallExtra {
     // column-band passes (filled in by csrmv_call, see band_passes_for): > 1 = tile_kernel_band may serve the call
     int band_passes = 0, band_cols = 0, band_force = 0, num_cols = 0;
     bool no_bands = false;  // callers that must not take them (the band-major plan: its stacked matrix is banded already)
+    bool allow_skinny = false;   // the stateless public calls only: a large fp64 matrix of short rows over a tiny x may take the small tile shape (mspmv_api.hip: skinny_rule)
 };
 constexpr int TILE_MAP_CONTIGUOUS_CODE = 30;
 

@@ -10,6 +10,7 @@ within the stated tolerance otherwise:
     c = 2*(ceil(log2(len_r+1)) + items_per_thread + 8), eps = 2^-24 | 2^-53,
     empty rows exactly 0                      (SURVEY.md 8d / BASELINE.md 2).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -621,6 +622,55 @@ def test_short_row_matrices_are_bitwise_the_sequential_definition(M, kind, prec)
         finally:
             M.set_tuning(vb)
         check_strict(M, csr, x, y2)
+
+
+def test_large_fp64_matrix_of_short_rows_over_a_tiny_x_takes_the_small_shape(M):
+    """mspmv_api.hip: skinny_rule -- the reference's --dense=<cols> family (cpu_spmv.cpp:581-587; --dense=5 is BASELINE config 1's
+    matrix) beyond 8 M path items runs the small tile shape behind the compact front end.  launch_info with the column count reports
+    that layout, without it the default one with temp_bytes large enough for either; y is BIT FOR BIT the oracle's sequential gold
+    (every tile is a closed lean tile) and bit for bit what the default shape gives (compact launches off: the rule does not apply)."""
+    rng = np.random.default_rng(55)
+    rows, cols = 1_700_000, 5                                     # 10.2 M path items
+    csr = random_csr(rng, rows, cols, np.full(rows, 5, np.int64), np.float64)
+    x = rng.uniform(-1, 1, cols)
+    plain = M.launch_info(csr.rows, csr.nnz, 8)
+    exact = M.launch_info(csr.rows, csr.nnz, 8, num_cols=cols)
+    assert plain["items_per_thread"] == 11 and exact["items_per_thread"] == 7 and exact["num_tiles"] > plain["num_tiles"]
+    assert plain["temp_bytes"] == exact["temp_bytes"] >= 16 * exact["num_tiles"]
+    assert M.launch_info(csr.rows, csr.nnz, 8, num_cols=csr.rows)["items_per_thread"] == 11        # (x is not tiny: the default shape)
+    assert M.launch_info(csr.rows, csr.nnz, 4, num_cols=cols)["items_per_thread"] == 11            # (fp32: the default shape)
+    size = ctypes.c_size_t(0)                                     # the C size query knows the column count
+    assert M.load_library().mspmv_csrmv_f64(None, ctypes.byref(size), None, None, None, None, None, rows, cols, csr.nnz, None, 0) == 0
+    assert size.value == exact["temp_bytes"]
+    y, ws = run_gpu(M, csr, x)
+    y2t = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")       # the second call on the workspace: on hints
+    M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=y2t, num_cols=cols, workspace=ws)
+    torch.cuda.synchronize(); y2 = y2t.cpu().numpy()
+    gold = O.spmv_gold(csr, x)
+    assert np.array_equal(y.view(np.uint64), gold.view(np.uint64)) and np.array_equal(y2.view(np.uint64), gold.view(np.uint64))
+    check_strict(M, csr, x, y)
+    try:
+        M.set_compact_tiles(-1)
+        assert M.launch_info(csr.rows, csr.nnz, 8, num_cols=cols)["items_per_thread"] == 11
+        y3, _ = run_gpu(M, csr, x)
+    finally:
+        M.set_compact_tiles(0)
+    assert np.array_equal(y3.view(np.uint64), y.view(np.uint64))
+    # a workspace that is too small for the small shape's layout runs the default shape (no error)
+    dv = torch.from_numpy(csr.values).cuda(); do = torch.from_numpy(csr.row_offsets).cuda(); dc = torch.from_numpy(csr.column_indices).cuda()
+    dx = torch.from_numpy(x).cuda(); dy = torch.empty(rows, dtype=torch.float64, device="cuda")
+    small = ctypes.c_size_t(0)
+    try:
+        M.set_compact_tiles(-1)
+        assert M.load_library().mspmv_csrmv_f64(None, ctypes.byref(small), None, None, None, None, None, rows, cols, csr.nnz, None, 0) == 0
+    finally:
+        M.set_compact_tiles(0)
+    assert small.value < size.value
+    buf = torch.empty(small.value, dtype=torch.uint8, device="cuda")
+    st = M.load_library().mspmv_csrmv_f64(ctypes.c_void_p(buf.data_ptr()), ctypes.byref(small), ctypes.c_void_p(dv.data_ptr()), ctypes.c_void_p(do.data_ptr()),
+                                          ctypes.c_void_p(dc.data_ptr()), ctypes.c_void_p(dx.data_ptr()), ctypes.c_void_p(dy.data_ptr()), rows, cols, csr.nnz, None, 0)
+    torch.cuda.synchronize()
+    assert st == 0 and np.array_equal(dy.cpu().numpy().view(np.uint64), gold.view(np.uint64))
 
 
 def test_circuit5m_shaped_stand_in_full_size_fp64(M):

@@ -11,7 +11,7 @@ import numpy as np, torch
 import merge_spmv_amd as M
 from merge_spmv_amd import generators as G
 
-CALLS = 500
+CALLS = int(os.environ.get('COMPACT_OTHER_CALLS', '500'))
 
 
 def captured(fn):
@@ -32,6 +32,20 @@ def loop(g):
 
 
 def cases(dt):
+    if os.environ.get("COMPACT_OTHER_FULL"):            # fp64 workloads of the sweep, 256x7 behind the compact front end against the default (256x11)
+        if dt == torch.float64:
+            yield "dense5 fp64 (16.8M)", lambda: G.dense_csr((1 << 24) // 5, 5, dtype=dt, ones=False)
+            yield "grid2d 2000 (16M)", lambda: G.grid2d_csr(2000, dtype=dt)
+            yield "grid3d 200 (47.8M)", lambda: G.grid3d_csr(200, dtype=dt)
+        return
+    if os.environ.get("COMPACT_OTHER_BIG"):             # the same families at 3400-4400 tiles of the small shape
+        yield "rmat20 5M", lambda: G.rmat_csr(20, 5_000_000, dtype=dt)
+        yield "circuit 600k rows 6.4M", lambda: G.circuit_csr(rows=600_000, nnz=6_400_000, dtype=dt)
+        yield "uniform32 200k rows 6.4M", lambda: G.uniform_csr(200_000, 200_000, 32, dtype=dt)
+        yield "grid3d 100 (6.9M)", lambda: G.grid3d_csr(100, dtype=dt)
+        yield "dense5 1.2M rows (6.0M)", lambda: G.dense_csr(1_200_000, 5, dtype=dt)
+        yield "grid2d 1200 (5.8M)", lambda: G.grid2d_csr(1200, dtype=dt)
+        return
     yield "rmat18 1.5M", lambda: G.rmat_csr(18, 1_500_000, dtype=dt)
     yield "rmat19 2.5M", lambda: G.rmat_csr(19, 2_500_000, dtype=dt)
     yield "circuit 300k rows 3.2M", lambda: G.circuit_csr(rows=300_000, nnz=3_200_000, dtype=dt)
@@ -48,16 +62,22 @@ for dt in (torch.float64, torch.float32):
         A = make()
         x = G.uniform_pm1(7, A.cols, dt, "cuda")
         y = torch.empty(A.rows, dtype=dt, device="cuda")
+        if os.environ.get("COMPACT_OTHER_FULL"): M.set_tuning(vb, 256, 7)          # (the larger temp storage of the two shapes)
         ws = M.CsrMVWorkspace(A.rows, A.nnz, dt)
+        M.set_tuning(vb)
         info = M.launch_info(A.rows, A.nnz, vb)
         call = lambda: M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=A.cols, workspace=ws)
         res = {}
+        force7 = bool(os.environ.get("COMPACT_OTHER_FULL"))
+        def setmode(mode):
+            M.set_compact_tiles(mode)
+            if force7: M.set_tuning(vb, 256, 7) if mode == 0 else M.set_tuning(vb)
         for mode in (0, -1):
-            M.set_compact_tiles(mode); call(); torch.cuda.synchronize(); res[mode] = [y.clone()]
+            setmode(mode); call(); torch.cuda.synchronize(); res[mode] = [y.clone()]
         t = {0: [], -1: []}; graphs = {}
         for mode in (0, -1):
-            M.set_compact_tiles(mode); graphs[mode] = captured(call)
-        M.set_compact_tiles(0)
+            setmode(mode); graphs[mode] = captured(call)
+        setmode(-1); M.set_compact_tiles(0)
         for _ in range(7):
             for mode in (0, -1): loop(graphs[mode]); t[mode].append(loop(graphs[mode]))
         same = bool(torch.equal(res[0][0], res[-1][0]))
