@@ -428,7 +428,7 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             ms, prof, ws, y = time_stateless(M, torch, A, x, k, min(warmup, 3))
             vb = A.values.element_size()
             b_alg = algorithmic_bytes(A.rows, A.cols, A.nnz, vb)
-            info = M.launch_info(A.rows, A.nnz, vb)
+            info = M.launch_info(A.rows, A.nnz, vb, num_cols=A.cols)          # (with the column count: the shape the stateless call runs)
             offered = M.band_passes(A.rows, A.cols, A.nnz, vb)
             # the tile kernel's duration: its hipEvent average on the launch stream (one-launch calls: the kernel IS the step -- the
             # wall clock per step of K back-to-back calls is reported beside it, not mixed into it)

@@ -247,7 +247,9 @@ int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes,
 /* The same with the column count, i.e. exactly what mspmv_csrmv_f32 / _f64 (and _axpby_*) run for these sizes when given at least
  * info->temp_bytes of temp storage: a large fp64 matrix (more than 8 M rows + nonzeros, at most 256 MB of CSR arrays) of at most 8
  * nonzeros per row on average over an x of at most 4 KB -- the reference's --dense=<cols> inputs, cpu_spmv.cpp:581-587 -- takes the
- * small tile shape behind the compact front end (csrc/mspmv_api.hip: skinny_rule); y is bit for bit the same either way. */
+ * small tile shape behind the compact front end (csrc/mspmv_api.hip: skinny_rule).  Rows of closed lean tiles -- every row of a
+ * --dense input -- are summed left to right whatever the shape, so their y does not change by a bit; a long row among them is
+ * associated as that shape's tiles cut it (the stated bound holds either way). */
 int mspmv_get_launch_info_cols(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes,
                                mspmv_launch_info_t *info);
 

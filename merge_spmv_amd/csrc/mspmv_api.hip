@@ -672,7 +672,8 @@ hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<do
 // 8-byte values, the default tuning, a size that would take the large shape, x within the 4 KB that otherwise go to LDS, at most 8
 // nonzeros per row on average.  (Matrices with long rows among the short ones lose in the small shape's general body at these sizes --
 // R-MAT, 3400 tiles: +6...16 % -- and the host cannot tell them from grids unless x is tiny: a row over x of <= 512 entries is short.)
-// y does not depend on it: closed lean tiles sum every row left to right whatever the tile shape.
+// Rows of closed lean tiles are summed left to right whatever the tile shape: their y does not change by a bit; a long row among them is
+// associated as the shape's tiles cut it, like under any other choice of shape (tools/fuzz.py compares against the general kernel of the shape run).
 static bool skinny_rule(int rows, int cols, int nnz, int value_bytes, const Tune &t, const Layout &L)
 {
     return value_bytes == 8 && t.block == 0 && t.flags == 0 && t.compact_tiles == 0 && L.snap && L.shape.ipt != COMPACT_IPT &&

@@ -139,13 +139,18 @@ def main():
                 # against the general kernel of the same library: bit for bit, whatever the flags make of the call
                 if rng.random() < 0.5 and polls != 1 and not (flags & 2):          # (not with the atomic fix-up, whose order varies from run to run; one look: whether a record is there at that look depends on timing -- the last bits of a long row may differ from call to call)
                     ys = []
-                    for ct in (0, -1, int(rng.choice([0, 3, 100000]))):
+                    # (a large fp64 matrix of short rows over a tiny x takes the small shape by the column count -- mspmv_api.hip: skinny_rule --
+                    #  and its result is bit for bit the general kernel's OF THAT SHAPE: the three variants then run under the forced small shape)
+                    skinny = M.launch_info(rows, nnz, vb, num_cols=cols)["items_per_thread"] != M.launch_info(rows, nnz, vb)["items_per_thread"]
+                    if skinny: M.set_tuning(vb, 256, 7, flags)
+                    for ct in ((1 << 30) if skinny else 0, -1, int(rng.choice([(1 << 30) if skinny else 0, 3, 100000]))):
                         M.set_compact_tiles(ct)
                         yc = y0.clone()
                         M.csrmv(val_v, off_v, col_v, x, y=yc, num_cols=cols, workspace=ws,
                                 alpha=None if mode == 0 else alpha, beta=None if mode == 0 else beta)
                         ys.append(yc)
                     M.set_compact_tiles(0)
+                    if skinny: M.set_tuning(vb, shape[0], shape[1], flags)
                     if not (torch.equal(ys[0], ys[1]) and torch.equal(ys[2], ys[1]) and torch.equal(y, ys[1])):
                         print(f"COMPACT != GENERAL seed={seed} case={cases}: f32={f32} rows={rows} cols={cols} nnz={nnz} flags={flags:#x} shape={shape} mode={mode}", flush=True)
                         sys.exit(1)
