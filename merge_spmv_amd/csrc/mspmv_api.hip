@@ -676,7 +676,7 @@ hipError_t dispatch_shape<double>(const Layout &L, void *d_temp, const Params<do
 // associated as the shape's tiles cut it, like under any other choice of shape (tools/fuzz.py compares against the general kernel of the shape run).
 static bool skinny_rule(int rows, int cols, int nnz, int value_bytes, const Tune &t, const Layout &L)
 {
-    return value_bytes == 8 && t.block == 0 && t.flags == 0 && t.compact_tiles == 0 && L.snap && L.shape.ipt != COMPACT_IPT &&
+    return value_bytes == 8 && t.block == 0 && t.flags == 0 && t.compact_tiles == 0 && compact_max_tiles(8) > 0 && L.snap && L.shape.ipt != COMPACT_IPT &&
            cols > 0 && (size_t) cols * 8u <= (size_t) X_LDS_MAX_BYTES && (long long) nnz <= 8LL * rows &&
            (unsigned long long) nnz * 12ull + 4ull * (unsigned long long) rows <= (256ull << 20);      // (the dispatcher's `nt` threshold: ordinary loads)
 }
