@@ -41,7 +41,10 @@ static int small_max_tiles()
 #define SMALL_MAX_TILES (small_max_tiles())
 // Closed tiles of the one-launch kernel whose rows average at most this many nonzeros take the lean row-by-row reduction
 // (mspmv_kernels.hpp: consume_tile_rows); MSPMV_LEAN_AVG in the environment overrides it (read once: a re-tuning aid), 0 = never
-constexpr int LEAN_AVG_DEFAULT = 8;
+// (8 until round 5.  12: the reference's --dense=9 ... 12 inputs at 16 M nonzeros in fp64 0.0350 / 0.0347 / 0.0340 -> 0.0318 / 0.0317 / 0.0314 ms --
+//  rocSPARSE 0.0334 / 0.0329 / 0.0328 --, fp32 0.0240 -> 0.0231, a 1 M-nonzero --dense=10 5.5 -> 3.7 us per call (its tiles reach the compact
+//  front end's fast lane), nothing else in the sweep moves; 16: rows of 16 lose -- 0.0331 -> 0.0422; profiles/r05_lean_avg.txt)
+constexpr int LEAN_AVG_DEFAULT = 12;
 // The compact front end serves problems of up to 2304 tiles of the small shape (both precisions): about the sizes at which the matrix
 // stays in the XCDs' L2s from one call to the next -- each XCD works on ONE CONTIGUOUS RANGE of the tiles (compact_tile), the same range in
 // every call, 6 (fp64) / 8 (fp32) blocks per CU.  Measured with the limit lifted (tools/ab_driver, profiles/r05_compact_limit.txt): 5-point
