@@ -109,7 +109,7 @@ def main():
                       f"fix {p['fixup_ms']:.4f}  | {2*A.nnz/total/1e6:9.1f} GFLOP/s  alg {balg/p['tile_ms']/1e6:8.1f} GB/s", flush=True)
         M.set_tuning(vb)
         total, pr = time_it(A, x)
-        info = M.launch_info(A.rows, A.nnz, vb)
+        info = M.launch_info(A.rows, A.nnz, vb, num_cols=A.cols)      # (the shape the default call runs: by the column count too)
         print(f"  DEFAULT {info['block_threads']}x{info['items_per_thread']}: total {total:8.4f} ms  search {pr['search_ms']:.4f} tile {pr['tile_ms']:.4f} fix {pr['fixup_ms']:.4f}  | {2*A.nnz/total/1e6:9.1f} GFLOP/s", flush=True)
         ws = M.CsrMVWorkspace(A.rows, A.nnz, A.values.dtype).prepare(A.row_offsets)
         yp = torch.empty(A.rows, dtype=A.values.dtype, device="cuda")
