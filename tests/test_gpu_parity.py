@@ -656,6 +656,19 @@ def test_large_fp64_matrix_of_short_rows_over_a_tiny_x_takes_the_small_shape(M):
     finally:
         M.set_compact_tiles(0)
     assert np.array_equal(y3.view(np.uint64), y.view(np.uint64))
+    # y = alpha A x + beta y through the same rule (mspmv_csrmv_axpby_f64): bit for bit what the default shape gives
+    y0 = torch.from_numpy(rng.uniform(-1, 1, rows)).cuda()
+    outs = []
+    for ct in (0, -1):
+        try:
+            M.set_compact_tiles(ct)
+            ya = y0.clone()
+            M.csrmv(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x), y=ya, num_cols=cols, alpha=0.5, beta=-1.0)
+            torch.cuda.synchronize(); outs.append(ya.cpu().numpy())
+        finally:
+            M.set_compact_tiles(0)
+    assert np.array_equal(outs[0].view(np.uint64), outs[1].view(np.uint64))
+    assert np.allclose(outs[0], 0.5 * gold - y0.cpu().numpy(), rtol=0, atol=1e-13)
     # a workspace that is too small for the small shape's layout runs the default shape (no error)
     dv = torch.from_numpy(csr.values).cuda(); do = torch.from_numpy(csr.row_offsets).cuda(); dc = torch.from_numpy(csr.column_indices).cuda()
     dx = torch.from_numpy(x).cuda(); dy = torch.empty(rows, dtype=torch.float64, device="cuda")
