@@ -1190,6 +1190,20 @@ template <typename V, int IPT> constexpr bool layout_hints() { return IPT <= 7; 
 // VALU issue, not bytes: profiles/r04_short_rows/.)
 template <typename V> struct CompactChain;
 template <> struct CompactChain<double> {
+    // the first half alone: rows of at most four products (the caller knows that no lane of the wave has more)
+    static __device__ __forceinline__ void add4(double &acc, const double (&v)[4], int len)
+    {
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f64 %[a], %[a], %[v0]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f64 %[a], %[a], %[v1]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f64 %[a], %[a], %[v2]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f64 %[a], %[a], %[v3]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(sv)
+                     : [l] "v"(len), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3])
+                     : "vcc");
+    }
     // acc (+0.0 on entry) += v[j] for j < len, left to right, lanes leaving as their row ends (EXEC restored)
     static __device__ __forceinline__ void add8(double &acc, const double (&v)[8], int len, int base)
     {
@@ -1211,6 +1225,20 @@ template <> struct CompactChain<double> {
     }
 };
 template <> struct CompactChain<float> {
+    // the first half alone: rows of at most four products (the caller knows that no lane of the wave has more)
+    static __device__ __forceinline__ void add4(float &acc, const float (&v)[4], int len)
+    {
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 0, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v0]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 1, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v1]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 2, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v2]\n\t"
+                     "v_cmpx_lt_i32_e32 vcc, 3, %[l]\n\tv_add_f32_e32 %[a], %[a], %[v3]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(sv)
+                     : [l] "v"(len), [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3])
+                     : "vcc");
+    }
     static __device__ __forceinline__ void add8(float &acc, const float (&v)[8], int len, int base)
     {
         unsigned long long sv;
@@ -1332,22 +1360,37 @@ __device__ __forceinline__ void consume_tile_rows(const Params<V> &p, const Coor
             len[h] = valid[h] ? e1 - e0[h] : 0;
         }
         if (r0 == 0) MSPMV_LEAN_TR(9);
+        // (a wave none of whose rows -- of this pair of rounds -- has more than four products reads and adds the first four of each only: the
+        //  row-strided product reads are bank-conflict-laden, 57 % of the LDS cycles of a 5-point grid's launch, and the LDS is busy for more
+        //  than half of such a kernel: profiles/r05_lds_counters.txt)
+        const bool more = __ballot(len[0] > LEAN_BATCH / 2 || len[1] > LEAN_BATCH / 2) != 0ull;      // wave-uniform
         V v[2][LEAN_BATCH];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < LEAN_BATCH; ++j) v[h][j] = s_prod_raw[pshift + e0[h] + j];
-        // (all of them requested here, in one go: without this the compiler sinks a read into the branch of the first addition that uses it)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < LEAN_BATCH; ++j) asm volatile("" : "+v"(v[h][j]));
-        // (what lies beyond the row becomes +0.0 first -- independent selects -- and is then added like the rest: the running sum is
-        //  never -0.0 (it starts from +0.0), so adding +0.0 leaves every bit of it, and the dependent chain is the additions alone)
+            for (int j = 0; j < LEAN_BATCH / 2; ++j) v[h][j] = s_prod_raw[pshift + e0[h] + j];
         V acc[2] = {(V) 0, (V) 0};
         static_assert(LEAN_BATCH == 8, "CompactChain adds eight");
+        if (more) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) CompactChain<V>::add8(acc[h], v[h], len[h], 0);
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = LEAN_BATCH / 2; j < LEAN_BATCH; ++j) v[h][j] = s_prod_raw[pshift + e0[h] + j];
+            // (all of them requested here, in one go: without this the compiler sinks a read into the branch of the first addition that uses it)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < LEAN_BATCH; ++j) asm volatile("" : "+v"(v[h][j]));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) CompactChain<V>::add8(acc[h], v[h], len[h], 0);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < LEAN_BATCH / 2; ++j) asm volatile("" : "+v"(v[h][j]));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { const V q[4] = {v[h][0], v[h][1], v[h][2], v[h][3]}; CompactChain<V>::add4(acc[h], q, len[h]); }
+        }
         if (r0 == 0) MSPMV_LEAN_TR(10);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -2649,11 +2692,24 @@ next_round:
         start = s_ro[rr]; const int end = s_ro[rr + 1];
         len = valid ? end - start : 0;
         src = s_prod + (start - a0);                                   // (start - a0 + 15 < SLOTS for any lane)
+        // THE PRODUCT READS ARE WHAT THE LANE WAITS FOR: lanes a row apart read 8-byte words 32 bytes (rows of 4) or 64 bytes (rows of 8)
+        // apart, 4 or 2 distinct bank groups for the 16 lanes of an LDS cycle -- SQ_LDS_BANK_CONFLICT is 65 % of the LDS cycles of a
+        // 5-point grid's call, and the LDS is busy for ~3/4 of such a kernel (profiles/r05_lds_counters.txt).  So a wave none of whose rows
+        // has more than four products (wave-uniform: one ballot) reads and adds the first four only.  (A third level -- six -- for rows of
+        // 5 and 6, whose strides conflict far less, measured no gain: profiles/r05_ab_half_batch.txt.)
         V v[LEAN_BATCH];
+        const bool more = __ballot(len > LEAN_BATCH / 2) != 0ull;
 #pragma unroll
-        for (int j = 0; j < LEAN_BATCH; ++j) v[j] = src[j];
+        for (int j = 0; j < LEAN_BATCH / 2; ++j) v[j] = src[j];
         acc = (V) 0;
-        CompactChain<V>::add8(acc, v, len, 0);
+        if (more) {
+#pragma unroll
+            for (int j = LEAN_BATCH / 2; j < LEAN_BATCH; ++j) v[j] = src[j];
+            CompactChain<V>::add8(acc, v, len, 0);
+        } else {
+            const V h[4] = {v[0], v[1], v[2], v[3]};
+            CompactChain<V>::add4(acc, h, len);
+        }
     }
     if (__builtin_expect(__ballot(len > LEAN_BATCH) != 0ull, 0)) goto longer_rows;
 store_row:
