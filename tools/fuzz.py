@@ -48,7 +48,22 @@ def main():
     cases = 0
     compact_pairs = 0
     worst = 0.0
+    # every case is watched: one that does not come back within 90 s is reported with what it was and the run ends (exit 3) -- a hang
+    # must not look like a budget that ran out
+    import threading
+    state = {"what": "start", "since": time.time(), "case": 0}
+    def watch():
+        while True:
+            time.sleep(5)
+            if time.time() - state["since"] > 90:
+                sys.stderr.write(f"fuzz: WATCHDOG -- case {state['case']} has not come back for 90 s: {state['what']}\n"); sys.stderr.flush()
+                sys.stdout.write(f"fuzz: WATCHDOG seed={seed} case={state['case']}: {state['what']}\n"); sys.stdout.flush()
+                os._exit(3)
+    threading.Thread(target=watch, daemon=True).start()
+    t_note = time.time()
     while time.time() < t_end:
+        if time.time() - t_note > 120:
+            print(f"fuzz: ... {cases} cases so far", flush=True); t_note = time.time()
         f32 = bool(rng.integers(0, 2))
         tdt = torch.float32 if f32 else torch.float64
         vb = 4 if f32 else 8
@@ -77,12 +92,14 @@ def main():
             shape = (256, 7) if (not f32 and rng.random() < 0.4) else (256, 11)
             flags |= 16; flags &= ~4; passes = int(rng.integers(2, 10))
         cfac = 2.0 * (torch.ceil(torch.log2(lens_t + 1)) + 16 + 8 + passes)
+        state.update(what=f"f32={f32} rows={rows} cols={cols} nnz={nnz} flags={flags:#x} shape={shape} passes={passes} offsets={a_off, c_off, r_off}", since=time.time(), case=cases)
         try:
             M.set_tuning(vb, shape[0], shape[1], flags)
             M.set_band_passes(vb, passes)
             polls = int(rng.choice([0, 0, 0, 1, -1]))
             M.set_record_polls(polls)       # default / one look / never look at the published records: the recomputing path
             mode = rng.integers(0, 5)
+            state["what"] += f" mode={int(mode)} polls={polls}"
             if mode == 3:                              # prepared band-major plan (mspmv_csrmv_plan_*)
                 x = (torch.rand(cols, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
                 colp = col
