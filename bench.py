@@ -1,59 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- CsrMV throughput of the MI355X-native merge-based SpMV.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: either under a launcher -- python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... -- or
-     plainly, in which case bench.py starts that launcher itself: self_launch)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or plainly -- self_launch)
 
 A "step" is one y = A*x through the C ABI (include/mspmv.h); inputs are resident in HBM before timing.
 
-N = 1 (default workload "c2"): BASELINE.json config 2, the configuration the metric is quoted on for one
-GPU -- fp32, 3 125 000 x 3 125 000, exactly 32 nnz/row = 100 000 000 nnz, uniform random sorted columns
- -- through the stateless drop-in call mspmv_csrmv_f32 (which, on a matrix like this one, lets the
-tile kernel run its column-band passes: `column_band_passes` in the roofline record says whether and how many;
-DESIGN.md 4).  The same line carries a
-`prepared_plan` sub-record: the opt-in band-major plan (mspmv_csrmv_plan_*; set-up reported separately,
-like the reference reports the HYB conversion, gpu_spmv.cu:106-257) on the same matrix.
+N = 1: BASELINE.json config 2 -- fp32, 3 125 000^2, 32 nnz/row = 100 000 000 nnz, uniform random sorted columns --
+       through the stateless drop-in call mspmv_csrmv_f32.
+N > 1: BASELINE.json config 5 -- fp64 R-MAT scale 26, 2 000 000 000 edges, ONE matrix cut by merge-path diagonals into N swaths
+       (mspmv_mg_partition), one rank per GPU, ONE RCCL all-gather of the N boundary-row carries per step below the C ABI.
+       Strong scaling; rank 0 then runs the whole matrix alone (`single_gpu_same_workload`; --no-single-gpu-leg skips it).
+       `--preflight`: communicator, one all-gather, one step, exit (< 10 s; a failure names the rank).
 
-N > 1 (default workload "c5"): BASELINE.json config 5 -- fp64 R-MAT scale 26 (67 108 864^2), 2 000 000 000
-edges, ONE matrix independent of N, merge-partitioned by diagonal into N swaths (mspmv_mg_partition);
-every rank builds its swath in its own HBM from the counter-based generator and drives it through the C
-multi-GPU operator (mspmv_mg_plan_*: the part's CsrMV launches + ONE RCCL all-gather of the N
-boundary-row carries + the owner's add, all below the C ABI).  Strong scaling: `value` = 2 * nnz_total /
-max-over-ranks time; `per_rank` carries the spread of the ranks' tile-kernel and step times, `hot_column_plan` the same job
-with every rank's columns renumbered by reference count (mspmv_mg_plan_hot_columns: opt-in, set-up apart).  Rank 0 then also
-runs the WHOLE matrix alone on its GPU in the same job (`single_gpu_same_workload`, 5 steps; --no-single-gpu-leg skips it), so
-the line is self-contained for an efficiency figure.
-"c2" can also be run sharded (--workload c2 --gpus N: weak scaling, N x 3 125 000 rows over the same
-3 125 000 columns); "dense32" is C2's pure-streaming variant (--dense=32 --size=100000000).
-
-value           = 2 * nnz_total / t  (GFLOP/s, whole job; reference formula gpu_spmv.cu:451-465)
-roofline        = algorithmic (compulsory) bytes of one tile_kernel launch / its average duration from
-                  hipEvents recorded on the launch stream (mspmv_profile_begin/_end).  `bound` / `resident` say what that rate is
-                  read against: "hbm" -- the 8 TB/s HBM3E spec peak -- when the call's arrays are beyond the 256 MB Infinity Cache;
-                  "infinity_cache" when they fit it (they then stay there between SpMVs): `peak` is then the rate of a bare
-                  16-byte-per-lane read stream over a buffer of the same size MEASURED IN THIS RUN (mspmv_probe_read_stream),
-                  `frac_of_hbm_spec_peak` kept beside it.  `traffic` = L2 <-> fabric bytes of the tile kernel from two live
-                  rocprofv3 --pmc child runs (Infinity-Cache hits included: fabric traffic, not HBM traffic, for a resident record)
-sampled_check   = an untimed correctness witness of the very record: 2^16 seeded rows + the first, last and longest recomputed in fp64
-                  with torch gathers against the stated bound (no oracle import; parity proper is tests/ -m gpu); < 1 passes
-configs         = (N = 1, default workload) one sub-record per remaining single-GPU configuration of BASELINE.json, each
-                  timed the same way on its own synthetic matrix -- config 1's --dense=5 matrix in fp64 with the product's
-                  cpu_spmv kernel on the host cores beside it (`cpu`), C2 in fp64 (the reference's default precision,
-                  gpu_spmv.cu:727-735), a circuit5M-SHAPED stand-in (the matrix of the reference's one published number),
-                  config 3's two matrices as size-matched R-MAT stand-ins (the SuiteSparse files cannot be fetched
-                  offline), config 4, config 5 on ONE GPU, and the reference's own --dense=32 streaming input -- with
-                  ms_per_step, GFLOP/s, the reference's effective-bandwidth share of peak (gpu_spmv.cu:452-465), the tile
-                  kernel's roofline fraction, live counter traffic (config 5 too: its CSR image is parked in /dev/shm for the two
-                  child runs), the sampled check, and rocSPARSE csrmv on the same arrays (`vendor`).  --mtx-dir DIR (default
-                  $MSPMV_C3_DIR): webbase-1M.mtx / com-Orkut.mtx / circuit5M.mtx found there replace the generated stand-ins,
-                  through the product's Matrix Market ingest; `data` says whether a record ran on the SuiteSparse file, on a
-                  stand-in file (tools/make_standin_mtx.py) or on a generated stand-in.
-cpu_baseline    = the PRODUCT's OpenMP merge-path kernel (merge_spmv_amd/host/merge_csrmv.hpp, what cpu_spmv
-                  runs; pinned bit for bit against the oracle by tests/test_cpu_product_parity.py) on the
-                  same matrix on this box's host cores: private first-touched arrays, threads = the cgroup
-                  CPU quota, bound to distinct cores of socket 0 when the cpuset allows; bounded sample.
-"""
+The LAST stdout line is ONE JSON object under 4 KB, numbers only (what the reference prints is one perf line, gpu_spmv.cu:459-471):
+  value        2 * nnz_total / t  (GFLOP/s, whole job; gpu_spmv.cu:451-465)
+  roofline     algorithmic bytes of one tile-kernel launch (every array once) / its average duration from hipEvents on
+               the launch stream; `bound` hbm (8 TB/s spec peak) or ic (arrays fit the 256 MB Infinity Cache: `peak` = a bare read
+               stream over a buffer of that size measured in this run, `frac_hbm` beside it); `traffic` = L2<->fabric bytes per launch
+               (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction; Infinity-Cache hits included) -- replayed from the
+               committed rocprofv3 --pmc passes of the same workload (`traffic_src` names the file), measured live with --full
+  cpu_baseline the product's OpenMP merge-path kernel (host/merge_csrmv.hpp, what cpu_spmv runs; bit for bit the oracle's,
+               tests/test_cpu_product_parity.py) on the same matrix on this box's host cores: bounded sample
+  configs      one compact object per remaining single-GPU configuration of BASELINE.json (+ the circuit5M-shaped matrix of the
+               reference's one published number); `worst` = sampled_check's worst |y - g| / bound (< 1 passes)
+Everything longer -- notes, sources, per-run CPU variants, vendor column, plans -- goes to the side file named in `detail`
+(default gpurun_out/bench_detail.json) and, with --full, includes live counters, rocSPARSE, the prepared plans and config 5 at G = 1
+(tools/bench_full.py)."""
 import argparse
 import ctypes
 import json
@@ -65,19 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-INFINITY_CACHE_BYTES = 256 << 20      # the die-level L3 (same guide): a call whose arrays fit it is not bound by HBM once they are in there
-TRAFFIC_IS = ("L2 <-> fabric bytes of the tile kernel (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction): requests the L2s send to the "
-              "memory side -- Infinity-Cache hits INCLUDED, so for a record whose arrays live in that cache this is fabric traffic, not HBM traffic")
-
-WORKLOADS = {
-    # name: default dtype.  "c2" is the N = 1 headline (BASELINE config 2); "dense32" its reference-compatible
-    # pure-streaming variant (--dense=32 --size=100000000, gpu_spmv.cu:645-650); "c5" = BASELINE config 5.
-    "c2": "f32",
-    "dense32": "f32",
-    "c5": "f64",
-}
+HBM_PEAK_GBS = 8000.0                  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+INFINITY_CACHE_BYTES = 256 << 20       # the die-level L3 (same guide)
+LINE_LIMIT = 4096                      # the final stdout line stays under this many bytes (tests/test_bench_helpers.py)
+WORKLOADS = {"c2": "f32", "dense32": "f32", "c5": "f64"}
 C2_ROWS_PER_GPU, C2_NPR = 3_125_000, 32
+REFERENCE_PUBLISHED_PCT = 62.96        # circuit5M fp64 on a K40: 181.6 effective GB/s of 288.4 (README.md:116,137-138)
+REAL_FILES = {"c3_web": "webbase-1M.mtx", "c3_orkut": "com-Orkut.mtx", "circuit": "circuit5M.mtx"}      # SuiteSparse names (ufl_matrices.txt)
+STANDIN_MARK = "STAND-IN written by tools/make_standin_mtx.py"
 
 
 def algorithmic_bytes(rows, cols, nnz, vb):
@@ -94,13 +61,11 @@ _CACHE_RATE = {}
 
 
 def roofline_bound(M, b_alg, achieved_gbs):
-    """The fields of a `roofline` record that say WHAT the achieved rate is read against.  Arrays beyond the 256 MB Infinity Cache:
-    the HBM3E spec peak.  Arrays that fit it (they stay there from SpMV to SpMV): the HBM peak is not the bound -- `peak` is then the
-    rate of a bare 16-byte-per-lane read stream over a buffer of the same size, measured in this run on this box
-    (mspmv_probe_read_stream), `frac` is against THAT, and `frac_of_hbm_spec_peak` keeps the old figure beside it, labelled."""
+    """What the achieved rate is read against.  Arrays beyond the 256 MB Infinity Cache: the HBM3E spec peak.  Arrays that fit it
+    (they stay there from SpMV to SpMV): `peak` is the rate of a bare 16-byte-per-lane read stream over a buffer of the same size
+    measured in this run (mspmv_probe_read_stream); `frac_hbm` keeps the spec-peak figure beside it."""
     if b_alg > INFINITY_CACHE_BYTES:
-        return {"bound": "hbm", "resident": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                "peak_source": "HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (its measured float4-copy rate is 6.29 TB/s = 0.79 of it)"}
+        return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4)}
     key = int(b_alg) >> 20
     if key not in _CACHE_RATE:
         try:
@@ -109,19 +74,11 @@ def roofline_bound(M, b_alg, achieved_gbs):
             _CACHE_RATE[key] = None
             sys.stderr.write(f"cache stream probe failed: {e}\n")
     peak = _CACHE_RATE[key]
-    rec = {"bound": "infinity_cache", "resident": "infinity_cache", "unit": "GB/s", "frac_of_hbm_spec_peak": round(achieved_gbs / HBM_PEAK_GBS, 4),
-           "note": f"the call's arrays ({b_alg / 2**20:.0f} MB) fit the 256 MB Infinity Cache and stay there between SpMVs: a cache-bandwidth figure, not an HBM one"}
-    if peak:
-        rec.update({"peak": round(peak, 1), "frac": round(achieved_gbs / peak, 4),
-                    "peak_source": f"measured in this run: bare 16-byte-per-lane read stream (mspmv_probe_read_stream) over a {b_alg / 2**20:.0f} MB buffer resident in the Infinity Cache"})
-    else:
-        rec.update({"peak": None, "frac": None, "peak_source": "cache stream probe unavailable"})
-    return rec
+    return {"bound": "ic", "peak": round(peak, 1) if peak else None, "unit": "GB/s", "frac": round(achieved_gbs / peak, 4) if peak else None,
+            "frac_hbm": round(achieved_gbs / HBM_PEAK_GBS, 4)}
 
 
 def _cgroup_cpu_stat():
-    """(nr_throttled, throttled_usec) of this container's CPU controller: a quota-sized OpenMP team that is descheduled as
-    a whole shows up here, which is what made the pinned figure swing between runs (VERDICT r02, weak #6)."""
     out = {}
     try:
         for line in open("/sys/fs/cgroup/cpu.stat"):
@@ -132,11 +89,10 @@ def _cgroup_cpu_stat():
     return out.get("nr_throttled"), out.get("throttled_usec")
 
 
-def cpu_baseline(A, x, label, budget_s=12.0, max_iters=40):
-    """Time the product's OpenMP merge-path kernel on the host cores (rank 0, N = 1 only): three team shapes --
-    quota-sized and bound to socket 0, quota-sized and unbound, two threads under the quota and unbound (so that the
-    process's other threads do not push the cgroup over its quota) -- each with the cgroup's throttling counters read
-    around the timed loop.  `value` is the fastest; all three are reported."""
+def cpu_baseline(A, x, label, budget_s=12.0, max_iters=200):
+    """The product's OpenMP merge-path kernel on the host cores (rank 0, N = 1 only): quota-sized team bound to socket 0, the same
+    unbound, and two threads under the quota unbound -- each with the cgroup's throttling counters read around the timed loop.
+    `value` is the fastest; all three go to the detail file."""
     import numpy as np
     H = ctypes.CDLL(os.path.join(ROOT, "merge_spmv_amd", "libmspmv_host.so"))
     vp, i = ctypes.c_void_p, ctypes.c_int
@@ -164,33 +120,21 @@ def cpu_baseline(A, x, label, budget_s=12.0, max_iters=40):
         if st != 0:
             runs.append({"variant": name, "error": f"mspmv_host_merge_csrmv_bench returned {st}"})
             continue
-        dt = avg.value * 1e-3
         runs.append({"variant": name, "threads": threads, "bound_to_socket0_cores": bool(pinned.value), "sockets_visible": packages.value,
-                     "ms": round(avg.value, 3), "iters": iters.value, "value": round(2.0 * nnz / dt / 1e9, 3),
-                     "cgroup_throttled_periods_during_run": None if thr0[0] is None else thr1[0] - thr0[0],
-                     "cgroup_throttled_ms_during_run": None if thr0[1] is None else round((thr1[1] - thr0[1]) / 1e3, 1)})
+                     "ms": round(avg.value, 3), "iters": iters.value, "value": round(2.0 * nnz / (avg.value * 1e-3) / 1e9, 3),
+                     "cgroup_throttled_periods": None if thr0[0] is None else thr1[0] - thr0[0]})
     good = [r for r in runs if "value" in r]
     if not good:
-        return {"error": "; ".join(r.get("error", "?") for r in runs)}
+        return {"error": "; ".join(r.get("error", "?") for r in runs)[:200]}
     best = max(good, key=lambda r: r["value"])
-    quota = "unlimited"
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        quota = "unlimited" if q == "max" else f"{int(q) / int(per):g} CPUs (cpu.max {q} {per})"
+        quota = "unlimited" if q == "max" else f"{int(q) / int(per):g} CPUs"
     except (OSError, ValueError):
-        pass
-    try:
-        cpuset = open("/sys/fs/cgroup/cpuset.cpus.effective").read().strip()
-    except OSError:
-        cpuset = "?"
-    return {"value": best["value"], "unit": "GFLOP/s", "cores": best["threads"], "kind": "port",
-            "value_is": best["variant"] + " (the fastest of `runs`)",
-            "kernel": "merge_spmv_amd/host/merge_csrmv.hpp (product OpenMP merge-path CsrMV; -O3 -march=x86-64-v3 -ffp-contract=off)",
-            "sample": f"{label} ({nnz} nnz), {best['iters']} SpMVs after 4 warm-ups, {best['ms']:.2f} ms each",
-            "runs": runs,
-            "hardware_threads": int(H.mspmv_host_hardware_threads()), "cpu_quota": quota, "cpuset": cpuset,
-            "first_touch": "every thread first-touches the swath of the arrays it streams",
-            "effective_GBs": round(effective_bytes(A.rows, nnz, val.dtype.itemsize) / (best["ms"] * 1e-3) / 1e9, 2)}
+        quota = "?"
+    return {"value": best["value"], "unit": "GFLOP/s", "cores": best["threads"], "kind": "port", "ms": best["ms"],
+            "sample": f"{label}: {best['iters']} SpMVs after 4 warm-ups", "kernel": "host/merge_csrmv.hpp (OpenMP merge-path)",
+            "variant": best["variant"], "runs": runs, "hardware_threads": int(H.mspmv_host_hardware_threads()), "cpu_quota": quota}
 
 
 def time_stateless(M, torch, A, x, steps, warmup):
@@ -213,117 +157,18 @@ def time_stateless(M, torch, A, x, steps, warmup):
 
 
 def replayed_traffic(workload, dtype_name):
-    """L2 <-> fabric bytes (Infinity-Cache hits included) per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same workload
-    (profiles/*/pmc_latest.json, written by tools/gpu_profile.sh): replayed constants, labelled as such.  The newest
-    round's file wins."""
+    """L2 <-> fabric bytes per launch of the tile kernel from the committed rocprofv3 --pmc passes of the same workload
+    (profiles/*/pmc_latest.json, written by tools/gpu_profile.sh): (bytes, repo-relative path).  The newest round's file wins."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_latest.json")) + [os.path.join(ROOT, "profiles", "pmc_latest.json")]):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_latest.json"))):
         try:
             pmc = json.load(open(path))
-        except Exception:
+        except Exception:  # noqa: BLE001
             continue
         if pmc.get("workload") == workload and pmc.get("dtype") == dtype_name and pmc.get("tile_kernel_hbm_bytes_per_launch"):
-            best = (pmc, os.path.relpath(path, ROOT))
-    if best is None:
-        return None, None
-    pmc, rel = best
-    return pmc["tile_kernel_hbm_bytes_per_launch"], (f"{TRAFFIC_IS}; {rel} (replayed, NOT measured in this run): FETCH_SIZE / WRITE_SIZE of the tile kernel "
-                                                      "from separate rocprofv3 --pmc passes over this workload, " + str(pmc.get("collected", "see profiles/README.md")))
-
-
-_LIVE_PMC = {"ok": True, "why": ""}       # one failure (no rocprofv3, a crash, a time-out) turns the live passes off for the rest of the run
-
-
-def live_traffic(label, steps=24, timeout_s=60, extra_args=()):
-    if not _LIVE_PMC["ok"]:
-        return None, "live counters switched off after an earlier failure in this run: " + _LIVE_PMC["why"]
-    tr, why = _live_traffic(label, steps, timeout_s, extra_args)
-    if tr is None:
-        _LIVE_PMC["ok"] = False; _LIVE_PMC["why"] = why
-    return tr, why
-
-
-def _live_traffic(label, steps, timeout_s, extra_args=()):
-    """L2 <-> fabric bytes (Infinity-Cache hits included) per launch of the tile kernel, MEASURED IN THIS RUN on this box: two separate `rocprofv3 --kernel-trace --pmc`
-    passes (FETCH_SIZE, then WRITE_SIZE: never combined with other trace domains) over `tools/run_config.py <label>`, which runs
-    the same call on the same synthetic matrix in a child process; corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
-    (KB -> bytes, and gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes: doubled).  None when rocprofv3 is missing, fails
-    or takes longer than `timeout_s` per pass -- the caller then falls back to the committed passes (replayed_traffic)."""
-    import csv
-    import glob
-    import shutil
-    import signal
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None:
-        return None, "rocprofv3 not found"
-    work = tempfile.mkdtemp(prefix="mspmv_pmc_", dir="/tmp")
-    env = dict(os.environ); env["TMPDIR"] = "/tmp"
-    got = {}
-    try:
-        for pmc in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, pmc)
-            # (counters only for the tile kernel -- --kernel-include-regex: the generation of the matrix in the child runs unprofiled,
-            #  which is what lets config 5's 36 GB through --; the child in a session of its own, so that a time-out takes the
-            #  grandchild python along instead of leaving it on the GPU beside the configurations timed next)
-            cmd = [exe, "--kernel-trace", "--pmc", pmc, "--kernel-include-regex", "tile_kernel", "--output-format", "csv", "-d", out, "-o", "b", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "run_config.py"), label, "--steps", str(steps), *extra_args]
-            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-            try:
-                proc.communicate(timeout=timeout_s)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(proc.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                proc.communicate()
-                return None, f"rocprofv3 --pmc {pmc} took longer than {timeout_s} s (its process group was killed)"
-            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if proc.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {pmc} failed (rc {proc.returncode})"
-            n, total = 0, 0.0
-            for row in csv.DictReader(open(files[0])):
-                if "tile_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == pmc:
-                    n += 1; total += float(row.get("Counter_Value", 0) or 0)
-            if n == 0:
-                return None, f"no tile-kernel dispatch in the {pmc} pass"
-            got[pmc] = (total / n, n)
-    except Exception as e:  # noqa: BLE001 - measurement garnish: never at the price of the line
-        return None, f"{type(e).__name__}: {e}"[:200]
-    finally:
-        shutil.rmtree(work, ignore_errors=True)
-    fetch_kb, nf = got["FETCH_SIZE"]; write_kb, nw = got["WRITE_SIZE"]
-    return int((2.0 * fetch_kb + write_kb) * 1024), (f"{TRAFFIC_IS}; measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/run_config.py {label}, "
-                                                    f"average of {nf} / {nw} dispatches of the tile kernel; FETCH_SIZE {fetch_kb:.0f} KB x 1024 x 2 (gfx950 correction) + WRITE_SIZE {write_kb:.0f} KB x 1024")
-
-
-REFERENCE_PUBLISHED_PCT = 62.96      # circuit5M fp64 on a K40: 181.6 effective GB/s of 288.4 (README.md:116,137-138)
-
-
-def effective_record(rows, nnz, vb, ms):
-    """the reference's own headline figure for one method (gpu_spmv.cu:452-465): bytes of its model / time, as a share of the
-    device's peak memory bandwidth"""
-    gbs = effective_bytes(rows, nnz, vb) / (ms * 1e-3) / 1e9
-    return {"effective_GBs": round(gbs, 2), "effective_pct_of_peak": round(100.0 * gbs / HBM_PEAK_GBS, 2)}
-
-
-def vendor_record(torch, A, x, y_ours, iters):
-    """rocSPARSE csrmv on the same device arrays -- the column the reference always prints beside its own (cuSPARSE there,
-    gpu_spmv.cu:262-364,565-578): analysis time apart, average SpMV time, and ours / theirs."""
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import rocsparse_ref
-        ana, avg, yr = rocsparse_ref.time_csrmv(A, x, iters=iters)
-        rec = {"library": "rocSPARSE csrmv (rocsparse_[sd]csrmv after rocsparse_[sd]csrmv_analysis), via tools/rocsparse_ref.py",
-               "analysis_ms": round(ana, 3), "ms_per_step": round(avg, 5), "steps": iters, "value": round(2.0 * A.nnz / (avg * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
-        if y_ours is not None:
-            rec["max_abs_diff_vs_ours"] = float((yr.double() - y_ours.double()).abs().max().item())
-        del yr
-        return rec
-    except Exception as e:  # noqa: BLE001 - the comparison column must never cost the headline
-        return {"error": f"{type(e).__name__}: {e}"[:200]}
+            best = (int(pmc["tile_kernel_hbm_bytes_per_launch"]), os.path.relpath(path, ROOT))
+    return best if best else (None, None)
 
 
 def config_specs(torch, G, dev, steps):
@@ -331,33 +176,23 @@ def config_specs(torch, G, dev, steps):
     tools/run_config.py, which profiles one of them under rocprofv3."""
     f32, f64 = torch.float32, torch.float64
     return [
-        ("C1 dense5 fp64", "dense5", "BASELINE config 1's matrix: the reference's --dense=5 (cpu_spmv.cpp:581-587: (1 << 24) / 5 rows x 5 columns, every entry 1.0), fp64 -- "
-         "the GPU beside the product's OpenMP merge-path kernel on this box's host cores (`cpu`)", f64, max(steps, 100),
+        ("C1 dense5", "dense5", "BASELINE config 1's matrix: --dense=5 (cpu_spmv.cpp:581-587), fp64, on the GPU; `cpu` = the product's cpu_spmv kernel", f64, max(steps, 100),
          lambda: (G.dense_csr((1 << 24) // 5, 5, dtype=f64, device=dev, ones=True), G.SEED_C2 + 2)),
-        ("C2 fp64", "c2", "BASELINE config 2's matrix in the reference's default precision (gpu_spmv.cu:727-735)", f64, steps,
+        ("C2 f64", "c2", "BASELINE config 2's matrix in the reference's default precision (gpu_spmv.cu:727-735)", f64, steps,
          lambda: (G.uniform_csr(C2_ROWS_PER_GPU, C2_ROWS_PER_GPU, C2_NPR, dtype=f64, device=dev), G.SEED_C2 + 2)),
-        ("circuit5M-shaped stand-in", "circuit", f"the matrix of the reference's one published number (README.md:116,137-138: circuit5M, {G.CIRCUIT5M_ROWS}^2, "
-         f"{G.CIRCUIT5M_NNZ} nonzeros, fp64, 62.96 % of the K40's peak in its effective-bandwidth metric); STAND-IN of exactly those sizes with a circuit "
-         "matrix's row-length spread (generators.circuit_csr): the SuiteSparse file cannot be fetched offline", f64, steps,
+        ("circuit5M-shaped", "circuit", f"stand-in of circuit5M's sizes ({G.CIRCUIT5M_ROWS}^2, {G.CIRCUIT5M_NNZ} nnz; README.md:116,137-138), fp64", f64, steps,
          lambda: (G.circuit_csr(dtype=f64, device=dev), G.SEED_CIRCUIT + 9)),
-        ("C3 webbase-1M-sized stand-in", "c3_web", f"BASELINE config 3: R-MAT scale {G.C3_WEBBASE_SCALE}, {G.C3_WEBBASE_EDGES} edges (webbase-1M's count, "
-         "ufl_matrices.txt:2379), fp64; STAND-IN: the SuiteSparse file cannot be fetched offline", f64, max(steps, 200),
+        ("C3 webbase-sized", "c3_web", f"BASELINE config 3 stand-in: R-MAT scale {G.C3_WEBBASE_SCALE}, {G.C3_WEBBASE_EDGES} edges (ufl_matrices.txt:2379), fp64", f64, max(steps, 200),
          lambda: (G.rmat_csr(G.C3_WEBBASE_SCALE, G.C3_WEBBASE_EDGES, dtype=f64, device=dev, seed=G.SEED_C3), G.SEED_C3 + 2)),
-        ("C3 com-Orkut-sized stand-in", "c3_orkut", f"BASELINE config 3: R-MAT scale {G.C3_ORKUT_SCALE}, {G.C3_ORKUT_EDGES} stored entries mirrored as a symmetric "
-         "matrix (com-Orkut's count), fp64; STAND-IN: the SuiteSparse file cannot be fetched offline", f64, steps,
+        ("C3 Orkut-sized", "c3_orkut", f"BASELINE config 3 stand-in: R-MAT scale {G.C3_ORKUT_SCALE}, {G.C3_ORKUT_EDGES} entries mirrored, fp64", f64, steps,
          lambda: (G.rmat_symmetric_csr(G.C3_ORKUT_SCALE, G.C3_ORKUT_EDGES, dtype=f64, device=dev, seed=G.SEED_C3), G.SEED_C3 + 2)),
-        ("C4 fp32", "c4", "BASELINE config 4: 16 777 216 rows, one row of 67 108 864 nonzeros, one nonzero in every 4096-th other row, "
-         "the rest empty; uniform values", f32, steps,
+        ("C4", "c4", "BASELINE config 4: 16 777 216 rows, one row of 67 108 864 nonzeros, one nonzero in every 4096-th other row, rest empty, fp32", f32, steps,
          lambda: (G.degenerate_csr(dtype=f32, device=dev, ones=False), G.SEED_C4 + 2)),
-        ("dense32 fp32", "dense32", "the reference's own streaming input --dense=32 --size=100000000 (gpu_spmv.cu:645-650): 3 125 000 x 32", f32, steps,
+        ("dense32", "dense32", "the reference's streaming input --dense=32 --size=100000000 (gpu_spmv.cu:645-650), fp32", f32, steps,
          lambda: (G.dense_csr(C2_ROWS_PER_GPU, C2_NPR, dtype=f32, device=dev, ones=False), G.SEED_C2 + 2)),
-        ("C5 at G = 1", "c5", "BASELINE config 5 on ONE GPU: fp64 R-MAT scale 26, 2 000 000 000 edges (x = 512 MB, beyond the Infinity Cache)",
-         f64, 5, lambda: (G.rmat_csr(26, 2_000_000_000, dtype=f64, device=dev, seed=G.SEED_C5), G.SEED_C5 + 2)),
+        ("C5 G=1", "c5", "BASELINE config 5 on ONE GPU: fp64 R-MAT scale 26, 2 000 000 000 edges (--full only)", f64, 5,
+         lambda: (G.rmat_csr(26, 2_000_000_000, dtype=f64, device=dev, seed=G.SEED_C5), G.SEED_C5 + 2)),
     ]
-
-
-REAL_FILES = {"c3_web": "webbase-1M.mtx", "c3_orkut": "com-Orkut.mtx", "circuit": "circuit5M.mtx"}      # SuiteSparse names (ufl_matrices.txt)
-STANDIN_MARK = "STAND-IN written by tools/make_standin_mtx.py"
 
 
 def load_mtx(torch, G, path, tdt, dev):
@@ -373,7 +208,6 @@ def load_mtx(torch, G, path, tdt, dev):
     H.mspmv_host_matrix_shape.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 3
     H.mspmv_host_matrix_copy.argtypes = [ctypes.c_void_p] * 4
     H.mspmv_host_matrix_destroy.argtypes = [ctypes.c_void_p]
-    stand_in = False
     with open(path, "rb") as f:
         f.readline()
         stand_in = STANDIN_MARK.encode() in f.readline()
@@ -394,32 +228,48 @@ def load_mtx(torch, G, path, tdt, dev):
     return A, stand_in
 
 
-def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True, live_pmc=True, mtx_dir=None, c5_pmc=True):
-    """The `configs` array: every single-GPU configuration of BASELINE.json that the headline does not cover (and the
-    circuit5M-shaped matrix of the reference's published number), through the same stateless call.  Generation is on the GPU
-    and not timed; a configuration that would start after `budget_s` of this function's wall time is reported as skipped
-    rather than run.  Every record carries the reference's own metric (`effective_pct_of_peak`, gpu_spmv.cu:452-465), the
-    tile kernel's roofline fraction, replayed counter traffic where a committed rocprofv3 pass of that workload exists, and
-    the vendor library's time on the same arrays (`vendor`)."""
+def roofline_record(M, A, cols, prof, ms, ws, workload_label, dtype_name):
+    """The `roofline` object of one stateless record (full form; compact() keeps the numbers)."""
+    vb = A.values.element_size()
+    b_alg = algorithmic_bytes(A.rows, cols, A.nnz, vb)
+    tile_s = prof["tile_ms"] * 1e-3
+    achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
+    offered = M.band_passes(A.rows, cols, A.nnz, vb)
+    passes = 0
+    if offered > 1:
+        spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
+        passes = offered if spread >= 56 else 0
+    rec = {"kernel": "tile_kernel_vec<BAND>" if offered > 1 else "tile_kernel_snap", "achieved": round(achieved, 1), **roofline_bound(M, b_alg, achieved),
+           "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(prof["tile_ms"], 5), "search_ms": round(prof["search_ms"], 5),
+           "fixup_ms": round(prof["fixup_ms"], 5), "launches_timed": prof["calls"], "band_passes": passes}
+    tr, src = replayed_traffic(workload_label, dtype_name)
+    rec["traffic"] = tr
+    rec["traffic_over_algorithmic"] = round(tr / b_alg, 3) if tr else None
+    rec["traffic_src"] = ("replayed:" + src) if tr else None
+    return rec
+
+
+def config_records(M, torch, G, dev, steps, warmup, budget_s, mtx_dir=None, full=None):
+    """The `configs` array (full form): every single-GPU configuration of BASELINE.json that the headline does not cover, through
+    the same stateless call.  Generation is on the GPU and not timed; a configuration that would start after `budget_s` is
+    reported as skipped.  `full` (tools/bench_full.py, --full) adds live counters, the vendor column, the plans and config 5."""
     out = []
     t_start = time.perf_counter()
     for name, label, desc, tdt, k, make in config_specs(torch, G, dev, steps):
+        if label == "c5" and full is None:
+            continue
         if time.perf_counter() - t_start > budget_s:
-            out.append({"config": name, "skipped": f"the configs leg had used its {budget_s:.0f} s budget"})
+            out.append({"config": name, "skipped": f"configs budget of {budget_s:.0f} s used"})
             continue
         t0 = time.perf_counter()
         try:
-            # --mtx-dir / $MSPMV_C3_DIR: the SuiteSparse file itself when it is there (webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx) --
-            # or the stand-in tools/make_standin_mtx.py wrote under that name --, through the product's Matrix Market ingest
-            from_file = False
-            data_label = "synthetic (generated on the GPU)"
+            data_label = "synthetic"
             path = os.path.join(mtx_dir, REAL_FILES[label]) if (mtx_dir and label in REAL_FILES) else None
-            if path and os.path.exists(path):
+            from_file = bool(path and os.path.exists(path))
+            if from_file:
                 A, stand_in = load_mtx(torch, G, path, tdt, dev)
                 x_seed = G.SEED_C3 + 2
-                from_file = True
-                data_label = (f"stand-in read from {path} through the Matrix Market ingest" if stand_in
-                              else f"suitesparse: {path} (the real matrix), through the Matrix Market ingest")
+                data_label = ("stand-in file " if stand_in else "suitesparse ") + path
             else:
                 A, x_seed = make()
             x = G.uniform_pm1(x_seed, A.cols, tdt, dev)
@@ -427,104 +277,141 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s=150.0, vendor=True,
             gen_s = time.perf_counter() - t0
             ms, prof, ws, y = time_stateless(M, torch, A, x, k, min(warmup, 3))
             vb = A.values.element_size()
-            b_alg = algorithmic_bytes(A.rows, A.cols, A.nnz, vb)
-            info = M.launch_info(A.rows, A.nnz, vb, num_cols=A.cols)          # (with the column count: the shape the stateless call runs)
-            offered = M.band_passes(A.rows, A.cols, A.nnz, vb)
-            # the tile kernel's duration: its hipEvent average on the launch stream (one-launch calls: the kernel IS the step -- the
-            # wall clock per step of K back-to-back calls is reported beside it, not mixed into it)
-            one_launch = offered <= 1
-            tile_s = prof["tile_ms"] * 1e-3
-            achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
-            rec = {"config": name, "workload": desc, "data": data_label, "dtype": "f32" if vb == 4 else "f64", "rows": A.rows, "cols": A.cols, "nnz": A.nnz,
-                   "steps": k, "ms_per_step": round(ms, 5), "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
+            dn = "f32" if vb == 4 else "f64"
+            info = M.launch_info(A.rows, A.nnz, vb, num_cols=A.cols)
+            eff = effective_bytes(A.rows, A.nnz, vb) / (ms * 1e-3) / 1e9
+            rec = {"config": name, "label": label, "workload": desc, "data": data_label, "dtype": dn, "rows": A.rows, "cols": A.cols, "nnz": A.nnz,
+                   "steps": k, "ms_per_step": round(ms, 5), "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 1), "unit": "GFLOP/s",
                    "tile": f"{info['block_threads']}x{info['items_per_thread']}", "generation_s": round(gen_s, 2),
-                   "roofline": {"kernel": "tile_kernel_snap (one launch)" if one_launch else "tile_kernel_vec<.., BAND>",
-                                "achieved": round(achieved, 2), **roofline_bound(M, b_alg, achieved),
-                                "algorithmic_bytes_per_launch": b_alg,
-                                "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5), "fixup": round(prof["fixup_ms"], 5)},
-                                "duration_used_ms": round(tile_s * 1e3, 5), "duration_source": "hipEvent average of the tile kernel on the launch stream",
-                                "wall_ms_per_step": round(ms, 5),
-                                "events": f"hipEvents on the launch stream, {prof['calls']} launches"}}
-            rec.update(effective_record(A.rows, A.nnz, vb, ms))
+                   "roofline": roofline_record(M, A, A.cols, prof, ms, ws, label, dn) if not from_file else
+                               dict(roofline_record(M, A, A.cols, prof, ms, ws, "-", dn)),
+                   "effective_GBs": round(eff, 1), "effective_pct_of_peak": round(100.0 * eff / HBM_PEAK_GBS, 2)}
             if label == "circuit":
                 rec["reference_published_pct_of_peak"] = REFERENCE_PUBLISHED_PCT
-                rec["reference_published_note"] = "circuit5M itself, fp64, merge-based CsrMV on a Tesla K40 (README.md:116,137-138); other hardware, the real matrix"
-            if offered > 1:
-                spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
-                rec["roofline"]["column_band_passes"] = {"offered_by_policy": offered, "windows_spread_of_64": spread, "passes_run": offered if spread >= 56 else 0}
-            rep_tr, src = (None, None) if from_file else replayed_traffic(label, "f32" if vb == 4 else "f64")
-            if not live_pmc or from_file:
-                live_tr, live_src = None, ("skipped (--no-live-pmc)" if not live_pmc else "skipped: the child run regenerates the stand-in, this record is a file")
-            elif label == "c5":
-                # (rocprofv3 --pmc dies -- SIGSEGV inside the tool -- while a child GENERATES the 2e9 edges, counters restricted or not;
-                #  so the matrix this record was timed on is parked as a raw image in RAM-backed /dev/shm and the two child passes load it)
-                live_tr, live_src = None, "skipped (--no-c5-pmc)"
-                if c5_pmc:
-                    img = f"/dev/shm/mspmv_bench_c5_{os.getpid()}.img"
-                    try:
-                        import shutil
-                        need = A.nnz * (vb + 4) + 4 * (A.rows + 1) + (1 << 30)
-                        if shutil.disk_usage("/dev/shm").free < need:
-                            live_src = "skipped: /dev/shm has no room for the CSR image"
-                        else:
-                            G.save_csr_image(A, x_seed, img)
-                            live_tr, live_src = live_traffic(label, steps=5, timeout_s=180, extra_args=("--load", img))
-                    except Exception as e:  # noqa: BLE001
-                        live_tr, live_src = None, f"{type(e).__name__}: {e}"[:200]
-                    finally:
-                        try:
-                            os.remove(img)
-                        except OSError:
-                            pass
-            else:
-                live_tr, live_src = live_traffic(label)
-            tr = live_tr if live_tr is not None else rep_tr
-            if tr is None:
-                rec["roofline"]["traffic"] = None
-                rec["roofline"]["traffic_source"] = f"not available: live counters: {live_src}; no committed passes for this label"
-            if tr is not None:
-                rec["roofline"]["traffic"] = tr
-                rec["roofline"]["traffic_source"] = live_src if live_tr is not None else src + f" [live counters: {live_src}]"
-                rec["roofline"]["traffic_is"] = "l2_fabric_bytes_infinity_cache_hits_included"
-                rec["roofline"]["traffic_over_algorithmic"] = round(tr / b_alg, 3)
-                rec["roofline"]["traffic_replayed_from_committed_passes"] = rep_tr
-            # a correctness witness of this very record (parity proper is tests/ -m gpu against the oracle): 2^16 seeded rows + the first,
-            # last and longest recomputed in fp64 with torch gathers, against the stated bound of SURVEY 8d (no oracle import)
-            rec["y_finite"] = bool(torch.isfinite(y).all().item())
             chk = M.sampled_check(A, x, y)
-            rec["sampled_worst_ratio"] = chk["worst_ratio"]
             rec["sampled_check"] = chk
-            rec["gathers_per_s_G"] = round(A.nnz / (ms * 1e-3) / 1e9, 2)
-            if label == "c5":
-                rec["roofline"]["note"] = ("x (512 MB) is beyond every cache: a gather that misses moves a whole 128-byte line whatever the load's cache "
-                                           "policy, and the chip delivers ~55 G random lines/s (tools/gather_granularity, profiles/r03_gather_granularity.txt); "
-                                           "`gathers_per_s_G` is to be read against that, `frac` counts each x entry once")
-            if label in ("c5", "c3_orkut"):
-                # scale-free graphs with an x beyond the caches: the opt-in hot-column plan on the same matrix
-                rec["hot_column_plan"] = M.hotcols_bench_record(A, x, y, steps=k, warmup=2, peak_gbs=HBM_PEAK_GBS)
-            if vendor:
-                v_iters = 3 if label == "c5" else 5 if label == "c4" else min(k, 30)
-                rec["vendor"] = vendor_record(torch, A, x, y, v_iters)
-                if "ms_per_step" in rec["vendor"]:
-                    rec["vendor"]["vendor_time_over_ours"] = round(rec["vendor"]["ms_per_step"] / ms, 3)
+            rec["y_finite"] = bool(torch.isfinite(y).all().item())
+            if full is not None:
+                full.extend_config(rec, M, torch, G, A, x, y, ws, label, x_seed, from_file, k)
             if label == "dense5":
-                # BASELINE config 1 proper: the product's cpu_spmv kernel on the same matrix, on this box's host cores
-                rec["cpu"] = cpu_baseline(A, x, "C1: --dense=5 fp64", budget_s=4.0, max_iters=60)
+                rec["cpu"] = cpu_baseline(A, x, "C1 --dense=5 fp64", budget_s=3.0, max_iters=60)
             out.append(rec)
             del A, x, ws, y
         except Exception as e:                   # e.g. out of memory on a smaller part: report, keep the headline
-            out.append({"config": name, "error": f"{type(e).__name__}: {e}"[:300]})
+            out.append({"config": name, "error": f"{type(e).__name__}: {e}"[:200]})
         torch.cuda.empty_cache()
     return out
 
 
+# ---- the final line ------------------------------------------------------------------------------------------------------------
+
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "traffic", "traffic_over_algorithmic", "traffic_src",
+              "algorithmic_bytes_per_launch", "kernel_ms", "band_passes")
+
+
+def _compact_config(c):
+    if "error" in c or "skipped" in c:
+        return {"config": c.get("config"), "error": str(c.get("error", c.get("skipped")))[:60]}
+    r = c.get("roofline", {})
+    out = {"config": c["config"], "dtype": c["dtype"], "ms_per_step": c["ms_per_step"], "value": c["value"], "bound": r.get("bound"),
+           "frac": r.get("frac"), "traffic_over_algorithmic": r.get("traffic_over_algorithmic"), "worst": c.get("sampled_check", {}).get("worst_ratio")}
+    if r.get("bound") == "ic":
+        out["frac_hbm"] = r.get("frac_hbm")
+    if "cpu" in c and "value" in c["cpu"]:
+        out["cpu_gflops"] = c["cpu"]["value"]; out["cpu_cores"] = c["cpu"]["cores"]
+    if "data" in c and c["data"] != "synthetic":
+        out["data"] = c["data"][:60]
+    return out
+
+
+def compact_line(detail, detail_path=None):
+    """The driver's line: the contract's keys, `roofline`, `cpu_baseline`, one compact object per config -- numbers, short tags,
+    nothing else; strictly JSON and under LINE_LIMIT bytes whatever `detail` holds (optional parts are dropped until it is)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: detail.get(k) for k in keep}
+    cfg = detail.get("config", {})
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:160], "tile": cfg.get("tile"), "partition": str(cfg.get("partition", ""))[:120]}
+    r = detail.get("roofline", {})
+    line["roofline"] = {k: r[k] for k in _ROOF_KEYS if k in r}
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = ({"error": str(cb["error"])[:80]} if "error" in cb else
+                                {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "ms", "sample", "kernel")})
+    for k in ("effective_pct_of_peak", "sampled_worst_ratio"):
+        if k in detail:
+            line[k] = detail[k]
+    optional = []
+    if "exchange" in detail:
+        ex = detail["exchange"]
+        line["exchange"] = {"backend": str(ex.get("backend", ex.get("exchange")))[:40], "carry_bytes_per_step": ex.get("carry_bytes_per_step"),
+                            "hot_parts": ex.get("hot_parts"), "fallbacks": len(ex.get("fallbacks", []))}
+    if "per_rank" in detail:
+        line["per_rank"] = {k: v for k, v in detail["per_rank"].items() if k != "note"}
+    if "single_gpu_same_workload" in detail:
+        s = detail["single_gpu_same_workload"]
+        line["single_gpu_same_workload"] = {k: s.get(k) for k in ("n_gpus", "steps", "ms_per_step", "value") if k in s}
+        optional.append("single_gpu_same_workload")
+    if "preflight" in detail:
+        line["preflight"] = detail["preflight"]
+    if "prepared_plan" in detail and "ms_per_step" in detail["prepared_plan"]:
+        p = detail["prepared_plan"]
+        line["prepared_plan"] = {"ms_per_step": p["ms_per_step"], "value": p["value"], "frac": p["roofline"]["frac"], "setup_ms": p["setup_ms"]}
+        optional.append("prepared_plan")
+    if "vendor" in detail and "ms_per_step" in detail["vendor"]:
+        line["vendor"] = {"library": "rocSPARSE csrmv", "ms_per_step": detail["vendor"]["ms_per_step"], "analysis_ms": detail["vendor"]["analysis_ms"]}
+        optional.append("vendor")
+    if detail.get("configs"):
+        line["configs"] = [_compact_config(c) for c in detail["configs"]]
+        optional.append("configs")
+    if detail_path:
+        line["detail"] = detail_path
+    s = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    while len(s) >= LINE_LIMIT and optional:
+        line.pop(optional.pop(0), None)
+        s = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    if len(s) >= LINE_LIMIT:
+        line["config"] = {"workload": line["config"]["workload"][:60]}
+        s = json.dumps(line, separators=(",", ":"), allow_nan=False)
+    return s
+
+
+def _finite(o):
+    """NaN / inf -> None, recursively (the line is strict JSON)."""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def emit(detail, detail_path):
+    """Side file first (best effort), then the line -- the LAST thing on stdout."""
+    detail = _finite(detail)
+    written = None
+    if detail_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(detail, f, indent=1)
+            written = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+        except OSError as e:
+            sys.stderr.write(f"bench detail file not written: {e}\n")
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stderr.flush()
+    print(compact_line(detail, written), flush=True)
+
+
+# ---- N > 1 ---------------------------------------------------------------------------------------------------------------------
+
 def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: re-run this very command line under
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one rank per
-    GPU, what the launcher form of the contract does) and hand its output through -- everything the ranks wrote to stdout
-    first, rank 0's JSON line LAST.  Returns the exit code.  With MSPMV_BENCH_ONE_DEVICE=1 (a one-GPU box: every rank on
-    cuda:0) the process group defaults to gloo -- RCCL admits one rank per device -- and the ranks still go through the C
-    operator (its exchange falls back rccl -> hipIpc together on every rank)."""
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run (one rank per GPU) and
+    hand its output through, rank 0's JSON line LAST.  MSPMV_BENCH_ONE_DEVICE=1 (a one-GPU box: every rank on cuda:0) defaults the
+    process group to gloo -- RCCL admits one rank per device -- and the ranks still go through the C operator (rccl -> hipIpc)."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -532,7 +419,7 @@ def self_launch(n):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")       # (torch.distributed.run would set 1 and say so on stderr)
+    env.setdefault("OMP_NUM_THREADS", "4")
     if env.get("MSPMV_BENCH_ONE_DEVICE") == "1":
         env.setdefault("MSPMV_BENCH_BACKEND", "gloo")
         env.setdefault("MSPMV_BENCH_FORCE_C_OPERATOR", "1")
@@ -545,15 +432,69 @@ def self_launch(n):
         if i != last_json:
             print(l)
     if last_json is not None:
-        rec = lines[last_json]
-        try:
-            d = json.loads(rec)
-            d["launched_by"] = f"bench.py itself (no WORLD_SIZE in the environment): torch.distributed.run --nproc-per-node {n}"
-            rec = json.dumps(d)
-        except ValueError:
-            pass
-        print(rec, flush=True)
+        print(lines[last_json], flush=True)
     return r.returncode if (r.returncode != 0 or last_json is not None) else 1
+
+
+def preflight(torch, dist, MG, rank, world, local_rank, dev, backend, one_device):
+    """--preflight: what a scaling run needs, checked in seconds and with the failing rank named -- process group, a torch
+    all-reduce, the C operator's communicator (RCCL id shipped through the group), one all-gather of carries inside one step of a
+    small sharded SpMV whose y is compared with the single-part result on every rank."""
+    import numpy as np
+    import merge_spmv_amd as M
+    t0 = time.perf_counter()
+    stage, why = "start", None
+    try:
+        stage = "torch all_reduce"
+        t = torch.ones(1, device=dev if backend == "nccl" else "cpu"); dist.all_reduce(t)
+        assert int(t.item()) == world, f"all_reduce gave {t.item()}, expected {world}"
+        stage = "shard"
+        scale, edges = 16, 1 << 20
+        shard = MG.rmat_shard(scale, edges, rank, world, torch.float64, device=dev, seed=0x5EED0005, use_dist=True)
+        x = torch.linspace(-1, 1, 1 << scale, dtype=torch.float64, device=dev)
+        stage = "communicator"
+        kind = MG.EXCHANGE_RCCL if (backend == "nccl" and not one_device) else MG.EXCHANGE_IPC
+        if kind == MG.EXCHANGE_RCCL:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            plan = MG.MgPlan(shard.row_split, shard.nz_split, 1 << scale, torch.float64, [rank], [local_rank], exchange=kind, id128=bytes(idt.cpu().numpy().tobytes()))
+        else:
+            plan = MG.MgPlan(shard.row_split, shard.nz_split, 1 << scale, torch.float64, [rank], [local_rank], exchange=kind)
+        plan.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
+        if kind == MG.EXCHANGE_IPC:
+            blobs = [None] * world
+            dist.all_gather_object(blobs, plan.ipc_export())
+            plan.ipc_import(blobs)
+        stage = "one step (SpMV + all-gather of carries)"
+        plan.x(0).copy_(x)
+        plan.csrmv(); plan.synchronize(); torch.cuda.synchronize()
+        stage = "result check"
+        yo = plan.y(0).clone()
+        # the same rows by the single-GPU call on this rank's swath + the carries it is owed are what plan.y holds; check against a
+        # gather-based fp64 recomputation of the owned rows
+        off = shard.row_offsets.to(torch.int64); n_owned = yo.numel()
+        seg = torch.repeat_interleave(torch.arange(off.numel() - 1, device=dev), off[1:] - off[:-1])
+        p = shard.values * x[shard.column_indices.to(torch.int64)]
+        g = torch.zeros(off.numel() - 1, dtype=torch.float64, device=dev).index_add_(0, seg, p)
+        # interior rows (not the first: a row cut by the left boundary receives carries) must match to rounding
+        if n_owned > 2:
+            err = float((yo[1:n_owned - 1] - g[1:n_owned - 1]).abs().max().item())
+            assert err < 1e-9, f"owned rows differ from the recomputation by {err}"
+        plan.close()
+    except Exception as e:  # noqa: BLE001
+        why = f"rank {rank} failed at '{stage}': {type(e).__name__}: {e}"[:300]
+        sys.stderr.write(why + "\n")
+    flags = [None] * world
+    try:
+        dist.all_gather_object(flags, why)
+    except Exception as e:  # noqa: BLE001
+        flags = [why or f"rank {rank}: all_gather_object failed: {e}"]
+    bad = [f for f in flags if f]
+    np.seterr(all="ignore")
+    return {"ok": not bad, "seconds": round(time.perf_counter() - t0, 2), "ranks": world, "backend": backend,
+            "exchange": "rccl" if (backend == "nccl" and not one_device) else "ipc", "failed": bad[:4]}
 
 
 def main():
@@ -561,34 +502,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2 on one GPU, c5 (one R-MAT matrix cut N ways) on N > 1")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 on one GPU, c5 (one R-MAT matrix cut N ways) on N > 1")
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--c5-scale", type=int, default=26)
     ap.add_argument("--c5-edges", type=int, default=2_000_000_000)
+    ap.add_argument("--full", action="store_true", help="N = 1: add live rocprofv3 --pmc traffic, the rocSPARSE column, the prepared plans and config 5 at G = 1 (minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-plan", action="store_true", help="skip the prepared_plan sub-record (N = 1, c2)")
-    ap.add_argument("--no-single-gpu-leg", action="store_true",
-                    help="N > 1, c5: skip rank 0's run of the WHOLE matrix alone afterwards (about 15 s during which the other ranks idle)")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"],
-                    help="N > 1: how the C operator exchanges the boundary-row carries -- one RCCL all-gather per step (default), or the hipIpc "
-                         "peer backend (carries written straight into the owner's mailbox, step tags instead of a collective; never timed over links)")
-    ap.add_argument("--no-live-pmc", action="store_true", help="N = 1: do not measure the headline's counter traffic with two rocprofv3 --pmc child runs (replay the committed passes instead)")
-    ap.add_argument("--no-vendor", action="store_true", help="N = 1: skip the rocSPARSE comparison column (`vendor` sub-records)")
-    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records (the other single-GPU configurations)")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the `configs` sub-records")
+    ap.add_argument("--configs-budget", type=float, default=60.0, help="seconds the `configs` leg may take before it stops starting new ones")
     ap.add_argument("--mtx-dir", default=os.environ.get("MSPMV_C3_DIR"),
-                    help="N = 1: a directory that may hold webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx (the SuiteSparse files, or the stand-ins "
-                         "tools/make_standin_mtx.py writes under those names): a file that is there replaces the generated stand-in of its record, read "
-                         "through the product's Matrix Market ingest, and the record's `data` says which it was (default: $MSPMV_C3_DIR)")
-    ap.add_argument("--no-c5-pmc", action="store_true", help="N = 1: do not collect config 5's counter traffic (its CSR image parked in /dev/shm, two child runs that load it: ~40 s)")
-    ap.add_argument("--configs-budget", type=float, default=240.0, help="seconds the `configs` leg may take before it stops starting new ones")
+                    help="N = 1: a directory that may hold webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx (default: $MSPMV_C3_DIR); a file found replaces the generated stand-in")
+    ap.add_argument("--detail", default=os.environ.get("MSPMV_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
+                    help="side file for everything that is not in the line ('' = none)")
+    ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1, c5: skip rank 0's run of the WHOLE matrix alone afterwards")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"], help="N > 1: RCCL all-gather per step (default) or the hipIpc peer backend")
+    ap.add_argument("--preflight", action="store_true", help="N > 1: communicator init, one all-gather, one step; exits in seconds naming a failing rank")
     ap.add_argument("--dist-timeout", type=int, default=900, help="N > 1: seconds a collective may block before the job aborts")
-    ap.add_argument("--tune", default=None, help="development: BLOCKxIPT[:flags] passed to mspmv_set_tuning")
-    ap.add_argument("--band-passes", type=int, default=0,
-                    help="A/B: mspmv_set_band_passes (0 automatic = the product default, -1 never, >= 2 always that many)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: start the N ranks ourselves (below) -- the same job the launcher form runs
         raise SystemExit(self_launch(args.gpus))
 
     import torch
@@ -603,10 +534,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} under a launcher that started {world} ranks (WORLD_SIZE={world}): the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP merge-path kernels have no CPU fallback)")
-    # MSPMV_BENCH_ONE_DEVICE=1 + MSPMV_BENCH_BACKEND=gloo: exercise the multi-rank path on a
-    # single-GPU box (all ranks on cuda:0, carries exchanged through gloo by the Python twin of the C
-    # operator, because RCCL admits one rank per device) -- a functional check of the sharding /
-    # exchange / reporting code, not a measurement
+    # MSPMV_BENCH_ONE_DEVICE=1: the multi-rank path on a single-GPU box (all ranks on cuda:0): a functional check, not a measurement
     one_device = os.environ.get("MSPMV_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
@@ -615,30 +543,35 @@ def main():
     M.load_library()
     dist = None
     backend = os.environ.get("MSPMV_BENCH_BACKEND", "nccl")
-    # MSPMV_BENCH_FORCE_MG=1 with ONE rank (torch.distributed.run --nproc-per-node 1): take the N > 1 code path anyway --
-    # process group, shipped RCCL id, the C operator's multi-process form with its all-gather in the timed loop, the
-    # single-GPU leg -- so that everything but "more than one rank" is exercised on a one-GPU box
+    # MSPMV_BENCH_FORCE_MG=1 with ONE rank: take the N > 1 code path anyway (process group, shipped RCCL id, the C operator's
+    # multi-process form with its all-gather in the timed loop)
     mg = world > 1 or os.environ.get("MSPMV_BENCH_FORCE_MG") == "1"
     if mg:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import datetime
         tmo = datetime.timedelta(seconds=args.dist_timeout)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)          # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend, timeout=tmo)
+    detail_path = args.detail or None
+
+    if args.preflight:
+        if not mg:
+            raise SystemExit("--preflight is for --gpus N > 1")
+        res = preflight(torch, dist, MG, rank, world, local_rank, dev, backend, one_device)
+        if rank == 0:
+            emit({"metric": "preflight", "value": 1.0 if res["ok"] else 0.0, "unit": "ok", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": None,
+                  "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                  "config": {"workload": "preflight: R-MAT scale 16, one step", "tile": None, "partition": f"{world} ranks"}, "preflight": res}, None)
+        dist.barrier(); dist.destroy_process_group()
+        raise SystemExit(0 if res["ok"] else 3)
 
     workload = args.workload or ("c5" if mg else "c2")
     dtype_name = args.dtype or WORKLOADS[workload]
-    if args.tune:
-        shape, _, fl = args.tune.partition(":")
-        b, _, i = shape.partition("x")
-        M.set_tuning(4 if dtype_name == "f32" else 8, int(b or 0), int(i or 0), int(fl or "0", 0))
     tdt = torch.float32 if dtype_name == "f32" else torch.float64
     vb = 4 if dtype_name == "f32" else 8
-    if args.band_passes:
-        M.set_band_passes(vb, args.band_passes)
     if workload == "dense32" and mg:
         raise SystemExit("dense32 is a single-GPU workload")
 
@@ -651,8 +584,7 @@ def main():
         nnz_total = args.c5_edges
         x_seed = G.SEED_C5 + 2
         scaling = "strong"
-        desc = (f"C5 R-MAT scale {args.c5_scale}: {n} x {n}, {nnz_total} generated edges (duplicates kept), a,b,c,d = "
-                f".57,.19,.19,.05, seed 0x5EED0005, values/x uniform in [-1,1); one matrix independent of the GPU count")
+        desc = f"C5 R-MAT scale {args.c5_scale}: {n}^2, {nnz_total} edges (duplicates kept), a,b,c,d=.57,.19,.19,.05, seed 0x5EED0005; one matrix whatever N"
         if not mg:
             A = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
         else:
@@ -663,9 +595,8 @@ def main():
         nnz_total = rows * C2_NPR
         x_seed = G.SEED_C2 + 2
         scaling = "weak"
-        desc = ((f"C2 uniform CSR: {rows} x {cols}, {C2_NPR} nnz/row, {nnz_total} nnz ({C2_ROWS_PER_GPU * C2_NPR} nnz per GPU), "
-                 f"uniform random sorted columns, values/x in [-1,1)") if workload == "c2" else
-                f"dense {rows} x {C2_NPR} as CSR ({nnz_total} nnz): the streaming variant of C2 (--dense=32 --size=100000000)")
+        desc = (f"C2 uniform CSR: {rows} x {cols}, {C2_NPR} nnz/row, {nnz_total} nnz, uniform random sorted columns, values/x in [-1,1)" if workload == "c2" else
+                f"dense {rows} x {C2_NPR} as CSR ({nnz_total} nnz): C2's streaming variant (--dense=32 --size=100000000)")
         if not mg:
             A = (G.uniform_csr(rows, cols, C2_NPR, dtype=tdt, device=dev) if workload == "c2"
                  else G.dense_csr(rows, C2_NPR, dtype=tdt, device=dev, ones=False))
@@ -676,8 +607,8 @@ def main():
     # ---- the operator ------------------------------------------------------------------------------------------
     plan = None
     exchange = None
+    ws = y = None
     if not mg:
-        # the plain drop-in call: no shard wrapper, no collective
         local_rows, local_nnz = A.rows, A.nnz
         ws = M.CsrMVWorkspace(A.rows, A.nnz, tdt, device=dev)
         y = torch.empty(A.rows, dtype=tdt, device=dev)
@@ -689,8 +620,7 @@ def main():
             torch.cuda.synchronize()
     elif (backend == "nccl" and not one_device) or args.exchange == "ipc" or os.environ.get("MSPMV_BENCH_FORCE_C_OPERATOR") == "1":
         # the C multi-GPU operator, one part per process.  The exchange asked for is tried first; if any rank fails to set it up or
-        # to run two trial steps with it, every rank falls back together (rccl -> ipc -> the Python twin over torch.distributed) and
-        # the record says so: a scaling run on a node this code has never met should still produce its numbers.
+        # to run two trial steps with it, every rank falls back together (rccl -> ipc -> the Python twin over torch.distributed)
         local_rows, local_nnz = shard.local_rows, shard.local_nnz
 
         def all_ok(ok):
@@ -702,10 +632,8 @@ def main():
             p, why = None, None
             try:
                 if kind == "ipc":
-                    # hipIpc peer backend: no collective library in the step (works with all ranks on one device too)
                     p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_IPC)
                 else:
-                    # RCCL communicator over the ranks
                     idt = torch.zeros(128, dtype=torch.uint8, device=dev)
                     if rank == 0:
                         idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
@@ -715,7 +643,7 @@ def main():
                 p.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
                 blob = p.ipc_export() if kind == "ipc" else None
             except Exception as e:  # noqa: BLE001 - any failure means "fall back"
-                why = f"setup: {e}"
+                why = f"rank {rank} setup: {e}"
             if not all_ok(why is None):
                 return p, why or "another rank failed during setup"
             try:
@@ -729,7 +657,7 @@ def main():
                     p.csrmv()
                 p.synchronize(); torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001
-                why = f"trial steps: {e}"
+                why = f"rank {rank} trial steps: {e}"
             if not all_ok(why is None):
                 return p, why or "another rank failed in the trial steps"
             return p, None
@@ -741,6 +669,7 @@ def main():
             if why is None:
                 break
             fallbacks.append({"exchange": kind, "failed": why[:300]})
+            sys.stderr.write(f"[bench] exchange {kind} not usable: {why[:300]}\n")
             if plan is not None:
                 try:
                     plan.close()
@@ -749,8 +678,7 @@ def main():
             plan = None
         if plan is not None:
             exchange = plan.info()
-            if fallbacks:
-                exchange["fallbacks"] = fallbacks
+            exchange["fallbacks"] = fallbacks
 
             def op():
                 plan.csrmv()
@@ -805,9 +733,7 @@ def main():
     op_sync()
     prof = M.profile_end()
 
-    # ---- N > 1 through the C operator: what the step's exchange alone takes (events around it, per rank), and the same steps with the
-    # parts' hot-column plans switched OFF (they are automatic since round 5: the headline above ran with whatever the plan decided)
-    hot = None
+    # ---- N > 1 through the C operator: what the step's exchange alone takes (events around it, per rank)
     exchange_ms = None
     if plan is not None:
         ex = []
@@ -818,31 +744,6 @@ def main():
             except Exception:  # noqa: BLE001
                 break
         exchange_ms = sum(ex) / len(ex) if ex else None
-    if plan is not None and workload == "c5":
-        hot_parts = int(plan.info().get("hot_parts", 0))
-        torch.cuda.synchronize(); th0 = time.perf_counter()
-        plan.hot_columns(not hot_parts)            # the other setting: off when the plan chose them, on when it did not
-        op_sync(); switch_ms = (time.perf_counter() - th0) * 1e3
-        for _ in range(max(2, min(args.warmup, 5))):
-            op()
-        barrier()
-        th0 = time.perf_counter()
-        for _ in range(args.steps):
-            op()
-        barrier()
-        th = torch.tensor([time.perf_counter() - th0, switch_ms], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(th, op=dist.ReduceOp.MAX)
-        other_ms = float(th[0].item()) * 1e3 / args.steps
-        hot = {"api": "mspmv_mg_plan_hot_columns: AUTOMATIC by default (decided per part when its matrix is attached: x beyond the Infinity Cache and columns "
-                      "that come back, mspmv_csrmv_hotcols_skew); x permuted per step, inside the timed loop; y bit for bit the same either way",
-               "chosen_by_the_plan_on_rank0": bool(hot_parts), "headline_ran_with_hot_columns": bool(hot_parts),
-               "this_record_is": ("the same steps WITHOUT the hot-column plans (switched off for this leg)" if hot_parts
-                                  else "the same steps WITH the hot-column plans forced on (the plan had not chosen them)"),
-               "ms_per_step": round(other_ms, 5), "value": round(2.0 * nnz_total / (other_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
-               ("release_ms" if hot_parts else "setup_ms") + "_max_over_ranks": round(float(th[1].item()), 2)}
-        plan.hot_columns(-1)                       # back to the default for what follows
-        op_sync()
 
     # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
     single = None
@@ -867,141 +768,87 @@ def main():
                 M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
             torch.cuda.synchronize()
             sms = (time.perf_counter() - t1) * 1e3 / k
-            single = {"n_gpus": 1, "steps": k, "ms_per_step": round(sms, 5), "value": round(2.0 * nnz_total / (sms * 1e-3) / 1e9, 3),
-                      "unit": "GFLOP/s", "speedup_of_this_job": round(sms / ms_per_step, 3),
-                      "parallel_efficiency": round(sms / ms_per_step / world, 4)}
+            single = {"n_gpus": 1, "steps": k, "ms_per_step": round(sms, 5), "value": round(2.0 * nnz_total / (sms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
             if y0 is not None:
-                # rank 0's tiles are the single-GPU call's first tiles, so its rows must match bit for bit (its last row, completed by
-                # the next ranks' carries, to within re-association)
+                # (detail file) rank 0's tiles are the single-GPU call's first tiles, so its rows must match bit for bit when both run the
+                # same tile shape through the same path -- except inside rank 0's LAST tile, which ends where the part ends
                 ref = wy[:y0.numel()]
-                differ = int((ref != y0).sum().item())
-                part_info = M.launch_info(local_rows, local_nnz, vb)
-                whole_info = M.launch_info(W.rows, W.nnz, vb)
-                same = (part_info["items_per_thread"] == whole_info["items_per_thread"]
-                        and M.band_passes(W.rows, W.cols, W.nnz, vb) <= 1 and M.band_passes(local_rows, cols, local_nnz, vb) <= 1)
                 neq = (ref != y0).nonzero()
-                single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": differ,
-                                                      "first_differing_row": int(neq[0].item()) if differ else None,
-                                                      "tile_items": int(part_info["tile_items"]),
-                                                      "max_abs_diff": float((ref - y0).abs().max().item()) if y0.numel() else 0.0,
-                                                      "same_tiling": bool(same),
-                                                      "note": "bit for bit when rank 0's part and the whole matrix run the same tile shape through the same "
-                                                              "path (`same_tiling`: true at BASELINE's size), except inside rank 0's LAST tile, which ends where the part "
-                                                              "ends (another extent, possibly the other in-tile reduction): rows from `first_differing_row` on; "
-                                                              "otherwise the same sums in another association"}
+                part_info = M.launch_info(local_rows, local_nnz, vb)
+                same = (part_info["items_per_thread"] == M.launch_info(W.rows, W.nnz, vb)["items_per_thread"]
+                        and M.band_passes(W.rows, W.cols, W.nnz, vb) <= 1 and M.band_passes(local_rows, cols, local_nnz, vb) <= 1)
+                single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": int(neq.numel()),
+                                                      "first_differing_row": int(neq[0].item()) if neq.numel() else None,
+                                                      "tile_items": int(part_info["tile_items"]), "same_tiling": bool(same),
+                                                      "max_abs_diff": float((ref - y0).abs().max().item()) if y0.numel() else 0.0}
             del W, wws, wy
 
-    # anything native code left in C stdio buffers (RCCL prints a version banner at communicator creation) goes out on
-    # EVERY rank before rank 0 prints the result, so that the JSON line is the last line of the job's stdout
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
     sys.stdout.flush()
     per_rank = None
     if dist is not None:
-        # per-rank kernel times and what is left of a step after them (launch gaps + the carry exchange + the owner's add)
         mine = torch.tensor([prof["search_ms"], prof["tile_ms"], prof["fixup_ms"], elapsed_local * 1e3 / args.steps, float(local_nnz),
                              float("nan") if exchange_ms is None else exchange_ms], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rows_ = torch.stack(allr).cpu().numpy()
-        kern = rows_[:, 0] + rows_[:, 1] + rows_[:, 2]
+        nanmax = lambda a: None if np.isnan(a).all() else round(float(np.nanmax(a)), 5)
+        nanmin = lambda a: None if np.isnan(a).all() else round(float(np.nanmin(a)), 5)
         per_rank = {"tile_ms_max": round(float(rows_[:, 1].max()), 5), "tile_ms_min": round(float(rows_[:, 1].min()), 5),
                     "step_ms_max": round(float(rows_[:, 3].max()), 5), "step_ms_min": round(float(rows_[:, 3].min()), 5),
-                    "exchange_and_gaps_ms_max": round(float((rows_[:, 3] - kern).max()), 5),
-                    "exchange_and_gaps_ms_min": round(float((rows_[:, 3] - kern).min()), 5),
                     "nnz_per_rank_max": int(rows_[:, 4].max()), "nnz_per_rank_min": int(rows_[:, 4].min()),
-                    "exchange_ms_max": None if np.isnan(rows_[:, 5]).all() else round(float(np.nanmax(rows_[:, 5])), 5),
-                    "exchange_ms_min": None if np.isnan(rows_[:, 5]).all() else round(float(np.nanmin(rows_[:, 5])), 5),
-                    "note": "per rank: hipEvent averages of its kernels and its own wall time per step; exchange_and_gaps = step - kernels (inferred); "
-                            "exchange_ms = hipEvents on the rank's stream right after its SpMV and right after the all-gather + the owner's add "
-                            "(mspmv_mg_plan_exchange_ms, 5 separate steps): the exchange alone, the wait for slower ranks included"}
+                    "exchange_ms_max": nanmax(rows_[:, 5]), "exchange_ms_min": nanmin(rows_[:, 5]),
+                    "note": "per rank: hipEvent averages of its kernels, its own wall time per step; exchange_ms = events right after the SpMV and right after "
+                            "the all-gather + the owner's add (mspmv_mg_plan_exchange_ms, 5 separate steps), the wait for slower ranks included"}
         dist.barrier()
     if rank == 0:
         gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
         info = M.launch_info(local_rows, local_nnz, vb)
-        b_alg = algorithmic_bytes(local_rows, cols, local_nnz, vb)
-        tile_s = prof["tile_ms"] * 1e-3
-        achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
-        traffic = None
-        replayed = None
-        traffic_source = "not measured: the counter passes (rocprofv3 --pmc) are run for single-GPU workloads only"
-        if not mg:
-            label = "c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload
-            replayed, src = replayed_traffic(label, dtype_name)
-            live, live_src = ((None, "skipped (--no-live-pmc, a tuning override, or config 5: rocprofv3 does not survive generating its 36 GB)")
-                              if args.no_live_pmc or args.tune or args.band_passes or workload == "c5" else live_traffic(label))
-            if live is not None:
-                traffic, traffic_source = live, live_src
-            elif replayed is not None:
-                traffic, traffic_source = replayed, src + f" [live counters: {live_src}]"
+        eff = effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "CsrMV GFLOP/s", "value": round(gflops, 3), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": desc,
-                       "tile": f"{info['block_threads']}x{info['items_per_thread']}",
+            "config": {"workload": desc, "tile": f"{info['block_threads']}x{info['items_per_thread']}",
                        "partition": ("single GPU" if not mg else
-                                     f"merge-path diagonal split over {world} GPUs (mspmv_mg_partition): "
-                                     f"{local_rows - 1} rows + {local_nnz} nonzeros on rank 0; one exchange of {world} carries per step")},
-            "effective_GBs_reference_formula": round(effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
-            "effective_pct_of_peak": round(100.0 * effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 2),
-            "compulsory_GBs": round(algorithmic_bytes(rows, cols, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9, 2),
-            "roofline": {"kernel": "tile_kernel_snap (one launch per part)", "achieved": round(achieved, 2), **roofline_bound(M, b_alg, achieved),
-                         "traffic": traffic, "traffic_source": traffic_source, "traffic_is": "l2_fabric_bytes_infinity_cache_hits_included",
-                         "traffic_over_algorithmic": round(traffic / b_alg, 3) if traffic else None,
-                         "traffic_replayed_from_committed_passes": (replayed if not mg else None), "algorithmic_bytes_per_launch": b_alg,
-                         "kernel_ms": {"search": round(prof["search_ms"], 5), "tile": round(prof["tile_ms"], 5),
-                                       "fixup": round(prof["fixup_ms"], 5)},
-                         "events": f"hipEvents on the launch stream, {prof['calls']} launches"},
+                                     f"merge-path diagonal split over {world} GPUs: {local_rows - 1} rows + {local_nnz} nnz on rank 0; one exchange of {world} carries per step")},
+            "effective_GBs_reference_formula": round(eff, 1), "effective_pct_of_peak": round(100.0 * eff / HBM_PEAK_GBS, 2),
         }
         if not mg:
-            # column-band passes of the stateless call: offered by the sizes, accepted (or not) by the device-side windows
-            offered = M.band_passes(local_rows, cols, local_nnz, vb)
-            rec = {"offered_by_policy": offered, "passes_run": 0, "windows_spread_of_64": None}
-            if offered > 1:
-                spread = int(M.debug_band_windows(ws, local_rows, local_nnz, vb).sum())
-                rec["windows_spread_of_64"] = spread
-                rec["passes_run"] = offered if (spread >= 56 or args.band_passes >= 2) else 0
-                rec["note"] = ("the tile kernel streamed the CSR arrays `passes_run` times, each pass gathering one column band of x "
-                               "(the slice stays in every XCD's L2); algorithmic bytes count the arrays once")
-            out["roofline"]["column_band_passes"] = rec
-            # which kernel the figures are for: candidates for the column-band passes run the classic three launches with the BAND
-            # tile kernel, every other call ONE launch of tile_kernel_snap (its "search" / "fixup" figures are then just the cost of
-            # two back-to-back event records)
-            out["roofline"]["kernel"] = "tile_kernel_vec<.., BAND>" if offered > 1 else "tile_kernel_snap (one launch: no coordinate pass, no fix-up)"
-        if not mg:
+            label = "c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload
+            out["roofline"] = roofline_record(M, A, cols, prof, ms_per_step, ws, label, dtype_name)
             chk = M.sampled_check(A, x, y)
             out["sampled_worst_ratio"] = chk["worst_ratio"]
-            out["sampled_check"] = dict(chk, what="2^16 seeded rows + the first, last and longest recomputed in fp64 with torch gathers against the stated bound "
-                                                  "|y - g| <= 2 (ceil(log2(len + 1)) + depth + 8) eps s (SURVEY 8d); < 1 passes; parity proper: tests/ -m gpu")
+            out["sampled_check"] = chk
+        else:
+            b_alg = algorithmic_bytes(local_rows, cols, local_nnz, vb)
+            tile_s = prof["tile_ms"] * 1e-3
+            achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
+            out["roofline"] = {"kernel": "tile_kernel_snap (rank 0's part)", "achieved": round(achieved, 1), **roofline_bound(M, b_alg, achieved),
+                               "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(prof["tile_ms"], 5), "traffic": None,
+                               "traffic_over_algorithmic": None, "traffic_src": None}
         if exchange is not None:
-            out["exchange"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
+            ex = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
             if isinstance(exchange.get("exchange"), int):
-                out["exchange"]["backend"] = {1: "RCCL ncclAllGather (1 element per rank) below the C ABI", 2: "peer reads",
-                                              3: "hipIpc peer writes into the owner's mailbox, step-tagged (no collective)"}.get(exchange["exchange"])
+                ex["backend"] = {1: "rccl all-gather", 2: "peer reads", 3: "hipIpc mailbox"}.get(exchange["exchange"])
+            out["exchange"] = ex
         if per_rank is not None:
             out["per_rank"] = per_rank
-        if hot is not None:
-            out["hot_column_plan"] = hot
         if single is not None:
             out["single_gpu_same_workload"] = single
-        if not mg and workload == "c2" and not args.no_plan and hasattr(M, "CsrMVPlan"):
-            out["prepared_plan"] = M.plan_bench_record(A, x, y, steps=args.steps, warmup=args.warmup, peak_gbs=HBM_PEAK_GBS)
-        if not mg and not args.no_vendor:
-            out["vendor"] = vendor_record(torch, A, x, y, min(args.steps, 30))
-            if "ms_per_step" in out["vendor"]:
-                out["vendor"]["vendor_time_over_ours"] = round(out["vendor"]["ms_per_step"] / ms_per_step, 3)
+        full = None
+        if args.full and not mg:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_full as full
+            full.extend_headline(out, M, torch, G, A, x, y, ws, workload, dtype_name, args)
         if not mg and not args.no_cpu_baseline and A.nnz <= 400_000_000:
             out["cpu_baseline"] = cpu_baseline(A, x, "same " + workload.upper() + " matrix")
-        if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs and not args.tune and not args.band_passes:
+        if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs:
             del A, ws, y
             torch.cuda.empty_cache()
-            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget, vendor=not args.no_vendor, live_pmc=not args.no_live_pmc,
-                                            mtx_dir=args.mtx_dir, c5_pmc=not args.no_c5_pmc)
-        print(json.dumps(out), flush=True)
+            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget if not args.full else 600.0,
+                                            mtx_dir=args.mtx_dir, full=full)
+        emit(out, detail_path)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,10 +19,11 @@
  *     are updated atomically -- else hipErrorInvalidValue;
  *   - the caller owns every buffer including temp; the callee allocates
  *     nothing and keeps no state between calls (what a call leaves in temp
- *     storage is scratch, except for mspmv_csrmv_prepare); the only library
- *     state is the development override of mspmv_set_tuning /
- *     mspmv_set_band_passes, which is per host thread, off by default and read
- *     once per call on entry, and the opt-in event profiler;
+ *     storage is scratch, except for mspmv_csrmv_prepare); the library reads
+ *     nothing from the environment and has no setters -- the forcing and
+ *     re-tuning aids of the tests live in libmspmv_dev.so (include/mspmv_dev.h)
+ *     only; the one piece of process state is the opt-in event profiler
+ *     (mspmv_profile_begin/_end), which never changes what a call launches;
  *   - all array pointers are DEVICE pointers; d_row_offsets has rows+1 entries
  *     ([0]=0, [rows]=nnz, non-decreasing), 0-based int32 column indices,
  *     duplicates allowed (sparse_matrix.h:645-650,666-728); d_x holds cols
@@ -54,7 +55,7 @@ extern "C" {
  * no HIP headers (NULL = the default stream). */
 typedef void *mspmv_stream_t;
 
-#define MSPMV_VERSION 100 /* 0.1.0 */
+#define MSPMV_VERSION 101 /* 0.1.1: mspmv_launch_info_t grew (records_offset, layout_offset); the setters moved to mspmv_dev.h */
 int mspmv_version(void);
 
 /* hipGetErrorString for codes returned by this library. */
@@ -114,12 +115,15 @@ int mspmv_csrmm_f64(void *d_temp, size_t *temp_bytes, const double *d_values,
  * (same two-phase size query; the size equals mspmv_csrmv_*'s for the same rows/nnz/value_bytes).  The default
  * one-launch kernel treats the coordinates it finds in temp storage as hints and verifies them, so a stateless
  * call that follows another on the same temp storage and matrix already runs without a search; preparing makes
- * the FIRST call as fast as the later ones, and it is what the classic pipeline (column-band candidates, tuning
- * options) skips its coordinate launch on;
+ * the FIRST call as fast as the later ones, and it is what the classic pipeline (column-band candidates, arrays that
+ * are not 16-byte aligned) skips its coordinate launch on;
  * mspmv_csrmv_prepared_* then compute y = alpha*A*x + beta*y with the coordinates found there.
  * The caller guarantees that d_temp was prepared for this d_row_offsets / rows / nnz / value_bytes
- * and has since been used only by mspmv calls for the same matrix (they leave the coordinates
- * intact).  Results are bitwise those of mspmv_csrmv_* / mspmv_csrmv_axpby_*. ---- */
+ * and has since been used only by mspmv calls for the same matrix: they leave the prepared coordinates
+ * intact (the one family of calls that picks another tile shape by its column count -- mspmv_get_launch_info_cols --
+ * keeps that shape's hints in a region of its own behind the default layout, and only in the one-launch form, whose
+ * hints are verified).  mspmv_csrmv_prepared_* pick their shape by the same rule as the stateless calls, so results
+ * are bitwise those of mspmv_csrmv_* / mspmv_csrmv_axpby_* given the same temp_bytes. ---- */
 int mspmv_csrmv_prepare(void *d_temp, size_t *temp_bytes, const int32_t *d_row_offsets,
                         int32_t rows, int32_t nnz, int32_t value_bytes,
                         mspmv_stream_t stream, int debug_sync);
@@ -182,7 +186,7 @@ int mspmv_csrmv_plan_apply_f64(void *d_plan, size_t plan_bytes, const double *d_
  * the column-band passes; a stateless call whose sizes make it one (mspmv_get_band_passes > 1: x of 5.5-40 MiB, >= 8 nonzeros
  * per row, a CSR stream >= 160 MiB) runs the classic three launches -- one carry per tile and a fix-up, another association of
  * the sums of rows that cross tiles -- whether or not the device-side windows then let the passes run, so compare with
- * mspmv_set_band_passes(vb, -1) there (bench.py's hot_column_plan records do).  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
+ * the one-launch form there (dev library: mspmv_set_band_passes(vb, -1)).  Config 5 on one GPU: 34.2 -> 20.6 ms.  Same conventions as
  * the band-major plan below (caller-owned storage of mspmv_csrmv_hotcols_size bytes, the same rows / cols / nnz /
  * value_bytes to every call, asynchronous on `stream`); d_values / d_row_offsets passed to _apply must be the arrays
  * the plan was built for.  No reference counterpart (its HYB column is the precedent for set-up timed apart,
@@ -224,7 +228,7 @@ typedef struct mspmv_launch_info {
     int32_t num_tiles;         /* ceil((rows+nnz) / tile_items)               */
     int32_t fixup_chunk;       /* carry pairs per fix-up block                */
     int32_t fixup_levels;      /* fix-up launches (0 when num_tiles <= 1)     */
-    int32_t flags;             /* MSPMV_TUNE_* bits in effect                 */
+    int32_t flags;             /* option bits in effect: 0 in this library (mspmv_dev.h: MSPMV_TUNE_*) */
     int32_t snap_head_max;     /* > 0: calls of these sizes run ONE launch of row-snapped tiles (tile_kernel_snap;
                                   16-byte aligned arrays assumed, decided again per call):
                                   a tile boundary that falls <= this many nonzeros into a row is moved to the row's
@@ -236,20 +240,22 @@ typedef struct mspmv_launch_info {
     uint64_t diag_offset;      /* two int32: [0] = tag of the last one-launch call in which a tile gave up waiting for another
                                   workgroup's record and computed the sum itself (debug_sync reports it), [1] = how many such
                                   episodes this temp storage has seen; neither is ever needed for a result */
-    uint64_t records_offset;   /* the tagged records of the one-launch kernel: 16 bytes per tile + per group of 64 tiles; every slot is
-                                  (0, 0) again once a launch has ended (tests/test_forward_progress.py)                          */
+    uint64_t records_offset;   /* the tagged records of the one-launch kernel: 16 bytes per tile + per group of 64 tiles; every slot a
+                                  launch TOUCHED is (0, 0) again once it has ended (slots it never used keep what the buffer held:
+                                  tests/test_forward_progress.py zeroes the buffer first; tests/test_record_protocol_model.py) */
 } mspmv_launch_info_t;
 
 /* value_bytes = 4 (float) or 8 (double).  The layout of a call of these sizes under the default choice of tile shape; temp_bytes is
  * large enough for any column count (one family of calls picks its shape by the column count too: see mspmv_get_launch_info_cols). */
 int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes,
                           mspmv_launch_info_t *info);
-/* The same with the column count, i.e. exactly what mspmv_csrmv_f32 / _f64 (and _axpby_*) run for these sizes when given at least
- * info->temp_bytes of temp storage: a large fp64 matrix (more than 8 M rows + nonzeros, at most 256 MB of CSR arrays) of at most 8
- * nonzeros per row on average over an x of at most 4 KB -- the reference's --dense=<cols> inputs, cpu_spmv.cpp:581-587 -- takes the
- * small tile shape behind the compact front end (csrc/mspmv_api.hip: skinny_rule).  Rows of closed lean tiles -- every row of a
- * --dense input -- are summed left to right whatever the shape, so their y does not change by a bit; a long row among them is
- * associated as that shape's tiles cut it (the stated bound holds either way). */
+/* The same with the column count, i.e. exactly what mspmv_csrmv_f32 / _f64 (_axpby_*, _prepared_*) run for these sizes when given at
+ * least info->temp_bytes of temp storage and 16-byte aligned arrays: a large fp64 matrix (more than 8 M rows + nonzeros, at most 256 MB
+ * of CSR arrays) of at most 8 nonzeros per row on average over an x of at most 4 KB -- the reference's --dense=<cols> inputs,
+ * cpu_spmv.cpp:581-587 -- takes the small tile shape behind the compact front end (csrc/mspmv_api.hip: skinny_rule); its layout sits
+ * BEHIND the default one in temp storage (the offsets reported here are absolute), so temp_bytes is the sum of the two.  Rows of
+ * closed lean tiles -- every row of a --dense input -- are summed left to right whatever the shape, so their y does not change by a
+ * bit; a long row among them is associated as that shape's tiles cut it (the stated bound holds either way). */
 int mspmv_get_launch_info_cols(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes,
                                mspmv_launch_info_t *info);
 
@@ -265,45 +271,8 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz,
                            int32_t *h_carry_keys, void *h_carry_values,
                            mspmv_stream_t stream);
 
-/* Tuning override for experiments (per HOST THREAD: it affects the calls the same thread makes afterwards, including
- * the size queries, and nothing else -- the plans of mspmv_csrmv_plan_* and mspmv_mg_plan_* always run the library
- * defaults; 0 = library default): selects one of the
- * compiled tile shapes for value_bytes and/or the option bits below.  Returns 0, or
- * hipErrorInvalidValue if that shape was not compiled in or a bit is not one of these.  Every
- * combination accepted here computes correct results; kernels that exist only for timing
- * experiments are not part of this library (they live in the -DMSPMV_DEV build, include/mspmv_dev.h). */
-#define MSPMV_TUNE_NO_XLDS    0x80000 /* never gather a tiny x (<= 4 KB) from LDS */
-#define MSPMV_TUNE_ATOMIC_FIX 2   /* single-launch atomicAdd fix-up (non-deterministic) */
-#define MSPMV_TUNE_NO_VEC     4   /* force the dword-per-lane kernel with the reference's per-thread path walk (the path taken for unaligned arrays) */
-#define MSPMV_TUNE_BINARY_SEARCH 8 /* tile coordinates by a 64-ary wave search per boundary */
-#define MSPMV_TUNE_SCATTER_COORDS 0x10000000 /* ... always by one coalesced pass over all row offsets (the default below 10 M rows) */
-#define MSPMV_TUNE_INTERP_COORDS  0x20000000 /* ... always by one thread per boundary, interpolation search (the default from 10 M rows up) */
-#define MSPMV_TUNE_NO_FUSED   16  /* small problems take the large-problem tile shape too (256x11; fp64 up to 8 M path items: 256x7) */
-#define MSPMV_TUNE_TWO_LAUNCH 0x40000000 /* the classic three launches (coordinate pass, tile_kernel_vec with one carry per tile, fix-up) instead of ONE launch of
-                                           row-snapped tiles on verified coordinate hints (tile_kernel_snap) */
-#define MSPMV_TUNE_FORCE_NT   32  /* CSR streams always read with non-temporal loads */
-#define MSPMV_TUNE_FORCE_TEMPORAL 64 /* ... always with ordinary loads (default: by matrix size vs the 256 MB Infinity Cache) */
-#define MSPMV_TUNE_NO_LEAN ((int32_t) 0x80000000u) /* one-launch kernel: closed tiles of short rows take the general flag/segmented-scan reduction too (default: the
-                                           row-by-row reduction, consume_tile_rows) */
-#define MSPMV_TUNE_MULTILEVEL_FIX 128 /* carry fix-up in two/three chunked levels (one launch each) instead of the one-launch owner-computes kernel */
-/* bits 24..27: block -> tile mapping of the tile kernel: 0 = default (runs of 64 consecutive tiles per XCD),
- * 15 = plain round-robin, else log2 of the run length. */
-int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
-                     int32_t items_per_thread, int32_t flags);
-
-/* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of
- * 1.375-10 x one XCD's L2 (fp32; 1.75-9 x in fp64: 5.5-40 / 7-36 MiB on MI355X) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each
- * pass multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 10-29 %
- * faster.  The call stays stateless, asynchronous and three launches: 64 blocks added to the coordinate
- * launch sample 64 windows of 2048 consecutive column indices, and the tile kernel reads their verdicts and
- * runs either its ordinary body or the passes.  Results stay within the strict bound and are bitwise
- * reproducible; rounding differs from the one-sweep result in the last bits (a re-association).
- *   passes = 0  automatic (default): by the sizes of the call (csrc/mspmv_api.hip: band_passes_for) and the verdicts
- *   passes < 0  never
- *   passes >= 2 always that many passes, on any call that takes the 256x11 tile or, in fp64, the 256x7 tile (tests, tuning). */
-int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
 /* What the automatic column-band policy is derived from on the current device: one XCD's L2 in bytes and the number of XCDs
- * (queried from the runtime once per device; MSPMV_FAKE_L2_MIB / MSPMV_FAKE_XCDS in the environment override them), and the
+ * (queried from the runtime once per device), and the
  * CU count.  Without a device: the MI355X figures (4 MiB, 8, 256).  Any pointer may be NULL. */
 int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *cus);
 /* Measuring aid: ONE launch of a bare read stream over d_buf (16-byte aligned; bytes / 16 sixteen-byte loads, 256 x 11 per block
@@ -311,21 +280,14 @@ int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *c
  * in the Infinity Cache it gives the rate a cache-resident SpMV's algorithmic bytes are to be read against -- the HBM peak is not
  * the bound of such a call (bench.py: `roofline.bound` = "infinity_cache"). */
 int mspmv_probe_read_stream(const void *d_buf, size_t bytes, int32_t nontemporal, mspmv_stream_t stream);
-/* Testing aid (per HOST THREAD, like mspmv_set_tuning): how often a tile of the one-launch kernel in which a long row ENDS
- * looks for the partial sum another workgroup publishes before it computes that sum itself from the matrix (0 = the
- * library default, ~0.1 s of polling; 1 = one look; < 0 = never look, which sends every such tile down the recomputing path).  The
- * result is correct for any value: nothing in a call depends on another workgroup making progress; only the time and, by a
- * re-association, the last bits of such a row do. */
-int mspmv_set_record_polls(int32_t polls);
-/* Testing / tuning aid (per HOST THREAD): up to how many tiles a call of the small tile shape runs the one-launch kernel behind its
- * COMPACT FRONT END (csrc/mspmv_kernels.hpp: compact_front -- small problems, one contiguous tile range per XCD; closed lean tiles on good hints take
- * ~200 instructions per wave of straight-line code at the head of the kernel, every other tile the general body of the same kernel).
- * 0 = the library default (2304 tiles: the sizes at which the matrix stays in the XCDs' L2s between calls), > 0 = that many, < 0 = never.  y is bit for bit the same
- * either way (tests/test_gpu_parity.py: the `compact` / `no_compact` paths).  Matches the reference's special case for small
- * problems (dispatch_spmv_orig.cuh:674-679, agent_spmv_orig.cuh:867-891). */
-int mspmv_set_compact_tiles(int32_t max_tiles);
-/* *passes = how many passes a call of these sizes is offered under the current setting (0: none; the aligned,
- * vectorised path is assumed); with the automatic setting the device-side verdicts still have the last word. */
+/* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of 1.375-10 x one XCD's L2
+ * (fp32; 1.75-9 x in fp64: 5.5-40 / 7-36 MiB on MI355X) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each pass
+ * multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 10-29 % faster.  The call stays stateless,
+ * asynchronous and three launches: 64 blocks added to the coordinate launch sample 64 windows of 2048 consecutive column indices, and
+ * the tile kernel reads their verdicts and runs either its ordinary body or the passes.  Results stay within the strict bound and are
+ * bitwise reproducible; rounding differs from the one-sweep result in the last bits (a re-association).
+ * *passes = how many passes a call of these sizes is offered (0: none; the aligned, vectorised path is assumed; csrc/mspmv_api.hip:
+ * band_passes_for); the device-side verdicts have the last word. */
 int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes);
 /* The 64 window verdicts (1 = columns look uniformly spread) the last automatic call left in d_temp -> HOST
  * array of 64 int32 (synchronises `stream`); at least 56 ones select the band passes. */
@@ -458,7 +420,10 @@ int mspmv_mg_plan_info(mspmv_mg_plan_t *plan, mspmv_mg_info_t *info);
  *   enable > 0   always (every local part; hipErrorOutOfMemory if one cannot)
  *   enable == 0  never; releases the storage
  * y is bit for bit the same either way (parts that would take the column-band passes excepted, as above); mspmv_mg_plan_info reports
- * how many local parts run it (hot_parts).  MSPMV_FAKE_INFINITY_CACHE_MIB in the environment overrides the cache size (tests). */
+ * how many local parts run it (hot_parts).  May be called before the parts' matrices are attached: the mode is then applied by
+ * mspmv_mg_plan_set_part, which -- in the automatic and "always" modes -- runs a SYNCHRONOUS probe / build on the part's stream and
+ * may allocate the storage above; under "always" a part that cannot afford it makes set_part return hipErrorOutOfMemory with the
+ * matrix attached and no plan (the part runs the ordinary call). */
 int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable);
 /* Milliseconds the EXCHANGE of the last mspmv_mg_csrmv took on local part `local_index` -- hipEvents on the part's stream right after
  * its SpMV and right after its share of the exchange (the all-gather / the peers' events, the owner's add): what a step costs beyond

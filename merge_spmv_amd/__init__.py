@@ -22,8 +22,9 @@ __all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "CsrMVPlan", "plan_
            "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_NAME = "libmspmv.so"
-_lib: Optional[ctypes.CDLL] = None
+_LIB_NAMES = {"product": "libmspmv.so", "dev": "libmspmv_dev.so"}
+_libs = {}                 # kind -> ctypes.CDLL
+_active = "product"
 
 TUNE_ATOMIC_FIX = 2
 TUNE_NO_VEC = 4
@@ -33,10 +34,29 @@ class MspmvError(RuntimeError):
     pass
 
 
-def library_path() -> str:
-    """libmspmv.so next to this file; MSPMV_LIB=<path> selects another build of the same ABI
-    (the -DMSPMV_DEV library the tuning tools use)."""
-    return os.environ.get("MSPMV_LIB") or os.path.join(_HERE, _LIB_NAME)
+def library_path(kind: Optional[str] = None) -> str:
+    """The active library's file: libmspmv.so (the product: no setters, nothing read from the environment) or libmspmv_dev.so (the same
+    sources built with -DMSPMV_TUNING: include/mspmv_dev.h) next to this file.  MSPMV_LIB=<path> replaces the PRODUCT library by another
+    build of the same ABI (A/B tools)."""
+    kind = kind or _active
+    if kind == "product" and os.environ.get("MSPMV_LIB"):
+        return os.environ["MSPMV_LIB"]
+    return os.path.join(_HERE, _LIB_NAMES[kind])
+
+
+def use_library(kind: str = "product") -> str:
+    """Make `kind` ("product" | "dev") the library every wrapper of this module calls from now on; returns the previous kind.  The
+    setters (set_tuning, set_band_passes, set_record_polls, set_compact_tiles) exist in the development library only and switch to
+    it themselves when asked for a non-default value -- tests/conftest.py switches back to the product after every test."""
+    global _active
+    if kind not in _LIB_NAMES:
+        raise ValueError(f"use_library: {kind!r} is not one of {sorted(_LIB_NAMES)}")
+    prev, _active = _active, kind
+    return prev
+
+
+def active_library() -> str:
+    return _active
 
 
 class _LaunchInfo(ctypes.Structure):
@@ -51,9 +71,8 @@ class _LaunchInfo(ctypes.Structure):
 def load_library() -> ctypes.CDLL:
     """dlopen libmspmv.so (built in-tree by `make -C merge_spmv_amd` or
     __graft_entry__.build()).  Fails loudly when absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    if _active in _libs:
+        return _libs[_active]
     path = library_path()
     if not os.path.exists(path):
         raise MspmvError(f"{path} not found: build the HIP extension first "
@@ -97,18 +116,19 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_get_launch_info_cols.argtypes = [i32, i32, i32, i32, ctypes.POINTER(_LaunchInfo)]
     lib.mspmv_debug_read_tiles.restype = ctypes.c_int
     lib.mspmv_debug_read_tiles.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
-    lib.mspmv_set_tuning.restype = ctypes.c_int
-    lib.mspmv_set_tuning.argtypes = [i32, i32, i32, i32]
     lib.mspmv_profile_begin.restype = ctypes.c_int
     lib.mspmv_profile_begin.argtypes = [i32]
     lib.mspmv_profile_end.restype = ctypes.c_int
     lib.mspmv_profile_end.argtypes = [ctypes.POINTER(ctypes.c_int32)] + [ctypes.POINTER(ctypes.c_float)] * 3
-    lib.mspmv_set_band_passes.restype = ctypes.c_int
-    lib.mspmv_set_band_passes.argtypes = [ctypes.c_int32, ctypes.c_int32]
-    lib.mspmv_set_record_polls.restype = ctypes.c_int
-    lib.mspmv_set_record_polls.argtypes = [ctypes.c_int32]
-    lib.mspmv_set_compact_tiles.restype = ctypes.c_int
-    lib.mspmv_set_compact_tiles.argtypes = [ctypes.c_int32]
+    if hasattr(lib, "mspmv_set_tuning"):          # (the development library, or an MSPMV_LIB build that has the setters)
+        lib.mspmv_set_tuning.restype = ctypes.c_int
+        lib.mspmv_set_tuning.argtypes = [i32, i32, i32, i32]
+        lib.mspmv_set_band_passes.restype = ctypes.c_int
+        lib.mspmv_set_band_passes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+        lib.mspmv_set_record_polls.restype = ctypes.c_int
+        lib.mspmv_set_record_polls.argtypes = [ctypes.c_int32]
+        lib.mspmv_set_compact_tiles.restype = ctypes.c_int
+        lib.mspmv_set_compact_tiles.argtypes = [ctypes.c_int32]
     lib.mspmv_get_band_passes.restype = ctypes.c_int
     lib.mspmv_get_band_passes.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)]
     lib.mspmv_debug_band_windows.restype = ctypes.c_int
@@ -161,8 +181,22 @@ def load_library() -> ctypes.CDLL:
     for name in ("mspmv_mg_csrmv", "mspmv_mg_allgather_rows", "mspmv_mg_synchronize", "mspmv_mg_plan_destroy"):
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = [vp]
-    _lib = lib
+    _libs[_active] = lib
     return lib
+
+
+def _setter(name: str, default: bool, *args) -> None:
+    """The setters of include/mspmv_dev.h.  The product library has none: asking it for the defaults is a no-op; asking for anything else
+    switches this module to the development library (use_library("dev")) -- the same kernels with the per-thread overrides compiled in."""
+    lib = load_library()
+    if not hasattr(lib, name):
+        if default:
+            if "dev" in _libs and _libs["dev"] is not lib:        # (a test may have left an override in the development library's thread state)
+                _check(getattr(_libs["dev"], name)(*args), name)
+            return
+        use_library("dev")
+        lib = load_library()
+    _check(getattr(lib, name)(*args), name)
 
 
 def _check(status: int, what: str) -> None:
@@ -518,12 +552,14 @@ def _equal_to_one_launch(A, x, y_plan) -> bool:
     """y_plan == the stateless call's y with the column-band candidacy switched off (mspmv_set_band_passes(vb, -1))"""
     import torch
     vb = A.values.element_size()
+    prev = active_library()
     try:
-        set_band_passes(vb, -1)
+        set_band_passes(vb, -1)               # (development library: the same kernels + the override)
         y = csrmv(A.values, A.row_offsets, A.column_indices, x, num_cols=A.cols)
         torch.cuda.synchronize()
     finally:
         set_band_passes(vb, 0)
+        use_library(prev)
     return bool(torch.equal(y, y_plan))
 
 
@@ -586,8 +622,9 @@ def serial_sum_depth(num_rows: int, num_cols: int, num_nonzeros: int, value_byte
 
 
 def set_tuning(value_bytes: int, block_threads: int = 0, items_per_thread: int = 0, flags: int = 0) -> None:
-    _check(load_library().mspmv_set_tuning(int(value_bytes), int(block_threads), int(items_per_thread), int(flags)),
-           "mspmv_set_tuning")
+    """mspmv_set_tuning (development library: a non-default value switches to it, see _setter)."""
+    _setter("mspmv_set_tuning", block_threads == 0 and items_per_thread == 0 and flags == 0,
+            int(value_bytes), int(block_threads), int(items_per_thread), int(flags))
 
 
 def profile_begin(max_calls: int) -> None:
@@ -605,7 +642,7 @@ def profile_end() -> dict:
 
 def set_band_passes(value_bytes: int, passes: int = 0) -> None:
     """Column-band passes (mspmv_set_band_passes): 0 automatic, < 0 never, >= 2 always that many."""
-    _check(load_library().mspmv_set_band_passes(int(value_bytes), int(passes)), "mspmv_set_band_passes")
+    _setter("mspmv_set_band_passes", passes == 0, int(value_bytes), int(passes))
 
 
 def device_caches() -> dict:
@@ -620,7 +657,7 @@ def device_caches() -> dict:
 def set_record_polls(polls: int = 0) -> None:
     """Testing aid (mspmv_set_record_polls): 0 = library default, 1 = one look, -1 = never look: tiles in which a long row ends
     compute the pieces held by other workgroups themselves instead of taking the published records."""
-    _check(load_library().mspmv_set_record_polls(int(polls)), "mspmv_set_record_polls")
+    _setter("mspmv_set_record_polls", polls == 0, int(polls))
 
 
 def cache_stream_rate(nbytes: int, reps: int = 20) -> float:
@@ -649,7 +686,7 @@ def cache_stream_rate(nbytes: int, reps: int = 20) -> float:
 def set_compact_tiles(max_tiles: int = 0) -> None:
     """Testing / tuning aid (mspmv_set_compact_tiles): up to how many tiles a call of the small tile shape runs the one-launch kernel
     behind its compact front end (0 = library default, > 0 = that many, < 0 = never).  y is bit for bit the same either way."""
-    _check(load_library().mspmv_set_compact_tiles(int(max_tiles)), "mspmv_set_compact_tiles")
+    _setter("mspmv_set_compact_tiles", max_tiles == 0, int(max_tiles))
 
 
 def band_passes(rows: int, cols: int, nnz: int, value_bytes: int) -> int:

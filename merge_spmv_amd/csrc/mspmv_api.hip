@@ -32,10 +32,17 @@ constexpr int FIX_CHUNK = FIX_BLOCK * FIX_IPT;
 constexpr int DEV_FLAG_MASK = 1 | 0xff00 | 0x70000 | 0xf00000;   // selectors of the -DMSPMV_DEV kernel variants
 constexpr int SMALL_MAX_TILES_DEFAULT = 2304;    // fp32: up to this many 256x7 tiles a problem takes that shape, 256x11 beyond (1024 until the compact front end, 1408 until its
                                                  // launches took one contiguous tile range per XCD: grid2d-900 fp32, 2258 tiles, 7.5 -> 6.7 us)
-// (MSPMV_SMALL_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
+// The PRODUCT library reads nothing from the environment and has no setters: the re-tuning aids below (an environment variable read
+// once, the per-thread overrides of include/mspmv_dev.h) exist only in the -DMSPMV_TUNING build, libmspmv_dev.so.
+#ifdef MSPMV_TUNING
+static int env_int(const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; }
+#else
+static constexpr int env_int(const char *, int fallback) { return fallback; }
+#endif
+// (dev library: MSPMV_SMALL_MAX_TILES in the environment overrides it, read once: an aid for re-tuning the threshold on other parts)
 static int small_max_tiles()
 {
-    static const int v = [] { const char *e = getenv("MSPMV_SMALL_MAX_TILES"); const int n = e ? atoi(e) : 0; return n > 0 ? n : SMALL_MAX_TILES_DEFAULT; }();
+    static const int v = [] { const int n = env_int("MSPMV_SMALL_MAX_TILES", 0); return n > 0 ? n : SMALL_MAX_TILES_DEFAULT; }();
     return v;
 }
 #define SMALL_MAX_TILES (small_max_tiles())
@@ -55,7 +62,7 @@ constexpr int LEAN_AVG_DEFAULT = 12;
 // once: a re-tuning aid), 0 = never
 static int compact_max_tiles(int value_bytes)
 {
-    static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAX_TILES"); return e ? atoi(e) : -1; }();
+    static const int v = env_int("MSPMV_COMPACT_MAX_TILES", -1);
     (void) value_bytes;
     return v >= 0 ? v : 2304;
 }
@@ -63,12 +70,12 @@ static int compact_max_tiles(int value_bytes)
 // MSPMV_COMPACT_MAP in the environment overrides it (read once: a re-tuning aid)
 static int compact_tile_map()
 {
-    static const int v = [] { const char *e = getenv("MSPMV_COMPACT_MAP"); return e ? (atoi(e) != 0) : 1; }();
+    static const int v = env_int("MSPMV_COMPACT_MAP", 1) != 0;
     return v;
 }
 static int lean_avg_default()
 {
-    static const int v = [] { const char *e = getenv("MSPMV_LEAN_AVG"); const int n = e ? atoi(e) : -1; return n >= 0 ? n : LEAN_AVG_DEFAULT; }();
+    static const int v = [] { const int n = env_int("MSPMV_LEAN_AVG", -1); return n >= 0 ? n : LEAN_AVG_DEFAULT; }();
     return v;
 }
 
@@ -82,15 +89,20 @@ struct Shape { int block, ipt; };
 #ifdef MSPMV_DEV
 static const Shape kShapesF32[] = {{256, 7}, {256, 11}, {256, 9}, {256, 15}, {256, 5}, {128, 7}, {512, 7}};
 static const Shape kShapesF64[] = {{256, 7}, {256, 11}, {256, 5}, {256, 9}, {256, 3}, {128, 5}, {512, 5}};
-#else
+#elif defined(MSPMV_TUNING)
 static const Shape kShapesF32[] = {{256, 7}, {256, 11}};
 static const Shape kShapesF64[] = {{256, 7}, {256, 11}};
 #endif
 
-// The development override of mspmv_set_tuning / mspmv_set_band_passes: per HOST THREAD (a measuring or testing aid; a
-// library user never touches it), read once per call at the C entry points.  [0] = 4-byte values, [1] = 8-byte values
+// The development override of mspmv_set_tuning / mspmv_set_band_passes (include/mspmv_dev.h, libmspmv_dev.so only): per HOST THREAD,
+// read once per call at the C entry points.  [0] = 4-byte values, [1] = 8-byte values.  The product library has no such state:
+// every call runs the defaults.
+#ifdef MSPMV_TUNING
 static thread_local Tune t_tune[2];
 static inline const Tune &thread_tune(int value_bytes) { return t_tune[value_bytes == 8]; }
+#else
+static inline const Tune &thread_tune(int) { static const Tune defaults; return defaults; }
+#endif
 
 // Default shape (measured on MI355X with the one-launch kernel; profiles/r03_small_shapes.txt, r03_sweep_vs_rocsparse.txt):
 //  * fp32: 256x7 while that cuts the problem into at most SMALL_MAX_TILES (2304; 1024 until round 5) tiles -- more, smaller tiles keep more CUs
@@ -174,8 +186,8 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune, 
 }
 
 // What the column-band policy is derived from: the L2 a gather can hit in -- one XCD's, as the runtime reports it -- and
-// how many of them the device has; queried once per device (never on the hot path again).  MSPMV_FAKE_L2_MIB / MSPMV_FAKE_XCDS in
-// the environment override the query (read once: tests, and other parts / partition modes where the runtime's figure is wrong).
+// how many of them the device has; queried once per device (never on the hot path again).  Dev library only: MSPMV_FAKE_L2_MIB /
+// MSPMV_FAKE_XCDS in the environment override the query (read once: tests of the policy).
 struct DeviceCaches { long long l2_bytes; int xcds; };
 static DeviceCaches device_caches()
 {
@@ -194,8 +206,10 @@ static DeviceCaches device_caches()
             // (the runtime reports one XCD's L2 on this part; a figure of 16 MiB or more can only be an aggregate)
             c.l2_bytes = v >= (16 << 20) && c.xcds > 1 ? (long long) v / c.xcds : (long long) v;
         } else (void) hipGetLastError();
+#ifdef MSPMV_TUNING
         if (const char *e = getenv("MSPMV_FAKE_L2_MIB")) { const double m = atof(e); if (m > 0) c.l2_bytes = (long long) (m * 1048576.0); }
         if (const char *e = getenv("MSPMV_FAKE_XCDS")) { const int n = atoi(e); if (n > 0) c.xcds = n; }
+#endif
         cached_xcds[dev].store(c.xcds, std::memory_order_relaxed);
         cached_l2[dev].store(c.l2_bytes, std::memory_order_release);
     }
@@ -455,8 +469,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
             //  earlier block of the same XCD, so a tile that waits for records waits for blocks dispatched before it -- EXCEPT the first
             //  tiles of XCD k's range, which wait for the LAST tiles of XCD k - 1's range: few waiters, a bounded poll, then the sum
             //  recomputed from the matrix; correct, and slow only for a row longer than HEAD_MAX that crosses a range boundary)
-            // (MSPMV_SNAP_MAP in the environment, read once: 30 = one contiguous tile range per XCD for every one-launch call, 0 .. 8 = that run length; a re-tuning aid)
-            static const int env_map = [] { const char *e = getenv("MSPMV_SNAP_MAP"); return e ? atoi(e) : -1; }();
+            // (dev library: MSPMV_SNAP_MAP in the environment, read once: 30 = one contiguous tile range per XCD for every one-launch call, 0 .. 8 = that run length)
+            static const int env_map = env_int("MSPMV_SNAP_MAP", -1);
             const int chunk_log2 = ex.tile_map ? ex.tile_map : env_map == TILE_MAP_CONTIGUOUS_CODE ? env_map
                                  : safe_chunk_log2(env_map >= 0 && env_map <= 8 ? env_map : wanted, resident_blocks(tile_kernel_snap<V, BLOCK, IPT, true, true>, BLOCK, snap_cache));
 #define MSPMV_LAUNCH_SNAP(AX, NTF) launched = launch_exact(tile_kernel_snap<V, BLOCK, IPT, AX, NTF>, dim3(grid), dim3(BLOCK), xl, stream, coords, rstart, L.num_tiles, chunk_log2, p, carries, lb, lean_avg)
@@ -694,17 +708,24 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
     Layout L = make_layout(rows, nnz, (int) sizeof(V), ex.tune);
     bool skinny = false;
     if (ex.allow_skinny && skinny_rule(rows, cols, nnz, (int) sizeof(V), ex.tune, L)) {
-        // (the size query asks for the larger of the two layouts; a caller that sized its storage without the column count --
-        //  mspmv_get_launch_info -- and brings less runs the default shape)
+        // The small-shape layout lives BEHIND the default one in temp storage, so a call that takes it never touches the default
+        // layout's coordinates (what mspmv_csrmv_prepare stored, what the classic pipeline of a prepared call trusts): the size query
+        // asks for both; a caller that sized its storage without the column count (mspmv_get_launch_info) and brings less runs the
+        // default shape.  Taken only when the arrays are 16-byte aligned, i.e. when the ONE-LAUNCH kernel will run (its hints are
+        // verified, whatever the region held before).
         const Layout S = make_layout(rows, nnz, (int) sizeof(V), ex.tune, true);
-        if (d_temp == nullptr) { *temp_bytes = (size_t) (S.total > L.total ? S.total : L.total); return hipSuccess; }
-        if (*temp_bytes >= S.total) { L = S; skinny = true; }
+        const uint64_t both = L.total + S.total;
+        if (d_temp == nullptr) { *temp_bytes = (size_t) both; return hipSuccess; }
+        const bool aligned = nnz >= 4 && rows >= 3 &&
+                             ((reinterpret_cast<uintptr_t>(d_values) | reinterpret_cast<uintptr_t>(d_cols) | reinterpret_cast<uintptr_t>(d_row_offsets) |
+                               reinterpret_cast<uintptr_t>(d_temp)) & 15) == 0;
+        if (*temp_bytes >= both && aligned && S.snap) { d_temp = static_cast<char *>(d_temp) + L.total; L = S; skinny = true; }
     }
     if (d_temp == nullptr) {                      // size query (dispatch_spmv_orig.cuh:651-655)
         *temp_bytes = (size_t) L.total;
         return hipSuccess;
     }
-    if (*temp_bytes < L.total) return hipErrorInvalidValue;   // util_device.cuh:90-93
+    if (!skinny && *temp_bytes < L.total) return hipErrorInvalidValue;   // util_device.cuh:90-93
     // (the temp storage holds 64-bit records updated atomically and is read with scalar loads: 16-byte alignment, which any
     //  device allocation has, is required rather than silently compensated for)
     if (reinterpret_cast<uintptr_t>(d_temp) & 15) return hipErrorInvalidValue;
@@ -737,7 +758,7 @@ static int csrmv_impl(void *d_temp, size_t *temp_bytes, const V *d_values, const
                       V beta, bool axpby, mspmv_stream_t stream_, int debug_sync, int phase = PHASE_ALL)
 {
     CallExtra ex; ex.phase = phase; ex.tune = thread_tune((int) sizeof(V));
-    ex.allow_skinny = phase == PHASE_ALL;
+    ex.allow_skinny = phase != PHASE_COORDS_ONLY;       // (stateless and prepared calls pick their shape by the same rule: bitwise the same y)
     return csrmv_call<V>(d_temp, temp_bytes, d_values, d_row_offsets, d_cols, d_x, d_y, rows, cols, nnz, alpha, beta, axpby,
                          reinterpret_cast<hipStream_t>(stream_), debug_sync, ex);
 }
@@ -1006,13 +1027,14 @@ static int launch_info_impl(int32_t rows, int32_t cols, int32_t nnz, int32_t val
     // cols < 0 (mspmv_get_launch_info: the column count is not known): the default layout, with temp_bytes large enough for the small
     // shape a large fp64 matrix of short rows over a tiny x takes (skinny_rule) -- a buffer sized from here serves either;
     // cols >= 0 (mspmv_get_launch_info_cols): the layout a stateless call of exactly these sizes runs
-    uint64_t temp_bytes = L.total;
+    uint64_t temp_bytes = L.total, base = 0;
     if (cols < 0) {
         if (skinny_rule(rows, 1, nnz, value_bytes, tune, L))      // (the rule holds for SOME column count)
-            temp_bytes = std::max<uint64_t>(temp_bytes, make_layout(rows, nnz, value_bytes, tune, true).total);
+            temp_bytes = L.total + make_layout(rows, nnz, value_bytes, tune, true).total;
     } else if (skinny_rule(rows, cols, nnz, value_bytes, tune, L)) {
+        base = L.total;                                           // (the small-shape layout sits behind the default one: csrmv_call)
         L = make_layout(rows, nnz, value_bytes, tune, true);
-        temp_bytes = std::max<uint64_t>(L.total, make_layout(rows, nnz, value_bytes, tune).total);
+        temp_bytes = base + L.total;
     }
     memset(info, 0, sizeof(*info));
     info->block_threads = L.shape.block;
@@ -1024,10 +1046,10 @@ static int launch_info_impl(int32_t rows, int32_t cols, int32_t nnz, int32_t val
     info->flags = L.flags;
     info->snap_head_max = L.snap ? snap_head_max_host(L.shape.block, L.shape.ipt) : 0;
     info->temp_bytes = temp_bytes;
-    info->coords_offset = L.coords_off;
-    info->carries_offset = L.carries_off;
-    info->diag_offset = L.err_off;
-    info->records_offset = L.pub_off;
+    info->coords_offset = base + L.coords_off;
+    info->carries_offset = base + L.carries_off;
+    info->diag_offset = base + L.err_off;
+    info->records_offset = base + L.pub_off;
     return hipSuccess;
 }
 int mspmv_get_launch_info(int32_t rows, int32_t nnz, int32_t value_bytes, mspmv_launch_info_t *info) { return launch_info_impl(rows, -1, nnz, value_bytes, info); }
@@ -1062,6 +1084,7 @@ int mspmv_debug_read_tiles(const void *d_temp, int32_t rows, int32_t nnz, int32_
     return hipSuccess;
 }
 
+#ifdef MSPMV_TUNING
 int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads, int32_t items_per_thread, int32_t flags)
 {
     if (value_bytes != 4 && value_bytes != 8) return hipErrorInvalidValue;
@@ -1090,6 +1113,8 @@ int mspmv_set_band_passes(int32_t value_bytes, int32_t passes)
     return hipSuccess;
 }
 
+#endif
+
 int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *cus)
 {
     const DeviceCaches dc = device_caches();
@@ -1112,6 +1137,7 @@ int mspmv_probe_read_stream(const void *d_buf, size_t bytes, int32_t nontemporal
     return (int) hipGetLastError();
 }
 
+#ifdef MSPMV_TUNING
 int mspmv_set_record_polls(int32_t polls)
 {
     t_tune[0].record_polls = t_tune[1].record_polls = polls < 0 ? -1 : polls;
@@ -1122,6 +1148,7 @@ int mspmv_set_compact_tiles(int32_t max_tiles)
     t_tune[0].compact_tiles = t_tune[1].compact_tiles = max_tiles < 0 ? -1 : max_tiles;
     return hipSuccess;
 }
+#endif
 
 int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes)
 {

@@ -6,7 +6,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "../../include/mspmv.h"
+#if defined(MSPMV_DEV) && !defined(MSPMV_TUNING)
+#define MSPMV_TUNING 1      // the experiment build includes the tuning overrides
+#endif
+#include "../../include/mspmv_dev.h"      // (for the MSPMV_TUNE_* option bits the dispatcher is written in; the setters it declares are DEFINED in the -DMSPMV_TUNING build only)
 
 namespace mspmv {
 

@@ -92,12 +92,15 @@ struct Params {
 //     the tile's reduction, its answer looked at only when the sum is there: nothing waits for it -- and later stores the record
 //     with two plain atomic stores;
 //   * the one consumer every record has takes it (both tags match) and clears it;
-//   * NOTHING DEPENDS ON ANOTHER WORKGROUP BEING DISPATCHED.  Polling is bounded; a consumer whose poll runs out -- the awaited block
+//   * NOTHING DEPENDS ON ANOTHER WORKGROUP BEING DISPATCHED -- only on workgroups that HAVE STARTED running to their stores (a block that
+//     has announced itself and is then preempted for good or faults hangs its consumer, as it would hang any kernel).  Polling for a
+//     publisher that has not started is bounded; a consumer whose poll runs out -- the awaited block
 //     has not been dispatched: possible only when far fewer blocks are resident than mspmv_api.hip assumed (a CU-masked stream, a
 //     long kernel beside this one, several processes on the device) AND the resident ones are all waiting -- CANCELS the slot by an
 //     atomic exchange.  What comes back decides: the RECORD (it arrived between the last look and now) -> taken like any other;
-//     PENDING -> the publisher is RUNNING (it announced itself) and publishers never wait for anything, so the record comes in
-//     finite time whatever else the device does: the consumer goes on polling for it; anything else -> the publisher has not
+//     PENDING -> the publisher is RUNNING (it announced itself); a plain publisher waits for nothing, a group LEADER (below) only --
+//     bounded, or for plain publishers that have started -- for its 63 predecessors: a chain of depth two, no cycle, so the record
+//     comes in finite time whatever else the device does: the consumer goes on polling for it WITHOUT a bound; anything else -> the publisher has not
 //     started: the cancellation stays, the block computes the missing sum itself from the matrix (recompute_row_head), and the
 //     publisher, whose announcement brings the cancellation back, wipes the slot instead of publishing.
 // (Until round 5 a cancelled slot's late record stayed where it was and an EPOCH word, bumped by the recomputing consumer and mixed
@@ -107,7 +110,11 @@ struct Params {
 //  that EXCHANGES its record in and cleans up when it finds a cancellation was measured first: correct, but the answer of the
 //  exchange sits on the critical path of a tile that does nothing after publishing -- BASELINE config 4, 23 800 such tiles: +7.5 %.)
 // The reference's fp64 fix-up spins without bound on the same residency assumption (single_pass_scan_operators.cuh:620-639);
-// here a broken assumption costs time, never the result.
+// here a broken assumption costs time, never the result.  Every interleaving of these operations under relaxed ordering -- one
+// publisher and one consumer, and the publisher -> leader -> consumer chain, every poll budget, clean and stale slots -- is
+// enumerated by tests/test_record_protocol_model.py (payload or recompute; slot (0, 0) at the end; no wait that nothing ends;
+// the unbounded wait only for a publisher that has started).  What the invariant excludes: a slot that already holds THIS call's
+// marker when the launch starts (a launch killed between announce and store, then replayed with the same tags).
 // ---------------------------------------------------------------------------
 constexpr int REC_MAX_POLLS = 1 << 17;      // x ~1 us: ~0.1 s before a consumer gives up on a record and computes the sum itself
 // (markers carry the call's tag with its low bit CLEARED: never a valid record tag, tag_a | 1)
@@ -2035,9 +2042,12 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
 {
     constexpr int CPT = IPT / 4 + 1;
     constexpr int SLOTS = CPT * BLOCK * 4;
-    __shared__ int s_next;
+    __shared__ int s_next, s_first;
     const int tid = threadIdx.x;
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
+    // (the block's index is needed again at the head of every pass; kept in LDS, not in a register across the tile loop -- the
+    //  fp32 kernel sits at its 64-VGPR cap there, and what does not fit went to scratch memory: .vgpr_spill_count 1-2 until round 6)
+    if (tid == 0) s_first = blockIdx.x;
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
     const V beta0 = p.beta;
@@ -2047,7 +2057,7 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
         p.band_lo = b * ba.band_cols; p.band_len = ba.band_cols; p.band_pass = b;
         p.beta = b == 0 ? beta0 : (V) 1;
         __syncthreads();
-        if (tid == 0) s_next = blockIdx.x;     // every pass starts with the block's own first tile: no claim
+        if (tid == 0) s_next = s_first;        // every pass starts with the block's own first tile: no claim
         __syncthreads();
         for (;;) {
             // (s_next: written before the barrier that ended the previous tile, or the one above)
@@ -2067,9 +2077,7 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
             }
             // the thread index goes through an empty asm once per tile: what the tile body derives from it (LDS addresses,
             // lane offsets) is then recomputed per tile instead of being hoisted out of the loop and kept live across it,
-            // which costs ~40 registers per lane and with them a quarter of the resident waves.  (What is left spills 2-3
-            // registers per lane in the fp32 kernel; the variant that keeps them -- thread 0's claim state in LDS, the index
-            // laundered in place -- measured 3 % slower on C2, so the spill stays.)
+            // which costs ~40 registers per lane and with them a quarter of the resident waves.
             int t = tid;
             asm volatile("" : "+v"(t));
             __builtin_assume(t >= 0 && t < BLOCK);

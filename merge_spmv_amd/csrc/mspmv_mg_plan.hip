@@ -780,12 +780,16 @@ int mspmv_mg_plan_ipc_import(mspmv_mg_plan_t *plan, const void *blobs, int32_t c
     return 0;
 }
 
-// the Infinity Cache the automatic hot-column decision compares x with (MSPMV_FAKE_INFINITY_CACHE_MIB in the environment overrides it,
-// read once: tests, other parts)
+// the Infinity Cache the automatic hot-column decision compares x with (dev library only: MSPMV_FAKE_INFINITY_CACHE_MIB in the
+// environment overrides it, read once: tests)
 static long long infinity_cache_bytes()
 {
+#ifdef MSPMV_TUNING
     static const long long v = [] { const char *e = getenv("MSPMV_FAKE_INFINITY_CACHE_MIB"); const double m = e ? atof(e) : 0; return m > 0 ? (long long) (m * 1048576.0) : (256LL << 20); }();
     return v;
+#else
+    return 256LL << 20;
+#endif
 }
 
 // one part's hot-column plan: built (want) or dropped; the part's stream is synchronised on the way
@@ -830,9 +834,11 @@ int mspmv_mg_plan_hot_columns(mspmv_mg_plan_t *plan, int32_t enable)
     if (!plan) return kErrInvalid;
     int prev = 0; MG_HIP(hipGetDevice(&prev));
     int st = 0;
+    // the mode holds for every matrix attached from now on (mspmv_mg_plan_set_part applies it); parts that already have their
+    // matrix are brought to it here, parts still waiting for one are left alone
     plan->hot_mode = enable < 0 ? -1 : enable ? 1 : 0;
     for (Part &q : plan->local) {
-        if (!q.attached) { st = kErrInvalid; break; }
+        if (!q.attached) continue;
         st = enable < 0 ? part_hot_auto(plan, q) : part_hot(plan, q, enable != 0);
         if (st != 0) break;
     }

@@ -10,15 +10,12 @@
 //   gpu_spmv [--device=<id>] [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32]
 //            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor] [--no-hyb]
 //            [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] [--mg-exchange=peer|rccl]
-//            [--band-passes=<n>]
 //            --mtx=<file> | --dense=<cols> [--size=<nnz>] | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
 //
 // Extra method lines of this project (non-quiet only; the CSV keeps the reference's columns):
 //   --prepared   the stateless call with the tile coordinates found once (mspmv_csrmv_prepare)
 //   --plan       the prepared band-major plan (mspmv_csrmv_plan_*): set-up = the plan build
 //   --hotcols    the hot-column plan (mspmv_csrmv_hotcols_*): set-up = ranking the columns by reference count
-//   --band-passes=<n>  column-band passes of the stateless call (mspmv_set_band_passes): 0 automatic (default),
-//                -1 never, n >= 2 always n
 //   --gpus=G     the matrix merge-partitioned over G GPUs of this node through the C multi-GPU operator
 //                (mspmv_mg_plan_*; the reference has a single --device, utils.h:465-474), one line per G;
 //                --mg-one-device runs all parts on --device (a functional run on a 1-GPU box)
@@ -487,7 +484,7 @@ int main(int argc, char **argv)
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
                "[--no-strict] [--no-vendor] [--no-hyb] [--cache] [--prepared] [--plan[=<bands>]] [--hotcols] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
-               "[--mg-exchange=peer|rccl] [--band-passes=<n>] [--chunk-times=<calls per chunk>]\n"
+               "[--mg-exchange=peer|rccl] [--chunk-times=<calls per chunk>]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
         return 0;
@@ -501,14 +498,6 @@ int main(int argc, char **argv)
     ex.hotcols = args.CheckCmdLineFlag("hotcols");
     ex.plan = args.CheckCmdLineFlag("plan");
     args.GetCmdLineArgument("plan", ex.plan_bands);
-    if (args.CheckCmdLineFlag("band-passes")) {
-        int passes = 0;
-        args.GetCmdLineArgument("band-passes", passes);
-        if (mspmv_set_band_passes(4, passes) != 0 || mspmv_set_band_passes(8, passes) != 0) {
-            fprintf(stderr, "--band-passes=%d: 0 (automatic), negative (never) or 2..64\n", passes);
-            return 1;
-        }
-    }
     ex.mg_one_device = args.CheckCmdLineFlag("mg-one-device");
     args.GetCmdLineArgument("chunk-times", g_chunk);
     std::string gpus, exchange;

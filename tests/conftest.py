@@ -34,3 +34,23 @@ def golden_host():
 @pytest.fixture(scope="session")
 def golden_kat():
     return load_golden("kat_device_spmv.json")
+
+
+@pytest.fixture(autouse=True)
+def _product_library_by_default():
+    """Every test starts and ends on the PRODUCT library (libmspmv.so).  A test that forces a code path calls one of the setters of
+    include/mspmv_dev.h, which switches merge_spmv_amd to libmspmv_dev.so (same kernels + the per-thread overrides); whatever it
+    left there is reset here."""
+    yield
+    M = sys.modules.get("merge_spmv_amd")
+    if M is None or not hasattr(M, "active_library"):
+        return
+    if M.active_library() != "product" or "dev" in M._libs:
+        try:
+            M.use_library("dev")
+            for vb in (4, 8):
+                M.set_tuning(vb); M.set_band_passes(vb, 0)
+            M.set_record_polls(0); M.set_compact_tiles(0)
+        except Exception:  # noqa: BLE001 - (no development library in this checkout: nothing to reset)
+            pass
+        M.use_library("product")

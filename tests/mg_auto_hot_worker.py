@@ -11,6 +11,7 @@ import merge_spmv_amd as M
 from merge_spmv_amd import multi_gpu as MG, generators as G
 
 assert os.environ.get("MSPMV_FAKE_INFINITY_CACHE_MIB") == "1"
+M.use_library("dev")           # (the environment override exists in the development library only)
 lib = M.load_library()
 dev = torch.device("cuda", 0)
 parts = 3

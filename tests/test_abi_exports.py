@@ -13,10 +13,17 @@ import merge_spmv_amd as M
 from oracle import oracle as O
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mspmv.h")).read()
+def declared_symbols(header="mspmv.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef MSPMV_DEV\n.*?#endif\n", "", text, flags=re.S)          # (the -DMSPMV_DEV experiment build's one extra entry point)
     return sorted(set(re.findall(r"\b(mspmv_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if " T mspmv_" in l)
 
 
 def test_library_exports_every_declared_symbol():
@@ -25,12 +32,46 @@ def test_library_exports_every_declared_symbol():
     assert "mspmv_csrmv_f32" in names and "mspmv_csrmv_f64" in names and len(names) >= 10
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mspmv_version() == 100
+    assert lib.mspmv_version() == 101
+    # ... and nothing else: what is exported is what include/mspmv.h declares
+    assert exported(M.library_path("product")) == names
+
+
+def test_the_product_library_has_no_setters_and_reads_no_environment():
+    """the forcing / re-tuning state lives in libmspmv_dev.so (include/mspmv_dev.h) only.  The product exports no
+    mspmv_set_* symbol, does not import getenv, and holds no MSPMV_* variable name; the development library exports exactly the
+    product's symbols plus the four setters."""
+    import subprocess
+    prod, dev = M.library_path("product"), M.library_path("dev")
+    names = exported(prod)
+    assert not [n for n in names if n.startswith("mspmv_set_") or n.startswith("mspmv_dev_")]
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", prod], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", dev], capture_output=True, text=True, check=True).stdout
+    strings = subprocess.run(["strings", prod], capture_output=True, text=True, check=True).stdout
+    assert not re.findall(r"^MSPMV_[A-Z0-9_]+$", strings, flags=re.M)
+    setters = ["mspmv_set_band_passes", "mspmv_set_compact_tiles", "mspmv_set_record_polls", "mspmv_set_tuning"]
+    assert exported(dev) == sorted(names + setters)
+    assert sorted(set(declared_symbols("mspmv_dev.h")) - set(names)) == setters
+
+
+def test_setters_switch_to_the_development_library_and_defaults_do_not():
+    assert M.active_library() == "product"
+    M.set_tuning(4); M.set_band_passes(8, 0); M.set_record_polls(0); M.set_compact_tiles(0)        # defaults: no-ops on the product
+    assert M.active_library() == "product"
+    M.set_tuning(4, 256, 11)
+    assert M.active_library() == "dev" and M.launch_info(10, 10, 4)["items_per_thread"] == 11
+    M.set_tuning(4)
+    assert M.use_library("product") == "dev"
+    assert M.launch_info(10, 10, 4)["items_per_thread"] == 7
+    with pytest.raises(ValueError):
+        M.use_library("nope")
 
 
 def test_missing_library_fails_loudly(monkeypatch):
-    monkeypatch.setattr(M, "_lib", None)
-    monkeypatch.setattr(M, "_LIB_NAME", "libmspmv_does_not_exist.so")
+    monkeypatch.setattr(M, "_libs", {})
+    monkeypatch.setattr(M, "_LIB_NAMES", {"product": "libmspmv_does_not_exist.so", "dev": "libmspmv_dev.so"})
+    monkeypatch.delenv("MSPMV_LIB", raising=False)
     with pytest.raises(M.MspmvError):
         M.load_library()
 
@@ -67,6 +108,7 @@ def test_size_query_two_phase_convention():
 
 
 def test_tuning_rejects_unknown_shapes():
+    """(the development library: the setters switch to it)"""
     M.set_tuning(4, 256, 11)
     assert M.launch_info(10, 10, 4)["items_per_thread"] == 11
     M.set_tuning(4)
@@ -116,6 +158,8 @@ def test_tuning_rejects_unknown_shapes():
         with pytest.raises(M.MspmvError):
             M.set_tuning(8, 256, 11, dev_bits | 16)
     assert not hasattr(M.load_library(), "mspmv_dev_set_trace")
+    assert M.launch_info(10, 10, 4)["flags"] == 0
+    M.use_library("product")
     assert M.launch_info(10, 10, 4)["flags"] == 0
 
 

@@ -19,6 +19,8 @@ NO_FUSED = 16
 
 
 def test_set_band_passes_argument_checks():
+    """(a setter of the development library, include/mspmv_dev.h)"""
+    M.use_library("dev")
     lib = M.load_library()
     for vb in (4, 8):
         for ok in (0, -1, -7, 2, 3, 64):
@@ -32,8 +34,7 @@ def test_set_band_passes_argument_checks():
 
 def test_automatic_policy_table():
     """what the host can decide from sizes alone (csrc/mspmv_api.hip: band_passes_for)"""
-    for vb in (4, 8):
-        assert M.load_library().mspmv_set_band_passes(vb, 0) == 0
+    assert M.active_library() == "product"
     C2 = (3_125_000, 3_125_000, 100_000_000)
     assert M.band_passes(*C2, 4) == 3 and M.band_passes(*C2, 8) == 4           # 11.9 / 23.8 MiB of x
     mib = lambda m, vb: m * 2**20 // vb
@@ -65,6 +66,7 @@ def test_policy_follows_the_l2_it_is_told_about():
     fewer, larger L2s shifts the other way."""
     import subprocess, sys, json
     code = ("import json, merge_spmv_amd as M\n"
+            "M.use_library('dev')      # (the environment overrides exist in the development library only)\n"
             "C2 = (3_125_000, 3_125_000, 100_000_000)\n"
             "mib = lambda m, vb: m * 2**20 // vb\n"
             "print(json.dumps({'caches': M.device_caches(), 'c2': [M.band_passes(*C2, 4), M.band_passes(*C2, 8)],\n"

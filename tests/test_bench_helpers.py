@@ -74,3 +74,67 @@ def test_sampled_check_passes_a_right_result_and_catches_wrong_ones():
         y2 = y.copy(); y2[row] = y2[row] + bad if bad == bad else bad
         res = M.sampled_check(A, torch.from_numpy(x), torch.from_numpy(y2), depth=12)
         assert res["violations"] >= 1, (row, res)
+
+
+def _fake_detail(n_configs=9, long=False):
+    pad = "x" * (700 if long else 20)
+    roof = {"kernel": "tile_kernel_vec<BAND>", "achieved": 1004.123, "bound": "hbm", "peak": 8000.0, "unit": "GB/s", "frac": 0.1255, "traffic": 4048229006,
+            "traffic_over_algorithmic": 4.834, "traffic_src": "replayed:profiles/r05_c2_f32/pmc_latest.json", "algorithmic_bytes_per_launch": 837500004,
+            "kernel_ms": 0.83412, "search_ms": 0.0102, "fixup_ms": 0.0067, "launches_timed": 200, "band_passes": 3, "note": pad}
+    cfgs = [{"config": f"config number {i} with a long name {pad}", "label": "c", "workload": pad * 3, "data": "synthetic", "dtype": "f64", "rows": 1 << 24, "cols": 1 << 24,
+             "nnz": 234366905, "steps": 50, "ms_per_step": 1.40935, "value": 332.6, "unit": "GFLOP/s", "tile": "256x11", "generation_s": 0.3,
+             "roofline": dict(roof, bound="ic" if i % 2 else "hbm", frac_hbm=0.4), "effective_GBs": 2865.2, "effective_pct_of_peak": 35.82,
+             "sampled_check": {"rows_checked": 65539, "worst_ratio": 0.0601, "violations": 0, "longest_row": 123, "depth_term": 12}, "y_finite": True,
+             "cpu": {"value": 93.1, "cores": 16, "runs": [pad] * 3}, "vendor": {"ms_per_step": 2.2, "note": pad}} for i in range(n_configs)]
+    cfgs.append({"config": "one that failed", "error": "OutOfMemoryError: " + pad * 5})
+    return {"metric": "CsrMV GFLOP/s", "value": 239.712, "unit": "GFLOP/s", "n_gpus": 1, "steps": 200, "warmup": 20, "ms_per_step": 0.83434, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 uniform CSR: 3125000 x 3125000, 32 nnz/row, 100000000 nnz " + pad, "tile": "256x11", "partition": "single GPU"},
+            "effective_GBs_reference_formula": 1468.2, "effective_pct_of_peak": 18.35, "roofline": roof, "sampled_worst_ratio": 0.0293,
+            "sampled_check": {"rows_checked": 65539, "worst_ratio": 0.0293, "what": pad * 4},
+            "cpu_baseline": {"value": 24.3, "unit": "GFLOP/s", "cores": 16, "kind": "port", "ms": 8.22, "sample": "same C2 matrix: 12 SpMVs after 4 warm-ups",
+                             "kernel": "host/merge_csrmv.hpp (OpenMP merge-path)", "runs": [{"variant": pad}] * 3, "cpu_quota": "16 CPUs"},
+            "prepared_plan": {"ms_per_step": 0.505, "value": 395.8, "setup_ms": 5.7, "roofline": {"frac": 0.21, "note": pad}, "api": pad},
+            "vendor": {"ms_per_step": 1.241, "analysis_ms": 12.2, "library": pad}, "configs": cfgs,
+            "per_rank": {"tile_ms_max": 4.1, "tile_ms_min": 3.9, "note": pad * 2}, "exchange": {"exchange": 1, "backend": "rccl all-gather", "carry_bytes_per_step": 64, "fallbacks": []},
+            "single_gpu_same_workload": {"n_gpus": 1, "steps": 5, "ms_per_step": 33.0, "value": 121.3}}
+
+
+@pytest.mark.parametrize("n_configs,long", [(0, False), (8, False), (9, True), (40, True)])
+def test_the_final_line_is_short_strict_json_with_the_contract_keys(n_configs, long):
+    """bench.compact_line: one line, strictly JSON (no NaN / Infinity tokens), under 4 KB whatever the detail record holds -- the driver's
+    parser gave up on the 27 KB line of round 5 (BENCH_r05.json: parsed null) --, carrying the contract's keys, `roofline` and `cpu_baseline`."""
+    import json
+    detail = bench._finite(_fake_detail(n_configs, long))
+    line = bench.compact_line(detail, "gpurun_out/bench_detail.json")
+    assert "\n" not in line and len(line.encode()) < bench.LINE_LIMIT == 4096
+    d = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["workload"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    if n_configs == 8:
+        assert len(d["configs"]) == 9 and all(set(c) >= {"config", "dtype", "ms_per_step", "value", "frac", "traffic_over_algorithmic", "worst"} or "error" in c for c in d["configs"])
+        assert d["detail"] == "gpurun_out/bench_detail.json"
+
+
+def test_nan_and_inf_never_reach_the_line():
+    import json
+    d = _fake_detail(2)
+    d["per_rank"]["exchange_ms_max"] = float("nan"); d["roofline"]["frac_hbm"] = float("inf"); d["configs"][0]["sampled_check"]["worst_ratio"] = float("nan")
+    line = bench.compact_line(bench._finite(d))
+    assert "NaN" not in line and "Infinity" not in line
+    json.loads(line)
+
+
+def test_replayed_traffic_finds_the_committed_counter_passes():
+    """roofline.traffic of the default run is replayed from profiles/*/pmc_latest.json (live with --full): the headline's and every config's label
+    must resolve to a committed pass of the same workload and precision."""
+    for label, dt in (("c2_f32", "f32"), ("c2", "f64"), ("dense5", "f64"), ("circuit", "f64"), ("c3_web", "f64"), ("c3_orkut", "f64"), ("c4", "f32"), ("dense32", "f32"), ("c5", "f64")):
+        tr, src = bench.replayed_traffic(label, dt)
+        assert tr and tr > 0 and src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), (label, dt)

@@ -14,7 +14,7 @@ for w in widths:
     A = G.grid2d_csr(w, tdt)
     x = torch.ones(A.cols, dtype=tdt, device="cuda"); y = torch.empty(A.rows, dtype=tdt, device="cuda")
     line = f"grid2d_{w} {'fp32' if f32 else 'fp64'} ({A.nnz} nnz):"
-    dev = "dev" in os.environ.get("MSPMV_LIB", "")        # MSPMV_LIB=merge_spmv_amd/libmspmv_dev.so: every sweep shape
+    dev = "exp" in os.environ.get("MSPMV_LIB", "")        # MSPMV_LIB=merge_spmv_amd/libmspmv_exp.so: every sweep shape
     for shape in [(0, 0)] + (([(256, 7), (256, 9), (256, 11), (256, 15)] if f32 else [(256, 5), (256, 7), (256, 9), (256, 11)]) if dev else [(256, 7), (256, 11)]):
         M.set_tuning(vb, shape[0], shape[1], 0)
         info = M.launch_info(A.rows, A.nnz, vb)

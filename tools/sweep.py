@@ -11,7 +11,7 @@ import merge_spmv_amd as M
 from merge_spmv_amd import generators as G
 
 SHAPES = {4: [(256, 7), (256, 11)], 8: [(256, 7), (256, 11)]}       # product shapes
-if "dev" in os.environ.get("MSPMV_LIB", ""):                         # the dev build (MSPMV_LIB=.../libmspmv_dev.so) has the sweep shapes
+if "exp" in os.environ.get("MSPMV_LIB", ""):                         # the dev build (MSPMV_LIB=.../libmspmv_exp.so) has the sweep shapes
     SHAPES = {4: [(256, 7), (256, 11), (256, 9), (256, 15), (256, 5), (128, 7), (512, 7)], 8: [(256, 7), (256, 11), (256, 5), (256, 9), (256, 3), (128, 5), (512, 5)]}
 
 

@@ -2,7 +2,7 @@
 """tools/trace_snap.py [workload ...] -- development: where a block of the one-launch kernel (tile_kernel_snap) spends its life.
 The -DMSPMV_DEV build stamps the 100 MHz wall clock at the block's phase boundaries (thread 0) and its hardware ids; this prints
 the phase averages in microseconds, the blocks alive per CU over the launch, and the launch's span.
-    make -C merge_spmv_amd dev && MSPMV_LIB=merge_spmv_amd/libmspmv_dev.so python tools/trace_snap.py dense5d grid3d"""
+    make -C merge_spmv_amd exp && MSPMV_LIB=merge_spmv_amd/libmspmv_exp.so python tools/trace_snap.py dense5d grid3d"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

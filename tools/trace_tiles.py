@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/trace_tiles.py [workload] -- development: per-phase cycle stamps inside tile_kernel_vec
 (the ABLATE=6 build of the kernel writes clock64() at phase boundaries for the first 16 tiles of each block).
-Needs the development library: make -C merge_spmv_amd dev && MSPMV_LIB=merge_spmv_amd/libmspmv_dev.so python tools/trace_tiles.py"""
+Needs the development library: make -C merge_spmv_amd exp && MSPMV_LIB=merge_spmv_amd/libmspmv_exp.so python tools/trace_tiles.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
