@@ -775,7 +775,8 @@ def main():
                 ref = wy[:y0.numel()]
                 neq = (ref != y0).nonzero()
                 part_info = M.launch_info(local_rows, local_nnz, vb)
-                same = (part_info["items_per_thread"] == M.launch_info(W.rows, W.nnz, vb)["items_per_thread"]
+                whole_info = M.launch_info(W.rows, W.nnz, vb)
+                same = (part_info["items_per_thread"] == whole_info["items_per_thread"] and part_info["snap_head_max"] == whole_info["snap_head_max"]
                         and M.band_passes(W.rows, W.cols, W.nnz, vb) <= 1 and M.band_passes(local_rows, cols, local_nnz, vb) <= 1)
                 single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": int(neq.numel()),
                                                       "first_differing_row": int(neq[0].item()) if neq.numel() else None,

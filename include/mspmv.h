@@ -214,6 +214,23 @@ int mspmv_csrmv_hotcols_apply_f64(void *d_plan, size_t plan_bytes, const double 
                                   const int32_t *d_row_offsets, const double *d_x, double *d_y,
                                   int32_t rows, int32_t cols, int32_t nnz, double alpha, double beta,
                                   mspmv_stream_t stream, int debug_sync);
+/* A caller that keeps x in the plan's numbering -- a fixed right-hand side, or a method whose vector updates are element-wise and can
+ * live in that numbering -- pays the permutation once instead of per SpMV (config 5 on one GPU: 0.7 of 21 ms):
+ * mspmv_csrmv_hotcols_permute_* writes d_x_permuted[k] = d_x[order[k]] (cols entries; not in place), and
+ * mspmv_csrmv_hotcols_apply_permuted_* is mspmv_csrmv_hotcols_apply_* on such a vector, without the pass.  y comes out in the ORIGINAL
+ * row order, bit for bit what _apply_* returns for the unpermuted x. */
+int mspmv_csrmv_hotcols_permute_f32(const void *d_plan, size_t plan_bytes, const float *d_x, float *d_x_permuted,
+                                    int32_t rows, int32_t cols, int32_t nnz, mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_hotcols_permute_f64(const void *d_plan, size_t plan_bytes, const double *d_x, double *d_x_permuted,
+                                    int32_t rows, int32_t cols, int32_t nnz, mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_hotcols_apply_permuted_f32(void *d_plan, size_t plan_bytes, const float *d_values,
+                                           const int32_t *d_row_offsets, const float *d_x_permuted, float *d_y,
+                                           int32_t rows, int32_t cols, int32_t nnz, float alpha, float beta,
+                                           mspmv_stream_t stream, int debug_sync);
+int mspmv_csrmv_hotcols_apply_permuted_f64(void *d_plan, size_t plan_bytes, const double *d_values,
+                                           const int32_t *d_row_offsets, const double *d_x_permuted, double *d_y,
+                                           int32_t rows, int32_t cols, int32_t nnz, double alpha, double beta,
+                                           mspmv_stream_t stream, int debug_sync);
 /* the plan's pieces (device pointers into d_plan): order[k] = the original column that became column k (cols entries),
  * and the renumbered column indices (nnz entries) */
 const int32_t *mspmv_csrmv_hotcols_order(const void *d_plan, int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes);

@@ -155,9 +155,13 @@ def load_library() -> ctypes.CDLL:
     lib.mspmv_csrmv_hotcols_build.restype = ctypes.c_int
     lib.mspmv_csrmv_hotcols_build.argtypes = [vp, ctypes.c_size_t, vp, vp, i32, i32, i32, i32, vp, ctypes.c_int]
     for name, ct in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
-        fn = getattr(lib, "mspmv_csrmv_hotcols_apply_" + name)
+        for stem in ("mspmv_csrmv_hotcols_apply_", "mspmv_csrmv_hotcols_apply_permuted_"):
+            fn = getattr(lib, stem + name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, i32, i32, i32, ct, ct, vp, ctypes.c_int]
+        fn = getattr(lib, "mspmv_csrmv_hotcols_permute_" + name)
         fn.restype = ctypes.c_int
-        fn.argtypes = [vp, ctypes.c_size_t, vp, vp, vp, vp, i32, i32, i32, ct, ct, vp, ctypes.c_int]
+        fn.argtypes = [vp, ctypes.c_size_t, vp, vp, i32, i32, i32, vp, ctypes.c_int]
     for name in ("mspmv_csrmv_hotcols_order", "mspmv_csrmv_hotcols_columns"):
         getattr(lib, name).restype = vp
         getattr(lib, name).argtypes = [vp, i32, i32, i32, i32]
@@ -503,7 +507,21 @@ class CsrMVHotColumns:
         """the renumbered column indices"""
         return self._view(load_library().mspmv_csrmv_hotcols_columns, self.nnz)
 
-    def __call__(self, x, y=None, alpha: float = 1.0, beta: float = 0.0, stream=None, debug_synchronous: bool = False):
+    def permute(self, x, out=None, stream=None):
+        """x in the plan's numbering (mspmv_csrmv_hotcols_permute_*): out[k] = x[order[k]]; pass the result to __call__(..., x_is_permuted=True)"""
+        import torch
+        if out is None:
+            out = torch.empty(max(self.cols, 1), dtype=self.dtype, device=self.storage.device)[:self.cols]
+        if x.dtype != self.dtype or out.dtype != self.dtype or not x.is_contiguous() or not out.is_contiguous() or x.numel() < self.cols or out.numel() < self.cols \
+                or x.data_ptr() == out.data_ptr():
+            raise MspmvError("CsrMVHotColumns.permute: x / out must be distinct contiguous tensors of the plan's dtype with at least cols entries")
+        lib = load_library()
+        fn = lib.mspmv_csrmv_hotcols_permute_f32 if self.vb == 4 else lib.mspmv_csrmv_hotcols_permute_f64
+        _check(fn(ctypes.c_void_p(self.storage.data_ptr()), self.bytes, _ptr(x), _ptr(out), self.rows, self.cols, self.nnz, _stream_handle(stream), 0),
+               "mspmv_csrmv_hotcols_permute")
+        return out
+
+    def __call__(self, x, y=None, alpha: float = 1.0, beta: float = 0.0, stream=None, debug_synchronous: bool = False, x_is_permuted: bool = False):
         import torch
         if y is None:
             y = torch.empty(self.rows, dtype=self.dtype, device=self.storage.device)
@@ -511,7 +529,11 @@ class CsrMVHotColumns:
                 or not x.is_contiguous() or not y.is_contiguous() or x.dim() != 1 or y.dim() != 1 \
                 or x.numel() < self.cols or y.numel() < self.rows:
             raise MspmvError("CsrMVHotColumns: x / y must be contiguous 1-D tensors of the plan's dtype on its device, with at least cols / rows entries")
-        fn = load_library().mspmv_csrmv_hotcols_apply_f32 if self.vb == 4 else load_library().mspmv_csrmv_hotcols_apply_f64
+        lib = load_library()
+        if x_is_permuted:
+            fn = lib.mspmv_csrmv_hotcols_apply_permuted_f32 if self.vb == 4 else lib.mspmv_csrmv_hotcols_apply_permuted_f64
+        else:
+            fn = lib.mspmv_csrmv_hotcols_apply_f32 if self.vb == 4 else lib.mspmv_csrmv_hotcols_apply_f64
         _check(fn(ctypes.c_void_p(self.storage.data_ptr()), self.bytes, _ptr(self.values), _ptr(self.row_offsets), _ptr(x), _ptr(y), self.rows, self.cols,
                   self.nnz, float(alpha), float(beta), _stream_handle(stream), int(bool(debug_synchronous))), "mspmv_csrmv_hotcols_apply")
         return y
@@ -534,7 +556,19 @@ def hotcols_bench_record(A, x, y_stateless, steps: int = 5, warmup: int = 2, pea
     ms = (time.perf_counter() - t0) * 1e3 / steps
     vb = A.values.element_size()
     b_alg = A.nnz * (vb + 4) + (A.rows + 1) * 4 + A.rows * vb + A.cols * vb
-    return {"api": "mspmv_csrmv_hotcols_build once, then mspmv_csrmv_hotcols_apply_* per SpMV (opt-in; not the drop-in call)",
+    xp = plan.permute(x)
+    yp = torch.empty_like(y_stateless)
+    for _ in range(max(warmup, 1)):
+        plan(xp, yp, x_is_permuted=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        plan(xp, yp, x_is_permuted=True)
+    torch.cuda.synchronize()
+    ms_p = (time.perf_counter() - t0) * 1e3 / steps
+    permuted = {"api": "mspmv_csrmv_hotcols_permute_* once, mspmv_csrmv_hotcols_apply_permuted_* per SpMV (the caller keeps x in the plan's numbering)",
+                "ms_per_step": round(ms_p, 5), "value": round(2.0 * A.nnz / (ms_p * 1e-3) / 1e9, 3), "frac": round(b_alg / (ms_p * 1e-3) / 1e9 / peak_gbs, 4),
+                "bitwise_equal_to_apply": bool(torch.equal(yp, y))}
+    return {"api": "mspmv_csrmv_hotcols_build once, then mspmv_csrmv_hotcols_apply_* per SpMV (opt-in; not the drop-in call)", "x_kept_permuted": permuted,
             "what": "columns renumbered by reference count (hot columns contiguous); x permuted once per SpMV, inside the timed call",
             "setup_ms": round(setup_ms, 3), "storage_bytes": plan.bytes, "ms_per_step": round(ms, 5),
             "value": round(2.0 * A.nnz / (ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s",

@@ -141,6 +141,24 @@ struct Layout {
                            // passes on offer); the regions of the classic pipeline are laid out all the same
 };
 
+// LARGE MATRICES WHOSE ROWS ARE ALL LONG (an average of 240 nonzeros or more: longer than the 192 a tile boundary can snap back over)
+// run the classic three launches: with most tile ends inside a row nearly every tile publishes a record and nearly every tile
+// takes one, and a record costs its consumer a round trip through the memory side (the records are agent-scope atomics: they pass
+// the XCDs' L2s) at the END of the tile's life -- +3...4 us on a block that lives 8-10 us, where a carry per tile and one fix-up
+// launch cost 15 us per CALL.  Measured (round 6, tools/long_rows_probe.py, profiles/r06_long_rows_probe.txt; one launch | classic,
+// us per SpMV): rows of 512 over a tiny x, 100 M nonzeros, fp64 312 | 209 (rocSPARSE 218), fp32 208 | 129 (172); 30 M: 95 | 67 (69),
+// 59 | 42 (48); rows of 2048, 50 M: 186 | 116, 141 | 81.  Crossovers: rows of 384+ from ~8 M path items, rows of 240-384 from ~16 M
+// (fp32 rows of 256 at 20 M: 39.1 | 38.4); rows of <= 224 and anything smaller stay with the one launch (rows of 200, 50 M: 178 | 180).
+// Judged on what the host knows -- rows and nonzeros -- so a matrix with a FEW long rows among short ones (R-MAT hubs, BASELINE
+// config 4's giant row: average 4) keeps the one launch and its records.  Same rule for stateless, prepared and plan-internal calls
+// (it is a function of the sizes), so whatever is bitwise equal between them stays so.
+static bool long_rows_rule(int rows, int nnz)
+{
+    const long long items = (long long) rows + nnz;
+    if (rows <= 0) return false;
+    return ((long long) nnz >= 384LL * rows && items >= 8000000LL) || ((long long) nnz >= 240LL * rows && items >= 16000000LL);
+}
+
 static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune, bool small_shape = false)
 {
     Layout L; memset(&L, 0, sizeof(L));
@@ -156,7 +174,7 @@ static Layout make_layout(int rows, int nnz, int value_bytes, const Tune &tune, 
     // ONE launch (tile_kernel_snap) unless the tuning asks for a piece of the classic pipeline (coordinate pass, tile_kernel_vec or the
     // dword-per-lane tile_kernel, fix-up)
     constexpr int classic = MSPMV_TUNE_TWO_LAUNCH | MSPMV_TUNE_ATOMIC_FIX | MSPMV_TUNE_MULTILEVEL_FIX;
-    L.snap = L.num_tiles >= 1 && !(L.flags & (classic | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | DEV_FLAG_MASK));
+    L.snap = L.num_tiles >= 1 && !(L.flags & (classic | MSPMV_TUNE_NO_VEC | MSPMV_TUNE_BINARY_SEARCH | DEV_FLAG_MASK)) && !long_rows_rule(rows, nnz);
     // published carries of rows longer than the snap limit (16 bytes per tile)
     // (one record per tile + one per group of LB_GROUP tiles: kernels, "GROUP RECORDS")
     L.pub_off = off; off = align256(off + (uint64_t(L.num_tiles > 0 ? L.num_tiles : 1) + uint64_t(L.num_tiles) / LB_GROUP + 1) * 16);

@@ -184,9 +184,24 @@ int hot_build(void *d_plan, size_t plan_bytes, const int32_t *d_row_offsets, con
     return csrmv_call<double>(base + L.temp_off, &tb, nullptr, d_row_offsets, nullptr, nullptr, nullptr, rows, 0, nnz, 1.0, 0.0, false, stream, debug_sync, ex);
 }
 
+// x -> the plan's numbering: out[k] = x[order[k]] (what hot_apply does per SpMV into the plan's own buffer; exported for callers that keep
+// x in the plan's numbering themselves: mspmv_csrmv_hotcols_permute_* / _apply_permuted_*)
+template <typename V>
+int hot_permute(const void *d_plan, size_t plan_bytes, const V *d_x, V *d_out, int32_t rows, int32_t cols, int32_t nnz, hipStream_t stream, int debug_sync)
+{
+    if (!d_plan || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
+    HotLayout L;
+    if (!make_layout(rows, cols, nnz, (int) sizeof(V), L) || plan_bytes < L.total || (reinterpret_cast<uintptr_t>(d_plan) & 15)) return hipErrorInvalidValue;
+    if (cols == 0) return hipSuccess;
+    if (!d_x || !d_out || d_x == d_out) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned) ((cols + HC_BLOCK - 1) / HC_BLOCK);
+    hipLaunchKernelGGL((hot_permute_x_kernel<V>), dim3(grid), dim3(HC_BLOCK), 0, stream, d_x, reinterpret_cast<const int *>(static_cast<const char *>(d_plan) + L.order_off), d_out, cols);
+    return launched(stream, debug_sync, "hot_permute_x_kernel", grid);
+}
+
 template <typename V>
 int hot_apply(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t *d_row_offsets, const V *d_x, V *d_y, int32_t rows, int32_t cols,
-              int32_t nnz, V alpha, V beta, hipStream_t stream, int debug_sync)
+              int32_t nnz, V alpha, V beta, hipStream_t stream, int debug_sync, bool x_is_permuted = false)
 {
     if (!d_plan || rows < 0 || cols < 0 || nnz < 0) return hipErrorInvalidValue;
     HotLayout L;
@@ -194,10 +209,10 @@ int hot_apply(void *d_plan, size_t plan_bytes, const V *d_values, const int32_t 
     if (rows == 0) return hipSuccess;
     if (!d_y || !d_row_offsets || (nnz > 0 && (!d_x || !d_values))) return hipErrorInvalidValue;
     char *base = static_cast<char *>(d_plan);
-    V *xp = reinterpret_cast<V *>(base + L.xp_off);
-    if (cols > 0 && nnz > 0) {
+    const V *xp = x_is_permuted ? d_x : reinterpret_cast<const V *>(base + L.xp_off);
+    if (cols > 0 && nnz > 0 && !x_is_permuted) {
         const unsigned grid = (unsigned) ((cols + HC_BLOCK - 1) / HC_BLOCK);
-        hipLaunchKernelGGL((hot_permute_x_kernel<V>), dim3(grid), dim3(HC_BLOCK), 0, stream, d_x, reinterpret_cast<const int *>(base + L.order_off), xp, cols);
+        hipLaunchKernelGGL((hot_permute_x_kernel<V>), dim3(grid), dim3(HC_BLOCK), 0, stream, d_x, reinterpret_cast<const int *>(base + L.order_off), reinterpret_cast<V *>(base + L.xp_off), cols);
         if (int e = launched(stream, debug_sync, "hot_permute_x_kernel", grid)) return e;
     }
     CallExtra ex; ex.phase = PHASE_ALL;            // (hints from the build; verified by the tiles as always)
@@ -277,6 +292,28 @@ int mspmv_csrmv_hotcols_apply_f64(void *d_plan, size_t plan_bytes, const double 
                                   int32_t rows, int32_t cols, int32_t nnz, double alpha, double beta, mspmv_stream_t stream, int debug_sync)
 {
     return hot_apply<double>(d_plan, plan_bytes, d_values, d_row_offsets, d_x, d_y, rows, cols, nnz, alpha, beta, reinterpret_cast<hipStream_t>(stream), debug_sync);
+}
+
+/* x kept in the plan's numbering by the caller: permute once (d_x_permuted[k] = d_x[order[k]]), then SpMVs without the per-call pass */
+int mspmv_csrmv_hotcols_permute_f32(const void *d_plan, size_t plan_bytes, const float *d_x, float *d_x_permuted, int32_t rows, int32_t cols, int32_t nnz,
+                                    mspmv_stream_t stream, int debug_sync)
+{
+    return hot_permute<float>(d_plan, plan_bytes, d_x, d_x_permuted, rows, cols, nnz, reinterpret_cast<hipStream_t>(stream), debug_sync);
+}
+int mspmv_csrmv_hotcols_permute_f64(const void *d_plan, size_t plan_bytes, const double *d_x, double *d_x_permuted, int32_t rows, int32_t cols, int32_t nnz,
+                                    mspmv_stream_t stream, int debug_sync)
+{
+    return hot_permute<double>(d_plan, plan_bytes, d_x, d_x_permuted, rows, cols, nnz, reinterpret_cast<hipStream_t>(stream), debug_sync);
+}
+int mspmv_csrmv_hotcols_apply_permuted_f32(void *d_plan, size_t plan_bytes, const float *d_values, const int32_t *d_row_offsets, const float *d_x_permuted,
+                                           float *d_y, int32_t rows, int32_t cols, int32_t nnz, float alpha, float beta, mspmv_stream_t stream, int debug_sync)
+{
+    return hot_apply<float>(d_plan, plan_bytes, d_values, d_row_offsets, d_x_permuted, d_y, rows, cols, nnz, alpha, beta, reinterpret_cast<hipStream_t>(stream), debug_sync, true);
+}
+int mspmv_csrmv_hotcols_apply_permuted_f64(void *d_plan, size_t plan_bytes, const double *d_values, const int32_t *d_row_offsets, const double *d_x_permuted,
+                                           double *d_y, int32_t rows, int32_t cols, int32_t nnz, double alpha, double beta, mspmv_stream_t stream, int debug_sync)
+{
+    return hot_apply<double>(d_plan, plan_bytes, d_values, d_row_offsets, d_x_permuted, d_y, rows, cols, nnz, alpha, beta, reinterpret_cast<hipStream_t>(stream), debug_sync, true);
 }
 
 /* the plan's pieces, for callers that keep x in the plan's numbering themselves (an iterative method on a symmetric permutation)

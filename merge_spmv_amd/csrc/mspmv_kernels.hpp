@@ -2047,18 +2047,18 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
     if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
     // (the block's index is needed again at the head of every pass; kept in LDS, not in a register across the tile loop -- the
     //  fp32 kernel sits at its 64-VGPR cap there, and what does not fit went to scratch memory: .vgpr_spill_count 1-2 until round 6)
-    if (tid == 0) s_first = blockIdx.x;
+    __shared__ V s_beta0;
+    if (tid == 0) { s_first = blockIdx.x; s_beta0 = p.beta; }
     const int last_full_nz = (p.nnz & ~3) - 4;
     const int last_full_ro = ((p.rows + 1) & ~3) - 4;
-    const V beta0 = p.beta;
     const int first_n = ba.grid / 8;           // sequence positions the blocks' first tiles used up (grid: a multiple of 8, or < 8 = all the tiles)
     int seq = (int) blockIdx.x & 7;            // thread 0: the sequence it claims from (moves on when one is exhausted)
     for (int b = 0; b < ba.bands; ++b) {
         p.band_lo = b * ba.band_cols; p.band_len = ba.band_cols; p.band_pass = b;
-        p.beta = b == 0 ? beta0 : (V) 1;
         __syncthreads();
         if (tid == 0) s_next = s_first;        // every pass starts with the block's own first tile: no claim
         __syncthreads();
+        p.beta = b == 0 ? s_beta0 : (V) 1;
         for (;;) {
             // (s_next: written before the barrier that ended the previous tile, or the one above)
             const int tile = s_next;

@@ -30,6 +30,7 @@ struct RunConfig {
     double peak_gbs = -1;                  // --peak-gbs: overrides the bus-width formula of utils.h:491
     bool cache = false;                    // --cache: keep / reuse <mtx>.<fp32|fp64>.csrbin next to a Matrix Market file
     bool timing = false;                   // --timing: print the wall-clock seconds of the ingest phases (non-quiet)
+    bool check = false;                    // --check: with --quiet, the strict check of the merge-based result all the same: one line on STDERR (the CSV stays the reference's), exit code 2 on a violation
 };
 
 inline RunConfig ParseCommon(const CommandLineArgs &args, bool gpu_driver)
@@ -44,6 +45,7 @@ inline RunConfig ParseCommon(const CommandLineArgs &args, bool gpu_driver)
     args.GetCmdLineArgument("mtx", c.mtx);
     c.cache = args.CheckCmdLineFlag("cache");
     c.timing = args.CheckCmdLineFlag("timing");
+    c.check = args.CheckCmdLineFlag("check");
     args.GetCmdLineArgument("grid2d", c.grid2d);
     args.GetCmdLineArgument("grid3d", c.grid3d);
     args.GetCmdLineArgument("wheel", c.wheel);      // parsed by gpu_spmv.cu:719 only; cpu_spmv.cpp forgot it

@@ -8,7 +8,7 @@
 // HybMV, where the reference ran cuSPARSE (gpu_spmv.cu:106-364,565-578).
 //
 //   gpu_spmv [--device=<id>] [--quiet] [--v] [--v2] [--i=<iterations>] [--fp32]
-//            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor] [--no-hyb]
+//            [--alpha=<a>] [--beta=<b>] [--peak-gbs=<GB/s>] [--no-strict] [--no-vendor] [--no-hyb] [--check]
 //            [--prepared] [--plan[=<bands>]] [--gpus=<G>[,<G2>...]] [--mg-one-device] [--mg-exchange=peer|rccl]
 //            --mtx=<file> | --dense=<cols> [--size=<nnz>] | --grid2d=<w> | --grid3d=<w> | --wheel=<spokes>
 //
@@ -170,6 +170,19 @@ void Verify(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, 
     fflush(stdout);
 }
 
+// --quiet --check (corpus sweeps, tools/corpus_sweep.sh): the strict check without touching the CSV on stdout
+static int g_check_failures = 0;
+template <typename V>
+void QuietCheck(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const V *d_y)
+{
+    std::vector<V> y((size_t) a.num_rows);
+    HIP_OK(hipMemcpy(y.data(), d_y, sizeof(V) * a.num_rows, hipMemcpyDeviceToHost));
+    double worst = 0;
+    const long long v = StrictCheck(a.num_rows, a.row_offsets.data(), a.column_indices.data(), a.values.data(), x.data(), y.data(), 16, &worst);
+    fprintf(stderr, "strict-check, %s, %s, %s, %lld, %.4g\n", c.mtx.empty() ? "generated" : c.mtx.c_str(), sizeof(V) > 4 ? "fp64" : "fp32", v ? "FAIL" : "PASS", v, worst);
+    if (v) ++g_check_failures;
+}
+
 // TestGpuMergeCsrmv (gpu_spmv.cu:376-435)
 template <typename V>
 float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> &x, const std::vector<V> &y_in,
@@ -199,6 +212,7 @@ float TestMerge(const RunConfig &c, const CsrMatrix<V> &a, const std::vector<V> 
     HIP_OK(hipMemcpy(p.d_y, y_in.data(), sizeof(V) * p.rows, hipMemcpyHostToDevice));
     HIP_OK(call(d_temp, temp_bytes, !c.quiet));                      // warm-up (+ launch log, like debug_synchronous)
     if (!c.quiet) Verify(c, a, x, gold, p.d_y, plain);
+    else if (c.check && plain && !prepared) QuietCheck(c, a, x, p.d_y);
     GpuTimer timer;
     timer.Start();
     for (int it = 0; it < iterations; ++it) HIP_OK(call(d_temp, temp_bytes, false));
@@ -483,7 +497,7 @@ int main(int argc, char **argv)
     if (args.CheckCmdLineFlag("help")) {
         printf("%s [--csrmv | --hybmv | --bsrmv ] [--device=<device-id>] [--quiet] [--v] [--i=<timing iterations>] [--fp32] "
                "[--alpha=<alpha scalar (default: 1.0)>] [--beta=<beta scalar (default: 0.0)>] [--peak-gbs=<GB/s>] "
-               "[--no-strict] [--no-vendor] [--no-hyb] [--cache] [--prepared] [--plan[=<bands>]] [--hotcols] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
+               "[--no-strict] [--no-vendor] [--no-hyb] [--check] [--cache] [--prepared] [--plan[=<bands>]] [--hotcols] [--gpus=<G>[,<G2>...]] [--mg-one-device] "
                "[--mg-exchange=peer|rccl] [--chunk-times=<calls per chunk>]\n"
                "\t--mtx=<matrix market file> \n\t--dense=<cols>\n\t--grid2d=<width>\n\t--grid3d=<width>\n\t--wheel=<spokes>\n",
                argv[0]);
@@ -513,5 +527,5 @@ int main(int argc, char **argv)
     if (c.fp32) Run<float>(c, dev, ex); else Run<double>(c, dev, ex);
     HIP_OK(hipDeviceSynchronize());
     printf("\n");
-    return 0;
+    return g_check_failures ? 2 : 0;
 }

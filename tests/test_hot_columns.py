@@ -87,6 +87,14 @@ def test_hotcols_spmv_is_bitwise_the_stateless_result(shape, prec, skew):
     assert torch.equal(a, b)
     # and again (the plan's hints and x buffer are reused)
     assert torch.equal(plan(xd), y_ref)
+    # a caller that keeps x in the plan's numbering (mspmv_csrmv_hotcols_permute_* once, _apply_permuted_* per SpMV: no per-call pass over x):
+    # the permuted vector is x[order], y comes out in the original row order, bit for bit the same -- with alpha / beta too
+    xp = plan.permute(xd)
+    assert torch.equal(xp, xd[plan.order().long()]) if cols else xp.numel() == 0
+    assert torch.equal(plan(xp, x_is_permuted=True), y_ref)
+    assert torch.equal(plan(xp, d(y0.copy()), alpha=-0.5, beta=2.0, x_is_permuted=True), a)
+    with pytest.raises(M.MspmvError):
+        plan.permute(xd, out=xd)                                  # not in place
 
 
 @gpu

@@ -11,8 +11,8 @@ rm -rf $OUT $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
 # PROFILE_MATCH (a regex, default mspmv) selects the kernels whose counters are summarised (e.g. 'mspmv|rocsparse' for the driver);
 # PROFILE_CMD overrides the profiled command (e.g. tools/plan_bench.py for the prepared plan); the default is the
-# headline bench without its prepared_plan leg (that leg launches the same kernel symbol on another matrix)
-BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-plan --no-configs $*"}
+# headline bench alone (no cpu_baseline, no `configs`: they launch the same kernel symbols on other matrices)
+BENCH=${PROFILE_CMD:-"python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-configs --detail /dev/null $*"}
 # PROFILE_INCLUDE (a regex): counters are collected for matching kernels only (--kernel-include-regex) -- what lets a command through
 # that first generates tens of GB with thousands of other kernels (BASELINE config 5: tools/r05_pmc.sh)
 INC=${PROFILE_INCLUDE:+--kernel-include-regex $PROFILE_INCLUDE}
@@ -55,8 +55,8 @@ def avg(name, counter):
         if r["kernel"].startswith("tile_kernel") and r["counter"] == counter: return float(r["avg_per_dispatch"])
     return None
 fetch_kb, write_kb = avg("FETCH_SIZE", "FETCH_SIZE"), avg("WRITE_SIZE", "WRITE_SIZE")
-workload = os.environ.get("PROFILE_LABEL") or ("dense32" if "dense32" in extra else "c2")
 dtype = os.environ.get("PROFILE_DTYPE") or ("f64" if "f64" in extra else "f32")
+workload = os.environ.get("PROFILE_LABEL") or ("dense32" if "dense32" in extra else "c2" if dtype == "f64" else "c2_f32")      # (bench.py's replay labels)
 d = {"workload": workload, "dtype": dtype, "command": os.environ.get("PROFILE_CMD", "bench.py " + extra),
      "collected": "separate rocprofv3 --kernel-trace --pmc passes (tools/gpu_profile.sh), averaged per dispatch of the tile kernel",
      "kernel": "tile kernel of the call (tile_kernel_vec<..,BAND> for column-band candidates, tile_kernel_snap otherwise)",

@@ -8,7 +8,7 @@ for c in $CPUS; do
   echo "## taskset -c $c: A = this build, B = ${PREV:-merge_spmv_amd/libmspmv_prev.so}"
   taskset -c $c tools/ab_driver merge_spmv_amd/libmspmv.so ${PREV:-merge_spmv_amd/libmspmv_prev.so} --loops=7 ${SIZES:-30 100 300 500 600 700}
   echo "## taskset -c $c: A = compact front end, B = general kernel (same build)"
-  taskset -c $c tools/ab_driver merge_spmv_amd/libmspmv.so merge_spmv_amd/libmspmv.so --tune-b=-1 --loops=7 ${SIZES:-30 100 300 500 600 700}
+  taskset -c $c tools/ab_driver merge_spmv_amd/libmspmv.so merge_spmv_amd/libmspmv_dev.so --tune-b=-1 --loops=7 ${SIZES:-30 100 300 500 600 700}
   echo "## taskset -c $c: fp32, A = compact front end, B = general kernel (same build)"
-  taskset -c $c tools/ab_driver merge_spmv_amd/libmspmv.so merge_spmv_amd/libmspmv.so --tune-b=-1 --loops=7 --fp32 ${SIZES:-30 100 300 500 600 700}
+  taskset -c $c tools/ab_driver merge_spmv_amd/libmspmv.so merge_spmv_amd/libmspmv_dev.so --tune-b=-1 --loops=7 --fp32 ${SIZES:-30 100 300 500 600 700}
 done

@@ -13,6 +13,5 @@ run ./gpu_spmv --grid2d=4096 --prepared
 run ./gpu_spmv --grid3d=200 --prepared
 run ./gpu_spmv --dense=32 --size=100000000 --fp32 --prepared
 run ./gpu_spmv --wheel=5000000 --fp32
-run ./gpu_spmv --grid3d=200 --band-passes=3      # forced column-band passes through the C driver (a matrix they do not help: correctness only)
 run ./gpu_spmv --quiet --grid3d=200
 for w in 30 100 300 700; do run ./gpu_spmv --grid2d=$w --no-strict | grep -E "^## |Merge-based|rocSPARSE|fp64:"; done

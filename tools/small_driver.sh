@@ -20,7 +20,7 @@ for w in ${SIZES:-30 100 300 500 600 700 800 900 1000 1200 2000}; do
 done
 if [ -x ../tools/ab_driver ]; then
   echo "## part 2: interleaved loops in one process (A = this build, B = the same without the compact front end, R = rocSPARSE), CPU $CPU"
-  $PIN ../tools/ab_driver ./libmspmv.so ./libmspmv.so --tune-b=-1 --loops=7 ${SIZES:-30 100 300 500 600 700 800 900 1000 1200 2000}
+  $PIN ../tools/ab_driver ./libmspmv.so ./libmspmv_dev.so --tune-b=-1 --loops=7 ${SIZES:-30 100 300 500 600 700 800 900 1000 1200 2000}
   echo "## part 2, fp32"
-  $PIN ../tools/ab_driver ./libmspmv.so ./libmspmv.so --tune-b=-1 --loops=7 --fp32 ${SIZES:-30 100 300 500 600 700 800 900 1000 1200 2000}
+  $PIN ../tools/ab_driver ./libmspmv.so ./libmspmv_dev.so --tune-b=-1 --loops=7 --fp32 ${SIZES:-30 100 300 500 600 700 800 900 1000 1200 2000}
 fi
