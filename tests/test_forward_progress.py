@@ -36,9 +36,9 @@ def _matrix(kind, dtype, rng):
     if kind == "giant":          # one row over ~150 tiles between short rows (the reference's --wheel shape, larger)
         rows = 30000
         lens = rng.integers(0, 4, rows); lens[rows // 3] = 400_000
-    elif kind == "many_long":    # dozens of rows of 2-40 tiles each, back to back: many tiles wait for many records
-        rows = 3000
-        lens = np.where(np.arange(rows) % 7 == 0, rng.integers(4000, 90_000, rows), rng.integers(0, 30, rows))
+    elif kind == "many_long":    # hundreds of rows of 2-15 tiles each, back to back: many tiles wait for many records.  (Under 8 M path items:
+        rows = 3000              #  beyond that a matrix whose rows are ALL long runs the classic three launches, mspmv_api.hip: long_rows_rule)
+        lens = np.where(np.arange(rows) % 7 == 0, rng.integers(4000, 28_000, rows), rng.integers(0, 30, rows))
     elif kind == "power_law":
         rows = 60000
         lens = np.minimum((rng.pareto(1.05, rows) * 3).astype(np.int64), 200_000)
