@@ -1086,3 +1086,74 @@ def test_concurrent_host_threads_on_their_own_streams(M):
     for th in threads: th.join()
     for (csr, t, tdt, serial), y in zip(jobs, results):
         assert y is not None and torch.equal(y, serial)
+
+
+def test_a_stateless_call_of_the_small_shape_family_leaves_prepared_coordinates_alone(M):
+    """Advisor (round 5, medium): a stateless fp64 call on a --dense=<cols> matrix takes the SMALL tile shape by its column count
+    (skinny_rule) while mspmv_csrmv_prepare stores coordinates of the DEFAULT shape -- and the classic pipeline of a prepared call
+    (arrays not 16-byte aligned: tile_kernel, PHASE_SKIP_COORDS) trusts what it finds.  Since round 6 the small shape's layout sits
+    behind the default one in temp storage and is taken only with aligned arrays, so: prepare -> stateless call (small shape) ->
+    prepared call on UNALIGNED copies of the arrays must still read intact coordinates and give the right y; and a prepared call on
+    the aligned arrays picks the same shape as the stateless one: bit for bit the same y."""
+    rng = np.random.default_rng(77)
+    rows, cols = 1_650_000, 5                                     # 9.9 M path items: the family of the rule
+    csr = random_csr(rng, rows, cols, np.full(rows, 5, np.int64), np.float64)
+    x = rng.uniform(-1, 1, cols)
+    assert M.launch_info(rows, csr.nnz, 8, num_cols=cols)["items_per_thread"] == 7 and M.launch_info(rows, csr.nnz, 8)["items_per_thread"] == 11
+    val, off, col, xd = dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), dev(x)
+    ws = M.CsrMVWorkspace(rows, csr.nnz, torch.float64)
+    ws.buffer.fill_(0xAB)
+    ws.prepare(off)
+    coords_before, _, _ = M.debug_read_tiles(ws.buffer, rows, csr.nnz, 8)
+    # 1. the stateless call (aligned arrays: the small shape), straight through the C ABI so that it is NOT routed to the prepared entry
+    y1 = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    st, _ = M.DeviceSpmv.CsrMV(ws.buffer, ws.bytes, val, off, col, xd, y1, rows, cols, csr.nnz)
+    assert st == 0
+    torch.cuda.synchronize()
+    coords_after, _, _ = M.debug_read_tiles(ws.buffer, rows, csr.nnz, 8)
+    assert np.array_equal(coords_before, coords_after)                        # the default layout's coordinates are untouched
+    # 2. a prepared call on the aligned arrays: the same rule, the same shape, the same bits
+    y2 = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    M.csrmv(val, off, col, xd, y=y2, num_cols=cols, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    # 3. a prepared call on arrays that are NOT 16-byte aligned (values and columns one element into their allocations): the classic
+    #    pipeline on the stored coordinates
+    val_u = torch.empty(csr.nnz + 1, dtype=torch.float64, device="cuda")[1:]; val_u.copy_(val)
+    col_u = torch.empty(csr.nnz + 1, dtype=torch.int32, device="cuda")[1:]; col_u.copy_(col)
+    assert val_u.data_ptr() % 16 == 8 and col_u.data_ptr() % 16 == 4
+    y3 = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    lib = M.load_library(); size = ctypes.c_size_t(ws.bytes)
+    st = lib.mspmv_csrmv_prepared_f64(ctypes.c_void_p(ws.buffer.data_ptr()), ctypes.byref(size), ctypes.c_void_p(val_u.data_ptr()), ctypes.c_void_p(off.data_ptr()),
+                                      ctypes.c_void_p(col_u.data_ptr()), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(y3.data_ptr()), rows, cols, csr.nnz,
+                                      ctypes.c_double(1.0), ctypes.c_double(0.0), None, 0)
+    assert st == 0
+    torch.cuda.synchronize()
+    gold = O.spmv_gold(csr, x)
+    check_strict(M, csr, x, y3.cpu().numpy())
+    assert np.allclose(y3.cpu().numpy(), gold, rtol=0, atol=1e-13) and np.array_equal(y1.cpu().numpy().view(np.uint64), gold.view(np.uint64))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_matrices_whose_rows_are_all_long_run_the_classic_launches(M, prec):
+    """mspmv_api.hip: long_rows_rule -- from an average of 384 nonzeros per row at >= 8 M path items (240 at >= 16 M) nearly every tile
+    would publish and take a tagged record, each a round trip through the memory side at the end of a block's life; such calls run
+    the coordinate pass + tiles with one carry each + one fix-up launch instead (tools/long_rows_probe.py: 25-40 % faster).  The host
+    decides from rows and nonzeros alone; both sides of the threshold give every row within the strict bound, and a matrix with a FEW
+    long rows among short ones keeps the one launch."""
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(5 + vb)
+    cases = []
+    for rows, k, classic in ((20_000, 400, True), (40_000, 190, False), (30_000, 256, False), (66_000, 250, True)):
+        info = M.launch_info(rows, rows * k, vb)
+        assert (info["snap_head_max"] == 0) == classic and (info["fixup_levels"] >= 1) == classic, (rows, k, info)
+        cases.append((rows, k))
+    assert M.launch_info(1 << 24, 67_112_959, vb)["snap_head_max"] > 0                    # BASELINE config 4: average 4, one giant row
+    for rows, k in cases[:2]:                                                                # (one of each side, run on the device)
+        lens = np.full(rows, k, np.int64); lens[::3] += rng.integers(0, 40, lens[::3].size)
+        csr = random_csr(rng, rows, 30_000, lens, dtype)
+        x = rng.uniform(-1, 1, csr.cols).astype(dtype)
+        y, ws = run_gpu(M, csr, x)
+        check_strict(M, csr, x, y)
+        y2, _ = run_gpu(M, csr, x)
+        assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))                          # bitwise repeatable either way

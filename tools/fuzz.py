@@ -71,6 +71,9 @@ def main():
         rows = int(rng.choice([1_000_000, 3_000_000])) if big else int(rng.choice([1, 2, 3, 5, 17, 100, 1000, 5000, 40000, 300000]))
         cols = int(rng.choice([1, 2, 7, 64, 1000, 100000]))
         lens = random_lens(rng, rows)
+        if rng.random() < float(os.environ.get("FUZZ_LONG", "0.01")):      # now and then a matrix whose rows are ALL long, around the sizes at which such
+            big = True                                                       # calls switch to the classic three launches (mspmv_api.hip: long_rows_rule)
+            rows = int(rng.integers(15_000, 60_000)); lens = rng.integers(int(rng.choice([150, 230, 380])), 700, rows).astype(np.int64)
         cap = 30_000_000 if big else 1_500_000
         if lens.sum() > cap: lens = lens // (lens.sum() // cap + 1)
         off = np.zeros(rows + 1, np.int64); np.cumsum(lens, out=off[1:])
