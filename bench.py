@@ -7,9 +7,12 @@ A "step" is one y = A*x through the C ABI (include/mspmv.h); inputs are resident
 
 N = 1: BASELINE.json config 2 -- fp32, 3 125 000^2, 32 nnz/row = 100 000 000 nnz, uniform random sorted columns --
        through the stateless drop-in call mspmv_csrmv_f32.
-N > 1: BASELINE.json config 5 -- fp64 R-MAT scale 26, 2 000 000 000 edges, ONE matrix cut by merge-path diagonals into N swaths
-       (mspmv_mg_partition), one rank per GPU, ONE RCCL all-gather of the N boundary-row carries per step below the C ABI.
-       Strong scaling; rank 0 then runs the whole matrix alone (`single_gpu_same_workload`; --no-single-gpu-leg skips it).
+N > 1: the same matrix family, WEAK scaling -- N x 3 125 000 rows over the same 3 125 000 columns, cut by merge-path diagonals into N
+       swaths (mspmv_mg_partition: every GPU holds what the N = 1 line's GPU holds), one rank per GPU, ONE RCCL all-gather of the N
+       boundary-row carries per step below the C ABI: the per-N values of a scaling series are about one workload.
+       Then, as a second leg in the same job (`c5_strong`; --no-c5-leg skips it), BASELINE.json config 5 -- fp64 R-MAT scale 26,
+       2 000 000 000 edges, ONE matrix whatever N, strong scaling; rank 0 then runs that whole matrix alone
+       (`single_gpu_same_workload`; --no-single-gpu-leg skips it).  `--workload c5` makes config 5 the headline instead.
        `--preflight`: communicator, one all-gather, one step, exit (< 10 s; a failure names the rank).
 
 The LAST stdout line is ONE JSON object under 4 KB, numbers only (what the reference prints is one perf line, gpu_spmv.cu:459-471):
@@ -353,6 +356,17 @@ def compact_line(detail, detail_path=None):
         optional.append("single_gpu_same_workload")
     if "preflight" in detail:
         line["preflight"] = detail["preflight"]
+    if detail.get("c5_strong"):
+        c = detail["c5_strong"]
+        if "error" in c:
+            line["c5_strong"] = {"error": str(c["error"])[:120]}
+        else:
+            line["c5_strong"] = {"n_gpus": c.get("n_gpus"), "scaling": c.get("scaling"), "dtype": c.get("dtype"), "steps": c.get("steps"),
+                                 "ms_per_step": c.get("ms_per_step"), "value": c.get("value"), "frac": c.get("roofline", {}).get("frac"),
+                                 "backend": str(c.get("exchange", {}).get("backend", c.get("exchange", {}).get("exchange")))[:40],
+                                 "hot_parts": c.get("exchange", {}).get("hot_parts"),
+                                 "tile_ms_max": c.get("per_rank", {}).get("tile_ms_max"), "exchange_ms_max": c.get("per_rank", {}).get("exchange_ms_max"),
+                                 "single_gpu_value": c.get("single_gpu_same_workload", {}).get("value")}
     if "prepared_plan" in detail and "ms_per_step" in detail["prepared_plan"]:
         p = detail["prepared_plan"]
         line["prepared_plan"] = {"ms_per_step": p["ms_per_step"], "value": p["value"], "frac": p["roofline"]["frac"], "setup_ms": p["setup_ms"]}
@@ -502,7 +516,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 on one GPU, c5 (one R-MAT matrix cut N ways) on N > 1")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 (N > 1: weak scaling, the same per-GPU matrix, then config 5 as a second leg); c5 = one R-MAT matrix cut N ways, strong scaling")
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--c5-scale", type=int, default=26)
     ap.add_argument("--c5-edges", type=int, default=2_000_000_000)
@@ -514,6 +528,7 @@ def main():
                     help="N = 1: a directory that may hold webbase-1M.mtx, com-Orkut.mtx, circuit5M.mtx (default: $MSPMV_C3_DIR); a file found replaces the generated stand-in")
     ap.add_argument("--detail", default=os.environ.get("MSPMV_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
                     help="side file for everything that is not in the line ('' = none)")
+    ap.add_argument("--no-c5-leg", action="store_true", help="N > 1, default workload: skip the config-5 leg (one R-MAT matrix cut N ways, strong scaling) after the headline")
     ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1, c5: skip rank 0's run of the WHOLE matrix alone afterwards")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"], help="N > 1: RCCL all-gather per step (default) or the hipIpc peer backend")
     ap.add_argument("--preflight", action="store_true", help="N > 1: communicator init, one all-gather, one step; exits in seconds naming a failing rank")
@@ -568,287 +583,314 @@ def main():
         dist.barrier(); dist.destroy_process_group()
         raise SystemExit(0 if res["ok"] else 3)
 
-    workload = args.workload or ("c5" if mg else "c2")
-    dtype_name = args.dtype or WORKLOADS[workload]
-    tdt = torch.float32 if dtype_name == "f32" else torch.float64
-    vb = 4 if dtype_name == "f32" else 8
-    if workload == "dense32" and mg:
-        raise SystemExit("dense32 is a single-GPU workload")
+    def measure(workload, steps, warmup):
+        """One workload through the whole protocol (every rank calls it); rank 0 gets the record, the others None."""
+        dtype_name = args.dtype or WORKLOADS[workload]
+        tdt = torch.float32 if dtype_name == "f32" else torch.float64
+        vb = 4 if dtype_name == "f32" else 8
+        if workload == "dense32" and mg:
+            raise SystemExit("dense32 is a single-GPU workload")
 
-    # ---- the matrix (this rank's swath of it), directly in HBM ----------------------------------------------
-    A = None
-    shard = None
-    if workload == "c5":
-        n = 1 << args.c5_scale
-        rows = cols = n
-        nnz_total = args.c5_edges
-        x_seed = G.SEED_C5 + 2
-        scaling = "strong"
-        desc = f"C5 R-MAT scale {args.c5_scale}: {n}^2, {nnz_total} edges (duplicates kept), a,b,c,d=.57,.19,.19,.05, seed 0x5EED0005; one matrix whatever N"
-        if not mg:
-            A = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
+        # ---- the matrix (this rank's swath of it), directly in HBM ----------------------------------------------
+        A = None
+        shard = None
+        if workload == "c5":
+            n = 1 << args.c5_scale
+            rows = cols = n
+            nnz_total = args.c5_edges
+            x_seed = G.SEED_C5 + 2
+            scaling = "strong"
+            desc = f"C5 R-MAT scale {args.c5_scale}: {n}^2, {nnz_total} edges (duplicates kept), a,b,c,d=.57,.19,.19,.05, seed 0x5EED0005; one matrix whatever N"
+            if not mg:
+                A = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
+            else:
+                shard = MG.rmat_shard(args.c5_scale, nnz_total, rank, world, tdt, device=dev, seed=G.SEED_C5, use_dist=True)
         else:
-            shard = MG.rmat_shard(args.c5_scale, nnz_total, rank, world, tdt, device=dev, seed=G.SEED_C5, use_dist=True)
-    else:
-        rows = C2_ROWS_PER_GPU * world
-        cols = C2_ROWS_PER_GPU if workload == "c2" else C2_NPR
-        nnz_total = rows * C2_NPR
-        x_seed = G.SEED_C2 + 2
-        scaling = "weak"
-        desc = (f"C2 uniform CSR: {rows} x {cols}, {C2_NPR} nnz/row, {nnz_total} nnz, uniform random sorted columns, values/x in [-1,1)" if workload == "c2" else
-                f"dense {rows} x {C2_NPR} as CSR ({nnz_total} nnz): C2's streaming variant (--dense=32 --size=100000000)")
+            rows = C2_ROWS_PER_GPU * world
+            cols = C2_ROWS_PER_GPU if workload == "c2" else C2_NPR
+            nnz_total = rows * C2_NPR
+            x_seed = G.SEED_C2 + 2
+            scaling = "weak"
+            desc = (f"C2 uniform CSR: {rows} x {cols}, {C2_NPR} nnz/row, {nnz_total} nnz, uniform random sorted columns, values/x in [-1,1)" if workload == "c2" else
+                    f"dense {rows} x {C2_NPR} as CSR ({nnz_total} nnz): C2's streaming variant (--dense=32 --size=100000000)")
+            if not mg:
+                A = (G.uniform_csr(rows, cols, C2_NPR, dtype=tdt, device=dev) if workload == "c2"
+                     else G.dense_csr(rows, C2_NPR, dtype=tdt, device=dev, ones=False))
+            else:
+                shard = MG.uniform_shard(rows, cols, C2_NPR, rank, world, tdt, device=dev)
+        x = G.uniform_pm1(x_seed, cols, tdt, dev)
+
+        # ---- the operator ------------------------------------------------------------------------------------------
+        plan = None
+        sharded = None
+        exchange = None
+        ws = y = None
         if not mg:
-            A = (G.uniform_csr(rows, cols, C2_NPR, dtype=tdt, device=dev) if workload == "c2"
-                 else G.dense_csr(rows, C2_NPR, dtype=tdt, device=dev, ones=False))
-        else:
-            shard = MG.uniform_shard(rows, cols, C2_NPR, rank, world, tdt, device=dev)
-    x = G.uniform_pm1(x_seed, cols, tdt, dev)
-
-    # ---- the operator ------------------------------------------------------------------------------------------
-    plan = None
-    exchange = None
-    ws = y = None
-    if not mg:
-        local_rows, local_nnz = A.rows, A.nnz
-        ws = M.CsrMVWorkspace(A.rows, A.nnz, tdt, device=dev)
-        y = torch.empty(A.rows, dtype=tdt, device=dev)
-
-        def op():
-            M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=cols, workspace=ws)
-
-        def op_sync():
-            torch.cuda.synchronize()
-    elif (backend == "nccl" and not one_device) or args.exchange == "ipc" or os.environ.get("MSPMV_BENCH_FORCE_C_OPERATOR") == "1":
-        # the C multi-GPU operator, one part per process.  The exchange asked for is tried first; if any rank fails to set it up or
-        # to run two trial steps with it, every rank falls back together (rccl -> ipc -> the Python twin over torch.distributed)
-        local_rows, local_nnz = shard.local_rows, shard.local_nnz
-
-        def all_ok(ok):
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item())
-
-        def try_exchange(kind):
-            p, why = None, None
-            try:
-                if kind == "ipc":
-                    p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_IPC)
-                else:
-                    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-                    if rank == 0:
-                        idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
-                    dist.broadcast(idt, 0)
-                    p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
-                                  id128=bytes(idt.cpu().numpy().tobytes()))
-                p.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
-                blob = p.ipc_export() if kind == "ipc" else None
-            except Exception as e:  # noqa: BLE001 - any failure means "fall back"
-                why = f"rank {rank} setup: {e}"
-            if not all_ok(why is None):
-                return p, why or "another rank failed during setup"
-            try:
-                if kind == "ipc":
-                    blobs = [None] * world
-                    dist.all_gather_object(blobs, blob)
-                    p.ipc_import(blobs)
-                p.x(0).copy_(x)
-                torch.cuda.synchronize()
-                for _ in range(2):
-                    p.csrmv()
-                p.synchronize(); torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                why = f"rank {rank} trial steps: {e}"
-            if not all_ok(why is None):
-                return p, why or "another rank failed in the trial steps"
-            return p, None
-
-        order = [args.exchange] + [k for k in ("rccl", "ipc") if k != args.exchange]
-        fallbacks = []
-        for kind in order:
-            plan, why = try_exchange(kind)
-            if why is None:
-                break
-            fallbacks.append({"exchange": kind, "failed": why[:300]})
-            sys.stderr.write(f"[bench] exchange {kind} not usable: {why[:300]}\n")
-            if plan is not None:
-                try:
-                    plan.close()
-                except Exception:  # noqa: BLE001
-                    pass
-            plan = None
-        if plan is not None:
-            exchange = plan.info()
-            exchange["fallbacks"] = fallbacks
+            local_rows, local_nnz = A.rows, A.nnz
+            ws = M.CsrMVWorkspace(A.rows, A.nnz, tdt, device=dev)
+            y = torch.empty(A.rows, dtype=tdt, device=dev)
 
             def op():
-                plan.csrmv()
+                M.csrmv(A.values, A.row_offsets, A.column_indices, x, y=y, num_cols=cols, workspace=ws)
 
             def op_sync():
-                plan.synchronize(); torch.cuda.synchronize()
+                torch.cuda.synchronize()
+        elif (backend == "nccl" and not one_device) or args.exchange == "ipc" or os.environ.get("MSPMV_BENCH_FORCE_C_OPERATOR") == "1":
+            # the C multi-GPU operator, one part per process.  The exchange asked for is tried first; if any rank fails to set it up or
+            # to run two trial steps with it, every rank falls back together (rccl -> ipc -> the Python twin over torch.distributed)
+            local_rows, local_nnz = shard.local_rows, shard.local_nnz
+
+            def all_ok(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+
+            def try_exchange(kind):
+                p, why = None, None
+                try:
+                    if kind == "ipc":
+                        p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_IPC)
+                    else:
+                        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                        if rank == 0:
+                            idt.copy_(torch.frombuffer(bytearray(MG.unique_id()), dtype=torch.uint8))
+                        dist.broadcast(idt, 0)
+                        p = MG.MgPlan(shard.row_split, shard.nz_split, cols, tdt, [rank], [local_rank], exchange=MG.EXCHANGE_RCCL,
+                                      id128=bytes(idt.cpu().numpy().tobytes()))
+                    p.set_part(0, shard.values, shard.row_offsets, shard.column_indices)
+                    blob = p.ipc_export() if kind == "ipc" else None
+                except Exception as e:  # noqa: BLE001 - any failure means "fall back"
+                    why = f"rank {rank} setup: {e}"
+                if not all_ok(why is None):
+                    return p, why or "another rank failed during setup"
+                try:
+                    if kind == "ipc":
+                        blobs = [None] * world
+                        dist.all_gather_object(blobs, blob)
+                        p.ipc_import(blobs)
+                    p.x(0).copy_(x)
+                    torch.cuda.synchronize()
+                    for _ in range(2):
+                        p.csrmv()
+                    p.synchronize(); torch.cuda.synchronize()
+                except Exception as e:  # noqa: BLE001
+                    why = f"rank {rank} trial steps: {e}"
+                if not all_ok(why is None):
+                    return p, why or "another rank failed in the trial steps"
+                return p, None
+
+            order = [args.exchange] + [k for k in ("rccl", "ipc") if k != args.exchange]
+            fallbacks = []
+            for kind in order:
+                plan, why = try_exchange(kind)
+                if why is None:
+                    break
+                fallbacks.append({"exchange": kind, "failed": why[:300]})
+                sys.stderr.write(f"[bench] exchange {kind} not usable: {why[:300]}\n")
+                if plan is not None:
+                    try:
+                        plan.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                plan = None
+            if plan is not None:
+                exchange = plan.info()
+                exchange["fallbacks"] = fallbacks
+
+                def op():
+                    plan.csrmv()
+
+                def op_sync():
+                    plan.synchronize(); torch.cuda.synchronize()
+            else:
+                sharded = MG.ShardedCsrMV(shard, group=None)
+                exchange = {"exchange": "python twin over " + backend, "carry_bytes_per_step": world * vb, "fallbacks": fallbacks}
+
+                def op():
+                    sharded(x)
+
+                def op_sync():
+                    torch.cuda.synchronize()
         else:
+            local_rows, local_nnz = shard.local_rows, shard.local_nnz
             sharded = MG.ShardedCsrMV(shard, group=None)
-            exchange = {"exchange": "python twin over " + backend, "carry_bytes_per_step": world * vb, "fallbacks": fallbacks}
+            exchange = {"exchange": "python twin over " + backend, "carry_bytes_per_step": world * vb}
 
             def op():
                 sharded(x)
 
             def op_sync():
                 torch.cuda.synchronize()
-    else:
-        local_rows, local_nnz = shard.local_rows, shard.local_nnz
-        sharded = MG.ShardedCsrMV(shard, group=None)
-        exchange = {"exchange": "python twin over " + backend, "carry_bytes_per_step": world * vb}
 
-        def op():
-            sharded(x)
+        def barrier():
+            op_sync()
+            if dist is not None:
+                dist.barrier()
+            op_sync()
 
-        def op_sync():
-            torch.cuda.synchronize()
-
-    def barrier():
-        op_sync()
+        for _ in range(warmup):
+            op()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            op()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed_local = elapsed
         if dist is not None:
-            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ms_per_step = elapsed * 1e3 / steps
+
+        # ---- per-kernel durations: the same K steps again with hipEvents on the launch stream
+        M.profile_begin(steps)
+        for _ in range(steps):
+            op()
         op_sync()
+        prof = M.profile_end()
 
-    for _ in range(args.warmup):
-        op()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        op()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_local = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-
-    # ---- per-kernel durations: the same K steps again with hipEvents on the launch stream
-    M.profile_begin(args.steps)
-    for _ in range(args.steps):
-        op()
-    op_sync()
-    prof = M.profile_end()
-
-    # ---- N > 1 through the C operator: what the step's exchange alone takes (events around it, per rank)
-    exchange_ms = None
-    if plan is not None:
-        ex = []
-        for _ in range(5):
-            op(); op_sync()
-            try:
-                ex.append(plan.exchange_ms(0))
-            except Exception:  # noqa: BLE001
-                break
-        exchange_ms = sum(ex) / len(ex) if ex else None
-
-    # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
-    single = None
-    if mg and workload == "c5" and not args.no_single_gpu_leg:
-        y0 = None
+        # ---- N > 1 through the C operator: what the step's exchange alone takes (events around it, per rank)
+        exchange_ms = None
         if plan is not None:
-            if rank == 0:
-                op_sync()
-                y0 = plan.y(0).clone()          # rank 0's owned rows of the last step (rows 0 .. of the whole matrix)
-            plan.close()
-        plan = None; shard = None; sharded = None
-        torch.cuda.empty_cache()
-        if rank == 0:
-            W = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
-            wws = M.CsrMVWorkspace(W.rows, W.nnz, tdt, device=dev)
-            wy = torch.empty(W.rows, dtype=tdt, device=dev)
-            k = 5
-            for _ in range(2):
-                M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(k):
-                M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
-            torch.cuda.synchronize()
-            sms = (time.perf_counter() - t1) * 1e3 / k
-            single = {"n_gpus": 1, "steps": k, "ms_per_step": round(sms, 5), "value": round(2.0 * nnz_total / (sms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
-            if y0 is not None:
-                # (detail file) rank 0's tiles are the single-GPU call's first tiles, so its rows must match bit for bit when both run the
-                # same tile shape through the same path -- except inside rank 0's LAST tile, which ends where the part ends
-                ref = wy[:y0.numel()]
-                neq = (ref != y0).nonzero()
-                part_info = M.launch_info(local_rows, local_nnz, vb)
-                whole_info = M.launch_info(W.rows, W.nnz, vb)
-                same = (part_info["items_per_thread"] == whole_info["items_per_thread"] and part_info["snap_head_max"] == whole_info["snap_head_max"]
-                        and M.band_passes(W.rows, W.cols, W.nnz, vb) <= 1 and M.band_passes(local_rows, cols, local_nnz, vb) <= 1)
-                single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": int(neq.numel()),
-                                                      "first_differing_row": int(neq[0].item()) if neq.numel() else None,
-                                                      "tile_items": int(part_info["tile_items"]), "same_tiling": bool(same),
-                                                      "max_abs_diff": float((ref - y0).abs().max().item()) if y0.numel() else 0.0}
-            del W, wws, wy
+            ex = []
+            for _ in range(5):
+                op(); op_sync()
+                try:
+                    ex.append(plan.exchange_ms(0))
+                except Exception:  # noqa: BLE001
+                    break
+            exchange_ms = sum(ex) / len(ex) if ex else None
 
-    sys.stdout.flush()
-    per_rank = None
-    if dist is not None:
-        mine = torch.tensor([prof["search_ms"], prof["tile_ms"], prof["fixup_ms"], elapsed_local * 1e3 / args.steps, float(local_nnz),
-                             float("nan") if exchange_ms is None else exchange_ms], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        rows_ = torch.stack(allr).cpu().numpy()
-        nanmax = lambda a: None if np.isnan(a).all() else round(float(np.nanmax(a)), 5)
-        nanmin = lambda a: None if np.isnan(a).all() else round(float(np.nanmin(a)), 5)
-        per_rank = {"tile_ms_max": round(float(rows_[:, 1].max()), 5), "tile_ms_min": round(float(rows_[:, 1].min()), 5),
-                    "step_ms_max": round(float(rows_[:, 3].max()), 5), "step_ms_min": round(float(rows_[:, 3].min()), 5),
-                    "nnz_per_rank_max": int(rows_[:, 4].max()), "nnz_per_rank_min": int(rows_[:, 4].min()),
-                    "exchange_ms_max": nanmax(rows_[:, 5]), "exchange_ms_min": nanmin(rows_[:, 5]),
-                    "note": "per rank: hipEvent averages of its kernels, its own wall time per step; exchange_ms = events right after the SpMV and right after "
-                            "the all-gather + the owner's add (mspmv_mg_plan_exchange_ms, 5 separate steps), the wait for slower ranks included"}
-        dist.barrier()
-    if rank == 0:
-        gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
-        info = M.launch_info(local_rows, local_nnz, vb)
-        eff = effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9
-        out = {
-            "metric": "CsrMV GFLOP/s", "value": round(gflops, 3), "unit": "GFLOP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-            "config": {"workload": desc, "tile": f"{info['block_threads']}x{info['items_per_thread']}",
-                       "partition": ("single GPU" if not mg else
-                                     f"merge-path diagonal split over {world} GPUs: {local_rows - 1} rows + {local_nnz} nnz on rank 0; one exchange of {world} carries per step")},
-            "effective_GBs_reference_formula": round(eff, 1), "effective_pct_of_peak": round(100.0 * eff / HBM_PEAK_GBS, 2),
-        }
-        if not mg:
-            label = "c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload
-            out["roofline"] = roofline_record(M, A, cols, prof, ms_per_step, ws, label, dtype_name)
-            chk = M.sampled_check(A, x, y)
-            out["sampled_worst_ratio"] = chk["worst_ratio"]
-            out["sampled_check"] = chk
-        else:
-            b_alg = algorithmic_bytes(local_rows, cols, local_nnz, vb)
-            tile_s = prof["tile_ms"] * 1e-3
-            achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
-            out["roofline"] = {"kernel": "tile_kernel_snap (rank 0's part)", "achieved": round(achieved, 1), **roofline_bound(M, b_alg, achieved),
-                               "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(prof["tile_ms"], 5), "traffic": None,
-                               "traffic_over_algorithmic": None, "traffic_src": None}
-        if exchange is not None:
-            ex = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
-            if isinstance(exchange.get("exchange"), int):
-                ex["backend"] = {1: "rccl all-gather", 2: "peer reads", 3: "hipIpc mailbox"}.get(exchange["exchange"])
-            out["exchange"] = ex
-        if per_rank is not None:
-            out["per_rank"] = per_rank
-        if single is not None:
-            out["single_gpu_same_workload"] = single
-        full = None
-        if args.full and not mg:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import bench_full as full
-            full.extend_headline(out, M, torch, G, A, x, y, ws, workload, dtype_name, args)
-        if not mg and not args.no_cpu_baseline and A.nnz <= 400_000_000:
-            out["cpu_baseline"] = cpu_baseline(A, x, "same " + workload.upper() + " matrix")
-        if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs:
-            del A, ws, y
+        # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
+        single = None
+        if mg and workload == "c5" and not args.no_single_gpu_leg:
+            y0 = None
+            if plan is not None:
+                if rank == 0:
+                    op_sync()
+                    y0 = plan.y(0).clone()          # rank 0's owned rows of the last step (rows 0 .. of the whole matrix)
+                plan.close()
+            plan = None; shard = None; sharded = None
             torch.cuda.empty_cache()
-            out["configs"] = config_records(M, torch, G, dev, min(args.steps, 50), args.warmup, args.configs_budget if not args.full else 600.0,
-                                            mtx_dir=args.mtx_dir, full=full)
+            if rank == 0:
+                W = G.rmat_csr(args.c5_scale, nnz_total, dtype=tdt, device=dev, seed=G.SEED_C5)
+                wws = M.CsrMVWorkspace(W.rows, W.nnz, tdt, device=dev)
+                wy = torch.empty(W.rows, dtype=tdt, device=dev)
+                k = 5
+                for _ in range(2):
+                    M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(k):
+                    M.csrmv(W.values, W.row_offsets, W.column_indices, x, y=wy, num_cols=cols, workspace=wws)
+                torch.cuda.synchronize()
+                sms = (time.perf_counter() - t1) * 1e3 / k
+                single = {"n_gpus": 1, "steps": k, "ms_per_step": round(sms, 5), "value": round(2.0 * nnz_total / (sms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"}
+                if y0 is not None:
+                    # (detail file) rank 0's tiles are the single-GPU call's first tiles, so its rows must match bit for bit when both run the
+                    # same tile shape through the same path -- except inside rank 0's LAST tile, which ends where the part ends
+                    ref = wy[:y0.numel()]
+                    neq = (ref != y0).nonzero()
+                    part_info = M.launch_info(local_rows, local_nnz, vb)
+                    whole_info = M.launch_info(W.rows, W.nnz, vb)
+                    same = (part_info["items_per_thread"] == whole_info["items_per_thread"] and part_info["snap_head_max"] == whole_info["snap_head_max"]
+                            and M.band_passes(W.rows, W.cols, W.nnz, vb) <= 1 and M.band_passes(local_rows, cols, local_nnz, vb) <= 1)
+                    single["rank0_rows_vs_single_gpu"] = {"rows": int(y0.numel()), "not_bitwise_equal": int(neq.numel()),
+                                                          "first_differing_row": int(neq[0].item()) if neq.numel() else None,
+                                                          "tile_items": int(part_info["tile_items"]), "same_tiling": bool(same),
+                                                          "max_abs_diff": float((ref - y0).abs().max().item()) if y0.numel() else 0.0}
+                del W, wws, wy
+
+        sys.stdout.flush()
+        per_rank = None
+        if dist is not None:
+            mine = torch.tensor([prof["search_ms"], prof["tile_ms"], prof["fixup_ms"], elapsed_local * 1e3 / steps, float(local_nnz),
+                                 float("nan") if exchange_ms is None else exchange_ms], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            rows_ = torch.stack(allr).cpu().numpy()
+            nanmax = lambda a: None if np.isnan(a).all() else round(float(np.nanmax(a)), 5)
+            nanmin = lambda a: None if np.isnan(a).all() else round(float(np.nanmin(a)), 5)
+            per_rank = {"tile_ms_max": round(float(rows_[:, 1].max()), 5), "tile_ms_min": round(float(rows_[:, 1].min()), 5),
+                        "step_ms_max": round(float(rows_[:, 3].max()), 5), "step_ms_min": round(float(rows_[:, 3].min()), 5),
+                        "nnz_per_rank_max": int(rows_[:, 4].max()), "nnz_per_rank_min": int(rows_[:, 4].min()),
+                        "exchange_ms_max": nanmax(rows_[:, 5]), "exchange_ms_min": nanmin(rows_[:, 5]),
+                        "note": "per rank: hipEvent averages of its kernels, its own wall time per step; exchange_ms = events right after the SpMV and right after "
+                                "the all-gather + the owner's add (mspmv_mg_plan_exchange_ms, 5 separate steps), the wait for slower ranks included"}
+            dist.barrier()
+        if plan is not None:                 # (a second leg follows in the default N > 1 run: the part's buffers go back first)
+            try:
+                plan.close()
+            except Exception:  # noqa: BLE001
+                pass
+            plan = None
+        shard = None; sharded = None
+        if mg:
+            torch.cuda.empty_cache()
+        if rank == 0:
+            gflops = 2.0 * nnz_total / (ms_per_step * 1e-3) / 1e9
+            info = M.launch_info(local_rows, local_nnz, vb)
+            eff = effective_bytes(rows, nnz_total, vb) / (ms_per_step * 1e-3) / 1e9
+            out = {
+                "metric": "CsrMV GFLOP/s", "value": round(gflops, 3), "unit": "GFLOP/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": scaling,
+                "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+                "config": {"workload": desc, "tile": f"{info['block_threads']}x{info['items_per_thread']}",
+                           "partition": ("single GPU" if not mg else
+                                         f"merge-path diagonal split over {world} GPUs: {local_rows - 1} rows + {local_nnz} nnz on rank 0; one exchange of {world} carries per step")},
+                "effective_GBs_reference_formula": round(eff, 1), "effective_pct_of_peak": round(100.0 * eff / HBM_PEAK_GBS, 2),
+            }
+            if not mg:
+                label = "c2_f32" if (workload, dtype_name) == ("c2", "f32") else workload
+                out["roofline"] = roofline_record(M, A, cols, prof, ms_per_step, ws, label, dtype_name)
+                chk = M.sampled_check(A, x, y)
+                out["sampled_worst_ratio"] = chk["worst_ratio"]
+                out["sampled_check"] = chk
+            else:
+                b_alg = algorithmic_bytes(local_rows, cols, local_nnz, vb)
+                tile_s = prof["tile_ms"] * 1e-3
+                achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
+                out["roofline"] = {"kernel": "tile kernel of rank 0's part", "achieved": round(achieved, 1), **roofline_bound(M, b_alg, achieved),
+                                   "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(prof["tile_ms"], 5), "traffic": None,
+                                   "traffic_over_algorithmic": None, "traffic_src": None}
+            if exchange is not None:
+                ex = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in exchange.items() if k != "steps"}
+                if isinstance(exchange.get("exchange"), int):
+                    ex["backend"] = {1: "rccl all-gather", 2: "peer reads", 3: "hipIpc mailbox"}.get(exchange["exchange"])
+                out["exchange"] = ex
+            if per_rank is not None:
+                out["per_rank"] = per_rank
+            if single is not None:
+                out["single_gpu_same_workload"] = single
+            full = None
+            if args.full and not mg:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_full as full
+                full.extend_headline(out, M, torch, G, A, x, y, ws, workload, dtype_name, args)
+            if not mg and not args.no_cpu_baseline and A.nnz <= 400_000_000:
+                out["cpu_baseline"] = cpu_baseline(A, x, "same " + workload.upper() + " matrix")
+            if not mg and workload == "c2" and dtype_name == "f32" and not args.no_configs:
+                del A, ws, y
+                torch.cuda.empty_cache()
+                out["configs"] = config_records(M, torch, G, dev, min(steps, 50), warmup, args.configs_budget if not args.full else 600.0,
+                                                mtx_dir=args.mtx_dir, full=full)
+            return out
+        return None
+    # N > 1 (default): config 2's matrix family, weak scaling -- the SAME per-GPU matrix as the N = 1 line, so the per-N values
+    # of a scaling series are comparable -- and then BASELINE config 5 (one R-MAT matrix cut N ways, strong scaling) as a second leg
+    primary = args.workload or "c2"
+    out = measure(primary, args.steps, args.warmup)
+    if mg and args.workload is None and not args.no_c5_leg:
+        c5 = None
+        try:
+            c5 = measure("c5", min(args.steps, 20), min(args.warmup, 3))
+        except Exception as e:  # noqa: BLE001 - the headline is already measured: the leg must not cost it
+            c5 = {"error": f"{type(e).__name__}: {e}"[:200]}
+            sys.stderr.write(f"[bench] config 5 leg failed on rank {rank}: {c5['error']}\n")
+        if rank == 0:
+            out["c5_strong"] = c5
+    if rank == 0:
         emit(out, detail_path)
     if dist is not None:
         dist.barrier()

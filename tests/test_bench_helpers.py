@@ -123,6 +123,22 @@ def test_the_final_line_is_short_strict_json_with_the_contract_keys(n_configs, l
         assert d["detail"] == "gpurun_out/bench_detail.json"
 
 
+def test_the_config_5_leg_of_an_n_gpu_run_rides_in_the_line():
+    """N > 1, default workload: config 2 weak-scaled is the headline (comparable with the N = 1 line), config 5 (strong scaling) a compact
+    sub-record `c5_strong`; a failed leg leaves a short error there and the headline intact."""
+    import json
+    d = _fake_detail(0)
+    d["n_gpus"] = 8; d["scaling"] = "weak"
+    d["c5_strong"] = dict(_fake_detail(0), n_gpus=8, scaling="strong", dtype="f64", ms_per_step=3.1, value=1290.0)
+    line = bench.compact_line(bench._finite(d), "gpurun_out/bench_detail.json")
+    assert len(line.encode()) < bench.LINE_LIMIT
+    c = json.loads(line)["c5_strong"]
+    assert c["n_gpus"] == 8 and c["scaling"] == "strong" and c["value"] == 1290.0 and "frac" in c and "single_gpu_value" in c
+    d["c5_strong"] = {"error": "RuntimeError: " + "x" * 500}
+    c = json.loads(bench.compact_line(bench._finite(d)))
+    assert len(c["c5_strong"]["error"]) <= 120 and c["value"] == d["value"]
+
+
 def test_nan_and_inf_never_reach_the_line():
     import json
     d = _fake_detail(2)
