@@ -11,8 +11,8 @@ N > 1: the same matrix family, WEAK scaling -- N x 3 125 000 rows over the same 
        swaths (mspmv_mg_partition: every GPU holds what the N = 1 line's GPU holds), one rank per GPU, ONE RCCL all-gather of the N
        boundary-row carries per step below the C ABI: the per-N values of a scaling series are about one workload.
        Then, as a second leg in the same job (`c5_strong`; --no-c5-leg skips it), BASELINE.json config 5 -- fp64 R-MAT scale 26,
-       2 000 000 000 edges, ONE matrix whatever N, strong scaling; rank 0 then runs that whole matrix alone
-       (`single_gpu_same_workload`; --no-single-gpu-leg skips it).  `--workload c5` makes config 5 the headline instead.
+       2 000 000 000 edges, ONE matrix whatever N, strong scaling.  `--workload c5` makes config 5 the headline instead; rank 0 then also runs that whole
+       matrix alone (`single_gpu_same_workload`; --no-single-gpu-leg skips it; --c5-single-gpu-leg adds it to the default run's leg).
        `--preflight`: communicator, one all-gather, one step, exit (< 10 s; a failure names the rank).
 
 The LAST stdout line is ONE JSON object under 4 KB, numbers only (what the reference prints is one perf line, gpu_spmv.cu:459-471):
@@ -529,6 +529,7 @@ def main():
     ap.add_argument("--detail", default=os.environ.get("MSPMV_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
                     help="side file for everything that is not in the line ('' = none)")
     ap.add_argument("--no-c5-leg", action="store_true", help="N > 1, default workload: skip the config-5 leg (one R-MAT matrix cut N ways, strong scaling) after the headline")
+    ap.add_argument("--c5-single-gpu-leg", action="store_true", help="N > 1, default workload: after the config-5 leg rank 0 also runs the WHOLE R-MAT matrix alone (another ~80 s)")
     ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1, c5: skip rank 0's run of the WHOLE matrix alone afterwards")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "ipc"], help="N > 1: RCCL all-gather per step (default) or the hipIpc peer backend")
     ap.add_argument("--preflight", action="store_true", help="N > 1: communicator init, one all-gather, one step; exits in seconds naming a failing rank")
@@ -583,7 +584,7 @@ def main():
         dist.barrier(); dist.destroy_process_group()
         raise SystemExit(0 if res["ok"] else 3)
 
-    def measure(workload, steps, warmup):
+    def measure(workload, steps, warmup, single_leg=True):
         """One workload through the whole protocol (every rank calls it); rank 0 gets the record, the others None."""
         dtype_name = args.dtype or WORKLOADS[workload]
         tdt = torch.float32 if dtype_name == "f32" else torch.float64
@@ -764,7 +765,7 @@ def main():
 
         # ---- N > 1, c5: rank 0 runs the WHOLE matrix alone on its GPU in the same job -----------------------------------
         single = None
-        if mg and workload == "c5" and not args.no_single_gpu_leg:
+        if mg and workload == "c5" and single_leg and not args.no_single_gpu_leg:
             y0 = None
             if plan is not None:
                 if rank == 0:
@@ -884,7 +885,7 @@ def main():
     if mg and args.workload is None and not args.no_c5_leg:
         c5 = None
         try:
-            c5 = measure("c5", min(args.steps, 20), min(args.warmup, 3))
+            c5 = measure("c5", min(args.steps, 20), min(args.warmup, 3), single_leg=args.c5_single_gpu_leg)
         except Exception as e:  # noqa: BLE001 - the headline is already measured: the leg must not cost it
             c5 = {"error": f"{type(e).__name__}: {e}"[:200]}
             sys.stderr.write(f"[bench] config 5 leg failed on rank {rank}: {c5['error']}\n")
