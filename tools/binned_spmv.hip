@@ -97,7 +97,7 @@ __device__ __forceinline__ Cnt8 shfl_up(Cnt8 c, int d) { Cnt8 r; r.a = __shfl_up
 template <typename V>
 __global__ __launch_bounds__(BLOCK) void k_bin(const int* __restrict__ off, const int* __restrict__ col, const V* __restrict__ val,
                                                const Coord* __restrict__ coords, int band_cols, unsigned band_magic,
-                                               V* __restrict__ bval, unsigned* __restrict__ bpk, int* __restrict__ hdr)
+                                               V* __restrict__ bval, unsigned* __restrict__ bpk, int* __restrict__ hdr, int4v* __restrict__ meta, int tiles)
 {
     __shared__ V s_val[REGION];
     __shared__ unsigned s_col[REGION];
@@ -202,7 +202,11 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const int* __restrict__ off, cons
             s_val[at] = v[j];
         }
     }
-    if (tid < NB) { hdr[tile * 16 + tid] = seg[tid]; hdr[tile * 16 + 8 + tid] = (int) field(total, tid); }
+    if (tid < NB) {
+        hdr[tile * 16 + tid] = seg[tid]; hdr[tile * 16 + 8 + tid] = (int) field(total, tid);
+        int4v m; m[0] = seg[tid]; m[1] = (int) field(total, tid); m[2] = c0.x; m[3] = nclosed;
+        meta[(size_t) tid * tiles + tile] = m;           // what the band phase needs to know about (band, tile), one record
+    }
     __syncthreads();
     const int used = seg[NB];
     const size_t rb = (size_t) tile * REGION;
@@ -278,6 +282,141 @@ __global__ __launch_bounds__(WAVES * 64) void k_bands(const V* __restrict__ bval
     }
 }
 
+
+// ---- phase B, second form: E consecutive entries per lane (16-byte loads), the next unit's entries requested behind this unit's
+// gathers, one segmented scan per 64 * E entries, the tile's partial rows collected in LDS and written in one coalesced piece
+// (tiles with more closed rows than the LDS window keeps: zero fill, wait, scattered stores -- as the first form)
+constexpr int ACC_ROWS = 384;
+template <typename V, int E> struct Entries { unsigned pk[E]; V v[E]; };
+
+template <typename V, int E>
+__device__ __forceinline__ void load_entries(Entries<V, E>& en, const V* __restrict__ bval, const unsigned* __restrict__ bpk, size_t eb, int first, int n_pad, int lane)
+{
+    const int e0 = first + lane * E;
+    if (e0 < n_pad) {            // (segments are padded to 16 entries with sentinels and E divides 16: a lane's E entries are all inside)
+#pragma unroll
+        for (int i = 0; i < E; i += 4) {
+            const uint4v q = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(bpk + eb + e0 + i));
+            en.pk[i] = q[0]; en.pk[i + 1] = q[1]; en.pk[i + 2] = q[2]; en.pk[i + 3] = q[3];
+        }
+        constexpr int EPC = 16 / (int) sizeof(V);
+#pragma unroll
+        for (int i = 0; i < E; i += EPC) {
+            const uint4v raw = __builtin_nontemporal_load(reinterpret_cast<const uint4v*>(bval + eb + e0 + i));
+            V tmp[EPC]; __builtin_memcpy(tmp, &raw, 16);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) en.v[i + j] = tmp[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) { en.pk[i] = 0xFFFFFFFFu; en.v[i] = (V) 0; }
+    }
+}
+template <typename V> __device__ __forceinline__ V readlane_v(V p, int l)
+{
+    if constexpr (sizeof(V) == 4) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), l));
+    else {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, p);
+        const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) bits, l), hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (bits >> 32), l);
+        return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+    }
+}
+
+template <typename V, int WAVES, int E>
+__global__ __launch_bounds__(WAVES * 64) void k_bands2(const V* __restrict__ bval, const unsigned* __restrict__ bpk, const int4v* __restrict__ meta,
+                                                       const V* __restrict__ x, int band_cols, int tiles,
+                                                       V* __restrict__ part, size_t part_stride, V* __restrict__ carry)
+{
+    __shared__ V s_acc[WAVES][ACC_ROWS + 1];
+    const int k = blockIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_global = (blockIdx.x >> 3) * WAVES + wave, waves_total = (gridDim.x >> 3) * WAVES;
+    const V* __restrict__ xb = x + (size_t) k * band_cols;
+    V* __restrict__ pout = part + (size_t) k * part_stride;
+    V* __restrict__ cout = carry + (size_t) k * tiles;
+    volatile V* acc = s_acc[wave];
+    const int4v* __restrict__ mk = meta + (size_t) k * tiles;
+    constexpr int CHUNK = 64 * E;
+    for (int batch = wave_global; batch < tiles; batch += waves_total * 64) {
+        // the records of this wave's next 64 units, one per lane
+        const int mine = batch + lane * waves_total;
+        int4v mm; mm[0] = 0; mm[1] = 0; mm[2] = 0; mm[3] = 0;
+        if (mine < tiles) mm = mk[mine];
+        const int units = (tiles - batch + waves_total - 1) / waves_total < 64 ? (tiles - batch + waves_total - 1) / waves_total : 64;
+        Entries<V, E> nxt;
+        {
+            const int s0 = __builtin_amdgcn_readlane(mm[0], 0), n0 = __builtin_amdgcn_readlane(mm[1], 0);
+            load_entries<V, E>(nxt, bval, bpk, (size_t) batch * REGION + s0, 0, (n0 + 15) & ~15, lane);
+        }
+        for (int u = 0; u < units; ++u) {
+            const int tile = batch + u * waves_total;
+            const int s = __builtin_amdgcn_readlane(mm[0], u), n = __builtin_amdgcn_readlane(mm[1], u);
+            const int row0 = __builtin_amdgcn_readlane(mm[2], u), nclosed = __builtin_amdgcn_readlane(mm[3], u);
+            const int n_pad = (n + 15) & ~15;
+            const size_t eb = (size_t) tile * REGION + s;
+            const bool in_lds = nclosed <= ACC_ROWS;
+            if (in_lds) { for (int r = lane; r <= nclosed; r += 64) acc[r] = (V) 0; }
+            else {
+                for (int r = lane; r < nclosed; r += 64) pout[row0 + r] = (V) 0;
+                if (lane == 0) cout[tile] = (V) 0;
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            auto store = [&](int key, V val) {
+                if (key == (int) SENT_KEY) return;
+                if (in_lds) acc[key] = val;
+                else if (key == nclosed) cout[tile] = val; else pout[row0 + key] = val;
+            };
+            int carry_key = -1; V carry_sum = (V) 0;
+            Entries<V, E> cur = nxt;
+            for (int first = 0; first < n_pad || first == 0; first += CHUNK) {
+                if (first > 0) load_entries<V, E>(cur, bval, bpk, eb, first, n_pad, lane);
+                // gathers of this chunk, then the request for the next unit's first chunk behind them
+                V xv[E];
+#pragma unroll
+                for (int i = 0; i < E; ++i) xv[i] = cur.pk[i] != 0xFFFFFFFFu ? xb[cur.pk[i] & ((1u << COL_BITS) - 1)] : (V) 0;
+                if (first == 0 && u + 1 < units) {
+                    const int s1 = __builtin_amdgcn_readlane(mm[0], u + 1), n1 = __builtin_amdgcn_readlane(mm[1], u + 1);
+                    load_entries<V, E>(nxt, bval, bpk, (size_t) (tile + waves_total) * REGION + s1, 0, (n1 + 15) & ~15, lane);
+                }
+                // inside the lane: the first run is kept for the carry, middle runs are complete, the last run goes into the scan
+                int key[E]; V p[E];
+#pragma unroll
+                for (int i = 0; i < E; ++i) { key[i] = (int) (cur.pk[i] >> COL_BITS); p[i] = cur.v[i] * xv[i]; }
+                V tail = p[0], head = (V) 0; bool boundary = false;
+#pragma unroll
+                for (int i = 1; i < E; ++i) {
+                    if (key[i] != key[i - 1]) {
+                        if (!boundary) { head = tail; boundary = true; } else store(key[i - 1], tail);
+                        tail = p[i];
+                    } else tail += p[i];
+                }
+                const int k0 = key[0], k3 = key[E - 1];
+                int prev_k3 = __shfl_up(k3, 1); if (lane == 0) prev_k3 = carry_key;
+                bool f = k3 != prev_k3;
+                if (lane == 0 && carry_key >= 0 && k0 != carry_key) store(carry_key, carry_sum);      // the carried run ended with the previous chunk
+                V incl = tail;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const V op = __shfl_up(incl, d); const int of = __shfl_up((int) f, d);
+                    if (lane >= d && !f) { incl += op; f = of != 0; }
+                }
+                if (!f) incl += carry_sum;
+                V prev_incl = __shfl_up(incl, 1); if (lane == 0) prev_incl = carry_sum;
+                if (boundary) store(k0, (k0 == prev_k3 ? prev_incl : (V) 0) + head);
+                const int next_k0 = __shfl_down(k0, 1);
+                if (lane < 63 && k3 != next_k0) store(k3, incl);
+                carry_key = __builtin_amdgcn_readlane(k3, 63);
+                carry_sum = readlane_v(incl, 63);
+                if (carry_key == (int) SENT_KEY) carry_key = -1;
+            }
+            if (lane == 0 && carry_key >= 0) store(carry_key, carry_sum);
+            if (in_lds) {
+                for (int r = lane; r < nclosed; r += 64) pout[row0 + r] = acc[r];
+                if (lane == 0) cout[tile] = acc[nclosed];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ phase C: sum
 template <typename V>
 __global__ void k_sum(const V* __restrict__ part, size_t part_stride, V* __restrict__ y, int rows)
@@ -329,11 +468,11 @@ static void run(int rows, int cols, int npr)
     int band_cols = (((cols + NB - 1) / NB) + 31) & ~31;
     if (band_cols > (1 << COL_BITS)) { printf("x too wide for %d column bits\n", COL_BITS); return; }
     const unsigned magic = (unsigned) (0x100000000ull / (unsigned) band_cols);
-    int *off, *col, *hdr; V *val, *x, *y, *bval, *part, *carry; unsigned* bpk; Coord* coords; double *g, *gabs; unsigned long long* worst;
+    int *off, *col, *hdr; int4v* meta; V *val, *x, *y, *bval, *part, *carry; unsigned* bpk; Coord* coords; double *g, *gabs; unsigned long long* worst;
     const size_t part_stride = ((size_t) rows + 63) & ~(size_t) 63;
     CK(hipMalloc(&off, ((size_t) rows + 1) * 4)); CK(hipMalloc(&col, nnz * 4 + 64)); CK(hipMalloc(&val, nnz * sizeof(V) + 64));
     CK(hipMalloc(&x, (size_t) band_cols * NB * sizeof(V))); CK(hipMalloc(&y, (size_t) rows * sizeof(V)));
-    CK(hipMalloc(&bval, (size_t) tiles * REGION * sizeof(V))); CK(hipMalloc(&bpk, (size_t) tiles * REGION * 4)); CK(hipMalloc(&hdr, (size_t) tiles * 64));
+    CK(hipMalloc(&bval, (size_t) tiles * REGION * sizeof(V))); CK(hipMalloc(&bpk, (size_t) tiles * REGION * 4)); CK(hipMalloc(&hdr, (size_t) tiles * 64)); CK(hipMalloc(&meta, (size_t) tiles * NB * 16));
     CK(hipMalloc(&part, part_stride * NB * sizeof(V))); CK(hipMalloc(&carry, (size_t) tiles * NB * sizeof(V))); CK(hipMalloc(&coords, ((size_t) tiles + 1) * sizeof(Coord)));
     CK(hipMalloc(&g, (size_t) rows * 8)); CK(hipMalloc(&gabs, (size_t) rows * 8)); CK(hipMalloc(&worst, 8));
     hipLaunchKernelGGL(k_gen<V>, dim3((rows + 256) / 256), dim3(256), 0, 0, off, col, val, rows, cols, npr);
@@ -346,7 +485,7 @@ static void run(int rows, int cols, int npr)
            (int) sizeof(V) * 8, rows, cols, npr, nnz, tiles, cols * sizeof(V) * 1e-6, band_cols * sizeof(V) * 1e-6, balg * 1e-6,
            ((double) tiles * REGION * (sizeof(V) + 4) + (double) part_stride * NB * sizeof(V)) * 1e-6);
     auto A0 = [&] { hipLaunchKernelGGL(k_coords, dim3((tiles + 256) / 256), dim3(256), 0, 0, off, rows, (int) nnz, tiles, coords); };
-    auto A = [&] { hipLaunchKernelGGL(k_bin<V>, dim3(tiles), dim3(BLOCK), 0, 0, off, col, val, coords, band_cols, magic, bval, bpk, hdr); };
+    auto A = [&] { hipLaunchKernelGGL(k_bin<V>, dim3(tiles), dim3(BLOCK), 0, 0, off, col, val, coords, band_cols, magic, bval, bpk, hdr, meta, tiles); };
     auto C = [&] {
         hipLaunchKernelGGL(k_sum<V>, dim3((rows + 255) / 256), dim3(256), 0, 0, part, part_stride, y, rows);
         hipLaunchKernelGGL(k_carry<V>, dim3((tiles + 255) / 256), dim3(256), 0, 0, carry, coords, tiles, rows, y);
@@ -380,6 +519,16 @@ static void run(int rows, int cols, int npr)
         printf("bands: %d waves/block, %d blocks/CU : %.4f ms | whole SpMV %.4f ms = %.3f of 8 TB/s | worst |y - gold| / (eps * sum|v x|) = %.2f\n",
                waves, per_cu, tB, tAll, balg / (tAll * 1e-3) / 8e12, w);
     }
+    auto check = [&](const char* name, float tB, float tAll) {
+        CK(hipMemset(worst, 0, 8));
+        hipLaunchKernelGGL(k_cmp<V>, dim3((rows + 255) / 256), dim3(256), 0, 0, y, g, gabs, rows, sizeof(V) == 4 ? 5.96e-8 : 1.11e-16, worst);
+        unsigned long long wb; CK(hipMemcpy(&wb, worst, 8, hipMemcpyDeviceToHost));
+        double w; memcpy(&w, &wb, 8);
+        printf("bands2 %s : %.4f ms | whole SpMV %.4f ms = %.3f of 8 TB/s | worst %.2f\n", name, tB, tAll, balg / (tAll * 1e-3) / 8e12, w);
+    };
+#define RUN2(W, EE, PC) { const int grid = PC * cus; auto B = [&] { hipLaunchKernelGGL((k_bands2<V, W, EE>), dim3(grid), dim3(W * 64), 0, 0, bval, bpk, meta, x, band_cols, tiles, part, part_stride, carry); }; \
+        CK(hipMemset(part, 0xFF, part_stride * NB * sizeof(V))); const float tB = time_ms(B); const float tAll = time_ms([&] { A0(); A(); B(); C(); }); check(#W " waves, E = " #EE ", " #PC " blocks/CU", tB, tAll); }
+    RUN2(4, 4, 4) RUN2(4, 4, 8) RUN2(4, 8, 4) RUN2(4, 8, 8) RUN2(8, 8, 2) RUN2(8, 8, 4) RUN2(2, 8, 8) RUN2(2, 8, 16)
     CK(hipFree(off)); CK(hipFree(col)); CK(hipFree(val)); CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(bval)); CK(hipFree(bpk)); CK(hipFree(hdr));
     CK(hipFree(part)); CK(hipFree(carry)); CK(hipFree(coords)); CK(hipFree(g)); CK(hipFree(gabs)); CK(hipFree(worst));
 }
