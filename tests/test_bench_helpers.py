@@ -83,7 +83,7 @@ def _fake_detail(n_configs=9, long=False):
             "kernel_ms": 0.83412, "search_ms": 0.0102, "fixup_ms": 0.0067, "launches_timed": 200, "band_passes": 3, "note": pad}
     cfgs = [{"config": f"config number {i} with a long name {pad}", "label": "c", "workload": pad * 3, "data": "synthetic", "dtype": "f64", "rows": 1 << 24, "cols": 1 << 24,
              "nnz": 234366905, "steps": 50, "ms_per_step": 1.40935, "value": 332.6, "unit": "GFLOP/s", "tile": "256x11", "generation_s": 0.3,
-             "roofline": dict(roof, bound="ic" if i % 2 else "hbm", frac_hbm=0.4), "effective_GBs": 2865.2, "effective_pct_of_peak": 35.82,
+             "roofline": dict(roof, **({"ic_resident": True, "frac_ic": 0.9} if i % 2 else {})), "effective_GBs": 2865.2, "effective_pct_of_peak": 35.82,
              "sampled_check": {"rows_checked": 65539, "worst_ratio": 0.0601, "violations": 0, "longest_row": 123, "depth_term": 12}, "y_finite": True,
              "cpu": {"value": 93.1, "cores": 16, "runs": [pad] * 3}, "vendor": {"ms_per_step": 2.2, "note": pad}} for i in range(n_configs)]
     cfgs.append({"config": "one that failed", "error": "OutOfMemoryError: " + pad * 5})
@@ -142,7 +142,7 @@ def test_the_config_5_leg_of_an_n_gpu_run_rides_in_the_line():
 def test_nan_and_inf_never_reach_the_line():
     import json
     d = _fake_detail(2)
-    d["per_rank"]["exchange_ms_max"] = float("nan"); d["roofline"]["frac_hbm"] = float("inf"); d["configs"][0]["sampled_check"]["worst_ratio"] = float("nan")
+    d["per_rank"]["exchange_ms_max"] = float("nan"); d["roofline"]["frac_ic"] = float("inf"); d["configs"][0]["sampled_check"]["worst_ratio"] = float("nan")
     line = bench.compact_line(bench._finite(d))
     assert "NaN" not in line and "Infinity" not in line
     json.loads(line)
