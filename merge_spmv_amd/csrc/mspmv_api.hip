@@ -25,6 +25,10 @@ namespace mspmv {
 
 constexpr int SEARCH_BLOCK = 256;
 constexpr int INTERP_MIN_ROWS = 10000000;       // coordinate pass: interpolation search from here up, scatter pass below
+#ifndef MSPMV_MM_LANE_BLOCK
+#define MSPMV_MM_LANE_BLOCK 256
+#endif
+constexpr int MM_LANE_BLOCK = MSPMV_MM_LANE_BLOCK;      // threads per block of the slot form of SpMM (its tile stays 256 x 7 path items)
 constexpr int MM_CHUNK_LOG2 = 6;         // XCD-chunked mapping of the SpMM tiles: 0-3 %
 constexpr int FIX_BLOCK = 256;
 constexpr int FIX_IPT = 2;              // little serial work per thread: the fix-up is latency-bound (256x8: 14 us, 256x2: 9.5 us, 1024x16: 40 us)
@@ -794,8 +798,19 @@ template <typename T, int K> struct MMShape {
     static constexpr int IPT = PACK >= 32 ? 3 : 7;
     static constexpr int TILE = BLOCK * IPT;
 };
-constexpr int MM_TILES[3] = {256 * 7, 256 * 3, 128 * 3};      // tile sizes in use: index 0 narrow packs, 1: 32-byte, 2: 64-byte
-template <typename T, int K> constexpr int mm_tile_index() { return MMShape<T, K>::PACK >= 64 ? 2 : MMShape<T, K>::PACK >= 32 ? 1 : 0; }
+#ifndef MSPMV_MM_LANE_IPT
+#define MSPMV_MM_LANE_IPT 11
+#endif
+constexpr int MM_LANE_IPT = MSPMV_MM_LANE_IPT;
+constexpr int MM_TILES[4] = {256 * 7, 256 * 3, 128 * 3, 256 * MM_LANE_IPT};      // tile sizes in use: index 0 narrow packs, 1: 32-byte packs, 2: 64-byte, 3: the slot form
+// groups of 8 or 16 right-hand sides of at least 32 bytes run the lane-per-column kernel (spmm_lane_kernel) on the 256 x 7 tiles
+template <typename T, int K> constexpr int mm_lane_vec() { return K / 4 * (int) sizeof(T) <= 16 ? K / 4 : 16 / (int) sizeof(T); }   // right-hand sides per lane of the slot form: four lanes per slot, at most 16 bytes per lane
+// (`lane_ok`: X spans less than 4 GB -- the slot form keeps 32-bit byte offsets of X's rows in LDS; beyond that the packs serve)
+static constexpr bool mm_lane(int width, int elem_bytes) { return width >= 8 && width * elem_bytes >= 32; }
+static constexpr int mm_ti(int width, int elem_bytes, bool lane_ok)
+{
+    return lane_ok && mm_lane(width, elem_bytes) ? 3 : width * elem_bytes >= 64 ? 2 : width * elem_bytes >= 32 ? 1 : 0;
+}
 
 // generic row-per-thread fallback (arrays not 16-byte aligned, or fewer than 4 nonzeros / 3 rows)
 template <typename T>
@@ -816,35 +831,38 @@ template <typename T> struct MMPlan { int width[5], count[5], n; };
 // Wide packs (32 / 64 bytes: a whole row of X per gather, but small tiles and few resident waves) pay
 // when the gathers miss -- X larger than a cache -- and cost when they hit anyway: measured, a 2 KB X
 // (dense 32-column matrix) runs k = 16 in 1.00 ms with four 16-byte groups and 1.42 ms with one 64-byte
-// pack, a 200 MB X (C2) in 7.4 ms vs 1.9 ms.  The X footprint decides.
+// pack, a 200 MB X (C2) in 7.4 ms vs 1.9 ms.  The X footprint decides -- for the PACK kernel; groups of 8 / 16 columns run the
+// lane-per-column kernel whatever the footprint (round 6: the same two cases in 0.3 and 1.9 ms).
 template <typename T>
-static MMPlan<T> make_mm_plan(int k, bool wide)
+static MMPlan<T> make_mm_plan(int k, bool wide, bool lane_ok)
 {
     MMPlan<T> pl; pl.n = 0;
-    for (int w = (wide ? 64 : 16) / (int) sizeof(T); w >= 1; w >>= 1) {
+    for (int w = 16; w >= 1; w >>= 1) {
+        const bool lane = lane_ok && mm_lane(w, (int) sizeof(T));
+        if (!lane && (w * (int) sizeof(T) > 64 || !(wide || w * (int) sizeof(T) <= 16))) continue;
         pl.width[pl.n] = w; pl.count[pl.n] = k / w; k -= pl.count[pl.n] * w; ++pl.n;
     }
     return pl;
 }
 
-struct MMLayout { int num_tiles[3]; uint64_t coords_off[3], carries_off, total; };
+struct MMLayout { int num_tiles[4]; uint64_t coords_off[4], carries_off, total; };
 template <typename T>
-static MMLayout make_mm_layout(int rows, int nnz, int k, bool wide)
+static MMLayout make_mm_layout(int rows, int nnz, int k, bool wide, bool lane_ok)
 {
     MMLayout L; memset(&L, 0, sizeof(L));
     const long long total = (long long) rows + nnz;
-    const MMPlan<T> pl = make_mm_plan<T>(k, wide);
+    const MMPlan<T> pl = make_mm_plan<T>(k, wide, lane_ok);
     uint64_t off = 0, carry_bytes = 256;
-    bool used[3] = {false, false, false};
+    bool used[4] = {false, false, false, false};
     for (int i = 0; i < pl.n; ++i) {
         if (pl.count[i] == 0) continue;
         const int pack = pl.width[i] * (int) sizeof(T);
-        const int ti = pack >= 64 ? 2 : pack >= 32 ? 1 : 0;
+        const int ti = mm_ti(pl.width[i], (int) sizeof(T), lane_ok);
         used[ti] = true;
         const uint64_t tiles = (uint64_t) ((total + MM_TILES[ti] - 1) / MM_TILES[ti]);
         carry_bytes = std::max<uint64_t>(carry_bytes, (tiles > 0 ? tiles : 1) * pl.count[i] * (uint64_t) (sizeof(T) + pack));   // sizeof(CarryMM): key padded to the element size
     }
-    for (int ti = 0; ti < 3; ++ti) {
+    for (int ti = 0; ti < 4; ++ti) {
         L.num_tiles[ti] = (int) ((total + MM_TILES[ti] - 1) / MM_TILES[ti]);
         if (used[ti]) { L.coords_off[ti] = off; off = align256(off + uint64_t(L.num_tiles[ti] + 1) * sizeof(Coord)); }
     }
@@ -853,26 +871,34 @@ static MMLayout make_mm_layout(int rows, int nnz, int k, bool wide)
     return L;
 }
 
-template <typename T, int K>
+template <typename T, int K, bool LANE>
 static hipError_t run_mm_group(const MMLayout &L, char *base, MMParams<T> p, int groups, bool axpby, bool nt, hipStream_t stream,
                                int debug_sync)
 {
     typedef MMShape<T, K> S;
-    constexpr int ti = mm_tile_index<T, K>();
+    constexpr int ti = mm_ti(K, (int) sizeof(T), LANE);
     const Coord *coords = reinterpret_cast<const Coord *>(base + L.coords_off[ti]);
     CarryMM<T, K> *carries = reinterpret_cast<CarryMM<T, K> *>(base + L.carries_off);
     static_assert(sizeof(CarryMM<T, K>) == sizeof(T) + K * sizeof(T), "carry layout assumed by make_mm_layout");
-    const uintptr_t pack_bytes = K * sizeof(T);
+    const uintptr_t pack_bytes = LANE ? mm_lane_vec<T, K>() * sizeof(T) : K * sizeof(T);     // (the slot form: four lanes per slot, K / 4 right-hand sides per lane)
     p.x_vec = (reinterpret_cast<uintptr_t>(p.x) % pack_bytes == 0 && ((uintptr_t) p.ldx * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
     p.y_vec = (reinterpret_cast<uintptr_t>(p.y) % pack_bytes == 0 && ((uintptr_t) p.ldy * sizeof(T)) % pack_bytes == 0) ? 1 : 0;
     const int num_tiles = L.num_tiles[ti];
     const unsigned grid = (unsigned) num_tiles;
     constexpr int mm_chunk = MM_CHUNK_LOG2;
-#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, S::BLOCK, S::IPT, AX, NTF>), dim3(grid), dim3(S::BLOCK), 0, stream, p, coords, carries, num_tiles, groups, mm_chunk)
-    if (axpby) { if (nt) MSPMV_MM_LAUNCH(true, true); else MSPMV_MM_LAUNCH(true, false); }
-    else { if (nt) MSPMV_MM_LAUNCH(false, true); else MSPMV_MM_LAUNCH(false, false); }
+    if constexpr (LANE) {
+#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_lane_kernel<T, K, mm_lane_vec<T, K>(), MM_LANE_BLOCK, 256 * MM_LANE_IPT / MM_LANE_BLOCK, AX, NTF>), dim3(grid), dim3(MM_LANE_BLOCK), 0, stream, p, coords, carries, num_tiles, groups, mm_chunk)
+        if (axpby) { if (nt) MSPMV_MM_LAUNCH(true, true); else MSPMV_MM_LAUNCH(true, false); }
+        else { if (nt) MSPMV_MM_LAUNCH(false, true); else MSPMV_MM_LAUNCH(false, false); }
 #undef MSPMV_MM_LAUNCH
-    MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_tile_kernel", grid, S::BLOCK));
+        MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_lane_kernel", grid, MM_LANE_BLOCK));
+    } else {
+#define MSPMV_MM_LAUNCH(AX, NTF) hipLaunchKernelGGL((spmm_tile_kernel<T, K, S::BLOCK, S::IPT, AX, NTF>), dim3(grid), dim3(S::BLOCK), 0, stream, p, coords, carries, num_tiles, groups, mm_chunk)
+        if (axpby) { if (nt) MSPMV_MM_LAUNCH(true, true); else MSPMV_MM_LAUNCH(true, false); }
+        else { if (nt) MSPMV_MM_LAUNCH(false, true); else MSPMV_MM_LAUNCH(false, false); }
+#undef MSPMV_MM_LAUNCH
+        MSPMV_CHECK(after_launch(stream, debug_sync, "spmm_tile_kernel", grid, S::BLOCK));
+    }
     if (num_tiles > 1) {
         const unsigned fgrid = (unsigned) ((num_tiles + FIX_CHUNK - 1) / FIX_CHUNK);
         hipLaunchKernelGGL((spmm_fixup_kernel<T, K, FIX_BLOCK, FIX_IPT>), dim3(fgrid, (unsigned) groups), dim3(FIX_BLOCK), 0, stream, carries, num_tiles,
@@ -883,11 +909,17 @@ static hipError_t run_mm_group(const MMLayout &L, char *base, MMParams<T> p, int
 }
 
 template <typename T, int W>
-static hipError_t run_mm_width(int width, const MMLayout &L, char *base, const MMParams<T> &p, int groups, bool axpby, bool nt,
+static hipError_t run_mm_width(int width, bool lane_ok, const MMLayout &L, char *base, const MMParams<T> &p, int groups, bool axpby, bool nt,
                                hipStream_t stream, int debug_sync)
 {
-    if (width == W) return run_mm_group<T, W>(L, base, p, groups, axpby, nt, stream, debug_sync);
-    if constexpr (W > 1) return run_mm_width<T, W / 2>(width, L, base, p, groups, axpby, nt, stream, debug_sync);
+    if (width == W) {
+        if constexpr (mm_lane(W, (int) sizeof(T))) {
+            if (lane_ok) return run_mm_group<T, W, true>(L, base, p, groups, axpby, nt, stream, debug_sync);
+        }
+        if constexpr (W * sizeof(T) <= 64) return run_mm_group<T, W, false>(L, base, p, groups, axpby, nt, stream, debug_sync);
+        else return hipErrorInvalidValue;
+    }
+    if constexpr (W > 1) return run_mm_width<T, W / 2>(width, lane_ok, L, base, p, groups, axpby, nt, stream, debug_sync);
     return hipErrorInvalidValue;
 }
 
@@ -898,12 +930,29 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
 {
     if (!temp_bytes || rows < 0 || cols < 0 || nnz < 0 || k < 0 || ldx < k || ldy < k) return hipErrorInvalidValue;
     if ((long long) rows + nnz > MAX_ITEMS) return hipErrorInvalidValue;
-    const bool wide = (unsigned long long) cols * (unsigned long long) ldx * sizeof(T) > (1ull << 20);
-    const MMLayout L = make_mm_layout<T>(rows, nnz, k, wide);
-    if (d_temp == nullptr) { *temp_bytes = (size_t) L.total; return hipSuccess; }
-    if (*temp_bytes < L.total || (reinterpret_cast<uintptr_t>(d_temp) & 15)) return hipErrorInvalidValue;
+    const unsigned long long x_bytes = (unsigned long long) cols * (unsigned long long) ldx * sizeof(T);
+    const bool wide = x_bytes > (1ull << 20);
+    // the slot form (groups of 8 / 16 columns): 32-bit byte offsets into X, and enough tiles to fill the chip (its blocks live long:
+    // R-MAT scale 20, 4 M path items, k = 8: 0.152 ms against the packs' 0.08)
+    const bool lane_ok = x_bytes < (1ull << 32) && (long long) rows + nnz >= (8ll << 20);
+    const MMLayout L = make_mm_layout<T>(rows, nnz, k, wide, lane_ok);
+    // one right-hand side stored as a plain vector IS CsrMV: the call goes there (one launch, the column-band passes, the
+    // compact front end) -- the temp storage asked for covers both layouts
+    const bool as_csrmv = k == 1 && ldx == 1 && ldy == 1;
+    size_t need = (size_t) L.total;
+    if (as_csrmv) {
+        size_t mv = 0;
+        const int st = csrmv_impl<T>(nullptr, &mv, nullptr, nullptr, nullptr, nullptr, nullptr, rows, cols, nnz, alpha, beta, true, stream_, 0);
+        if (st != 0) return st;
+        need = std::max(need, mv);
+    }
+    if (d_temp == nullptr) { *temp_bytes = need; return hipSuccess; }
+    if (*temp_bytes < need || (reinterpret_cast<uintptr_t>(d_temp) & 15)) return hipErrorInvalidValue;
     if (rows == 0 || k == 0) return hipSuccess;
     if (!d_row_offsets || !d_y || (nnz > 0 && (!d_values || !d_cols || !d_x))) return hipErrorInvalidValue;
+    if (as_csrmv)
+        return csrmv_impl<T>(d_temp, temp_bytes, d_values, d_row_offsets, d_cols, d_x, d_y, rows, cols, nnz, alpha, beta,
+                             !(alpha == (T) 1 && beta == (T) 0), stream_, debug_sync);
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const bool vec = nnz >= 4 && rows >= 3 &&
                      ((reinterpret_cast<uintptr_t>(d_values) | reinterpret_cast<uintptr_t>(d_cols) |
@@ -916,8 +965,8 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
         return (int) after_launch(stream, debug_sync, "spmm_rowwise_kernel", grid, 256);
     }
     char *base = static_cast<char *>(d_temp);
-    const MMPlan<T> pl = make_mm_plan<T>(k, wide);
-    bool have_coords[3] = {false, false, false};
+    const MMPlan<T> pl = make_mm_plan<T>(k, wide, lane_ok);
+    bool have_coords[4] = {false, false, false, false};
     const bool axpby = !(alpha == (T) 1 && beta == (T) 0);
     const unsigned long long stream_bytes = (unsigned long long) nnz * (sizeof(T) + 4) + 4ull * rows;
     const bool nt = stream_bytes > (200ull << 20);
@@ -927,20 +976,20 @@ static int csrmm_impl(void *d_temp, size_t *temp_bytes, const T *d_values, const
     int c = 0;
     for (int i = 0; i < pl.n; ++i) {
         if (pl.count[i] == 0) continue;
-        const int pack = pl.width[i] * (int) sizeof(T);
-        const int ti = pack >= 64 ? 2 : pack >= 32 ? 1 : 0;
+        const int ti = mm_ti(pl.width[i], (int) sizeof(T), lane_ok);
         if (!have_coords[ti]) {                   // tile coordinates for this tile size, once
             Coord *coords = reinterpret_cast<Coord *>(base + L.coords_off[ti]);
             const long long threads = ((long long) rows + 1 + 3) / 4;
             const unsigned grid = (unsigned) ((threads + SEARCH_BLOCK - 1) / SEARCH_BLOCK);
             if (ti == 0) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 7, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[0], BoundaryOut{coords, nullptr}, BandDetectArgs{});
+            else if (ti == 3) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * MM_LANE_IPT, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[3], BoundaryOut{coords, nullptr}, BandDetectArgs{});
             else if (ti == 1) hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 256 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[1], BoundaryOut{coords, nullptr}, BandDetectArgs{});
             else hipLaunchKernelGGL((coords_scatter_kernel<SEARCH_BLOCK, 128 * 3, true>), dim3(grid), dim3(SEARCH_BLOCK), 0, stream, d_row_offsets, rows, nnz, L.num_tiles[2], BoundaryOut{coords, nullptr}, BandDetectArgs{});
             MSPMV_CHECK(after_launch(stream, debug_sync, "coords_scatter_kernel", grid, SEARCH_BLOCK));
             have_coords[ti] = true;
         }
         p.x = d_x + c; p.y = d_y + c;
-        const hipError_t e = run_mm_width<T, 64 / (int) sizeof(T)>(pl.width[i], L, base, p, pl.count[i], axpby, nt, stream, debug_sync);
+        const hipError_t e = run_mm_width<T, 16>(pl.width[i], lane_ok, L, base, p, pl.count[i], axpby, nt, stream, debug_sync);
         if (e != hipSuccess) return (int) e;
         c += pl.count[i] * pl.width[i];
     }

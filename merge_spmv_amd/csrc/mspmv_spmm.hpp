@@ -335,6 +335,191 @@ __global__ __launch_bounds__(BLOCK) void spmm_tile_kernel(MMParams<T> p, const C
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Slot form, for groups of SW = 8 or 16 right-hand sides (round 6).  The pack kernel above carries K-wide products through LDS
+// and a block-wide scan: with 32- and 64-byte packs that is 20-45 KB of LDS traffic per kilobyte of matrix, tiles of 384-768
+// path items and few resident waves (dense 32-column matrix, k = 16: 1.0 ms for a 0.13 ms stream).  Here a SLOT of
+// LS = SW / VEC adjacent lanes owns one contiguous share of the tile's nonzeros and every lane of it VEC = 16 bytes' worth of
+// adjacent right-hand sides: the slot reads (col, val) from the tile staged in LDS (one broadcast read per nonzero), its lanes
+// fetch X[col, c0 .. c0+SW) as ONE coalesced 32/64-byte piece (16 bytes per lane) and accumulate in registers; rows that begin
+// and end inside the share are written straight to Y (one piece), a share's first and last row pieces meet through an LDS table
+// of NS = BLOCK / LS partial rows, added in slot order (deterministic).  The tile's open row leaves as the same CarryMM the pack
+// kernel writes: one fix-up serves both.  Tiles are merge-path tiles (rows + nonzeros bounded), the nonzero shares inside a tile
+// are equal whatever the row lengths.
+template <typename T, int SW, int VEC, int BLOCK, int IPT, bool AXPBY, bool NT>
+__global__ __launch_bounds__(BLOCK) void spmm_lane_kernel(MMParams<T> p, const Coord *__restrict__ coords,
+                                                          CarryMM<T, SW> *__restrict__ carries, int num_tiles, int groups,
+                                                          int xcd_chunk_log2)
+{
+    static_assert(SW == 8 || SW == 16, "group width");
+    static_assert(VEC * sizeof(T) <= 16 && SW % VEC == 0, "right-hand sides per lane: at most 16 bytes");
+    constexpr int LS = SW / VEC;                        // lanes per slot
+    constexpr int ITEMS = BLOCK * IPT;
+    constexpr int NS = BLOCK / LS;                      // slots per block
+    constexpr int U = 4;                                // nonzeros of a slot in flight per step (two steps are)
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    // (both arrays are indexed in ARRAY space -- position sh + e for the tile's nonzero e, sh = the tile's first nonzero modulo 4 --
+    //  so that a 16-byte chunk of the CSR arrays is one 16-byte LDS store)
+    __shared__ __attribute__((aligned(16))) unsigned s_off[ITEMS + 8];      // byte offset of X's row: col * ldx * sizeof(T) (the host checked that X spans < 4 GB)
+    __shared__ __attribute__((aligned(16))) T s_val[ITEMS + 8];
+    __shared__ int s_end[ITEMS];                        // row ends, relative to the tile's first nonzero
+    __shared__ int s_prow[NS];                          // every slot's last row piece: local row (-1: the slot has no nonzeros) ...
+    __shared__ __attribute__((aligned(16))) T s_pacc[NS][SW];      // ... and its sums
+    const int tid = threadIdx.x;
+    const int tile = xcd_chunked_tile((int) blockIdx.x, num_tiles, xcd_chunk_log2);
+    const Coord c0 = coords[tile];
+    const Coord c1 = coords[tile + 1];
+    const int tile_rows = c1.x - c0.x;
+    const int tile_nnz = c1.y - c0.y;
+    const unsigned ldx = (unsigned) p.ldx, ldy = (unsigned) p.ldy;
+    const unsigned ldx_bytes = ldx * (unsigned) sizeof(T);
+    const int sh = c0.y & 3;
+
+    // ---- staging (once per tile): 16-byte loads of chunks aligned in array space, the ragged array tail element by element
+    int empty_rows = 0;
+    {
+        const int a0 = c0.y & ~3;
+        const int chunks = (tile_nnz + sh + 3) >> 2;
+        const int full = p.nnz & ~3;
+        for (int ch = tid; ch < chunks; ch += BLOCK) {
+            const int g0 = a0 + 4 * ch;
+            int cc[4]; T vv[4];
+            if (g0 + 4 <= full) {
+                const Vec4<int> c4 = ld_stream4<NT>(p.cols + g0);
+                const Vec4<T> v4 = ld_stream4<NT>(p.values + g0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { cc[i] = c4.get(i); vv[i] = v4.get(i); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const bool in = g0 + i < p.nnz; cc[i] = in ? p.cols[g0 + i] : 0; vv[i] = in ? p.values[g0 + i] : (T) 0; }
+            }
+            int4v o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (int) ((unsigned) cc[i] * ldx_bytes);
+            *reinterpret_cast<int4v *>(&s_off[4 * ch]) = o;
+            st_lds4(&s_val[4 * ch], vv);
+        }
+        for (int r = tid; r < tile_rows; r += BLOCK) {
+            const int e = p.row_end[c0.x + r] - c0.y;
+            s_end[r] = e;
+            const int prev = r > 0 ? p.row_end[c0.x + r - 1] - c0.y : 0;        // (the neighbour's load: the same cache line)
+            empty_rows |= e == prev;
+        }
+    }
+    const int has_empty = __syncthreads_or(empty_rows);              // (also the barrier behind the staging)
+
+    const int slot = tid / LS, c = (tid % LS) * VEC;                 // this lane's first right-hand side within the group
+    const int i_begin = (int) ((long long) tile_nnz * slot / NS);
+    const int i_end = (int) ((long long) tile_nnz * (slot + 1) / NS);
+    int r0;                                                          // the row of nonzero i_begin: the first row that ends beyond it
+    {
+        int lo = 0, hi = tile_rows;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_end[mid] > i_begin) hi = mid; else lo = mid + 1; }
+        r0 = lo;
+    }
+    const bool xv = p.x_vec != 0, yv = p.y_vec != 0;                 // this lane's pieces of X / Y are aligned: one vector access each
+
+    auto ldv = [&](const T *src, bool aligned) {
+        vecT r;
+        if (aligned) r = *reinterpret_cast<const vecT *>(src);
+        else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) r[k] = src[k];
+        }
+        return r;
+    };
+    auto stv = [&](T *dst, vecT v, bool aligned) {
+        if (aligned) *reinterpret_cast<vecT *>(dst) = v;
+        else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dst[k] = v[k];
+        }
+    };
+
+    for (int g = 0; g < groups; ++g) {
+        const char *__restrict__ xg = reinterpret_cast<const char *>(p.x + (size_t) g * SW + c);
+        T *__restrict__ yg = p.y + (size_t) g * SW + c + (size_t) c0.x * ldy;
+        auto put = [&](int row, vecT sum) {
+            T *dst = yg + (size_t) row * ldy;
+            if (AXPBY) { sum = p.alpha * sum; if (p.beta != (T) 0) sum += p.beta * ldv(dst, yv); }
+            stv(dst, sum, yv);
+        };
+        int r = r0;
+        int cur_end = r < tile_rows ? s_end[r] : 0x7fffffff;
+        vecT acc = (T) 0, first_acc = (T) 0;
+        int first_row = -1;
+        // a step: U nonzeros of the share; their X pieces are requested one step ahead (two register sets, no copies)
+        auto fetch = [&](int i, T (&vv)[U], vecT (&xx)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pos = i + u < i_end ? i + u : i_end - 1;           // (clamped: a step past the share's end re-reads its last nonzero)
+                vv[u] = s_val[sh + pos];
+                xx[u] = ldv(reinterpret_cast<const T *>(xg + s_off[sh + pos]), xv);
+            }
+        };
+        auto consume = [&](int i, const T (&vv)[U], const vecT (&xx)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pos = i + u;
+                if (pos < i_end) {
+                    if (pos >= cur_end) {                              // the row ended before this nonzero (then empty rows, if any)
+                        if (first_row < 0) { first_row = r; first_acc = acc; } else put(r, acc);
+                        acc = (T) 0;
+                        do { ++r; cur_end = r < tile_rows ? s_end[r] : 0x7fffffff; } while (pos >= cur_end);
+                    }
+                    acc += vv[u] * xx[u];
+                }
+            }
+        };
+        T va[U], vb[U]; vecT xa[U], xb[U];
+        int i = i_begin;
+        if (i < i_end) fetch(i, va, xa);
+        while (i < i_end) {
+            if (i + U < i_end) fetch(i + U, vb, xb);
+            consume(i, va, xa);
+            i += U;
+            if (i >= i_end) break;
+            if (i + U < i_end) fetch(i + U, va, xa);
+            consume(i, vb, xb);
+            i += U;
+        }
+        const bool mine = i_begin < i_end;
+        if (c == 0) s_prow[slot] = mine ? r : -1;
+        *reinterpret_cast<vecT *>(&s_pacc[slot][c]) = acc;
+        __syncthreads();
+        // the pieces of `row` that earlier slots hold (a run of slots right before this one), added in slot order
+        auto before = [&](int row) {
+            int j = slot - 1;
+            while (j >= 0 && (s_prow[j] == row || s_prow[j] == -1)) --j;
+            vecT s = (T) 0;
+            for (++j; j < slot; ++j) if (s_prow[j] == row) s += *reinterpret_cast<const vecT *>(&s_pacc[j][c]);
+            return s;
+        };
+        if (first_row >= 0) put(first_row, before(first_row) + first_acc);          // the share's first row ended inside it
+        if (mine && cur_end == i_end && r < tile_rows)                                // its last row ends exactly where the share ends
+            put(r, before(r) + acc);
+        if (slot == NS - 1) {                                                          // the tile's open row: one carry
+            vecT s = (T) 0;
+            for (int j = 0; j < NS; ++j) if (s_prow[j] == tile_rows) s += *reinterpret_cast<const vecT *>(&s_pacc[j][c]);
+            CarryMM<T, SW> *cr = carries + (size_t) g * num_tiles + tile;
+            if (c == 0) cr->key = c0.x + tile_rows;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) cr->value.v[c + k] = s[k];
+        }
+        if (has_empty) {                                                               // rows without a nonzero in this tile
+            for (int idx = tid; idx < tile_rows * SW; idx += BLOCK) {
+                const int rr = idx / SW, cc = idx % SW;
+                if (s_end[rr] == (rr > 0 ? s_end[rr - 1] : 0)) {
+                    T *dst = p.y + (size_t) g * SW + cc + (size_t) (c0.x + rr) * ldy;
+                    *dst = (AXPBY && p.beta != (T) 0) ? p.beta * *dst : (T) 0;
+                }
+            }
+        }
+        __syncthreads();                                                               // the table is read before the next group writes it
+    }
+}
+
 // One-launch fix-up over pack-valued carries: fixup_onepass_kernel of mspmv_kernels.hpp with
 // Y[key, :] += alpha * sum.
 template <typename T, int K, int BLOCK, int IPT>

@@ -199,11 +199,17 @@ def test_extension_entry_points_follow_the_same_conventions():
     assert lib.mspmv_csrmv_prepare(None, ctypes.byref(size), None, 1000, 50000, 2, None, 0) == 1
     for fn in (lib.mspmv_csrmm_f32, lib.mspmv_csrmm_f64):
         sizes = []
-        for k, cols in ((1, 1000), (4, 1000), (16, 1000), (16, 10_000_000)):      # narrow packs ... 64-byte packs (X > 1 MiB)
+        for k, cols in ((2, 1000), (4, 1000), (16, 1000), (16, 10_000_000)):      # narrow packs ... 64-byte packs (X > 1 MiB)
             st = fn(None, ctypes.byref(size), None, None, None, None, k, None, k, 1000, cols, 50000, k, 1.0, 0.0, None, 0)
             assert st == 0 and size.value > 0
             sizes.append(size.value)
         assert sizes[1] >= sizes[0] and sizes[3] > sizes[2]          # more / wider carries, smaller tiles
+        # 8 M path items and more: groups of 8 / 16 columns run the slot form on its own 256 x 11 tiles whatever X's footprint
+        big = []
+        for cols in (1000, 10_000_000):
+            assert fn(None, ctypes.byref(size), None, None, None, None, 16, None, 16, 1_000_000, cols, 9_000_000, 16, 1.0, 0.0, None, 0) == 0
+            big.append(size.value)
+        assert big[0] == big[1]
         assert fn(None, ctypes.byref(size), None, None, None, None, 3, None, 4, 1000, 1000, 50000, 4, 1.0, 0.0, None, 0) == 1   # ldx < k
         assert fn(None, ctypes.byref(size), None, None, None, None, 4, None, 4, -1, 1000, 5, 4, 1.0, 0.0, None, 0) == 1
         small = ctypes.c_size_t(16)

@@ -767,7 +767,9 @@ def _check_csrmm(M, csr, X, Y, alpha=1.0, beta=0.0, Y0=None):
         want = alpha * g + (beta * Y0[:, c].astype(np.float64) if beta != 0.0 else 0.0)
         eps = 2.0 ** -24 if csr.values.dtype == np.float32 else 2.0 ** -53
         lens = np.diff(csr.row_offsets.astype(np.int64))
-        cc = 2.0 * (np.ceil(np.log2(lens + 1)) + 8 + 8)            # 8 products per thread in the SpMM tile
+        # 8 products per thread in the pack kernel's tile; a slot of the slot form (groups of 8 / 16 columns, large matrices) adds up to
+        # 2816 / 32 = 88 products one after the other, then the pieces of a row meet slot by slot (up to 64 per tile)
+        cc = 2.0 * (np.ceil(np.log2(lens + 1)) + 8 + 8) + np.minimum(lens, 160)
         tol = cc * eps * (abs(alpha) * s + (abs(beta) * np.abs(Y0[:, c]) if beta != 0.0 else 0.0)) + (0 if alpha == 1.0 and beta == 0.0 else 4 * eps * np.abs(want))
         got = Y[:, c].astype(np.float64)
         bad = np.abs(got - want) > tol
@@ -795,6 +797,41 @@ def test_csrmm_matches_the_oracle_column_by_column(M, prec, k):
     Y0 = rng.uniform(-1, 1, size=(csr.rows, k)).astype(dtype)
     Yw = torch.zeros(csr.rows, k + 2, dtype=Y.dtype, device="cuda"); Yv = Yw[:, 2:2 + k]; Yv.copy_(dev(Y0))
     M.csrmm(dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices), Xv, Y=Yv, alpha=-1.5, beta=0.5)
+    _check_csrmm(M, csr, X, Yv.cpu().numpy(), alpha=-1.5, beta=0.5, Y0=Y0)
+    assert float(Yw[:, :2].abs().max()) == 0.0                      # nothing outside the view was written
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_csrmm_slot_form_on_large_matrices(M, prec):
+    """Groups of 8 / 16 right-hand sides of matrices with >= 8 M path items run the slot form (spmm_lane_kernel: four or eight lanes
+    per nonzero share, rows written straight from registers, a share's first / last row pieces meeting through LDS).  A matrix with
+    everything that form distinguishes -- runs of empty rows, rows of one nonzero, rows longer than a share, longer than a tile,
+    a giant row over hundreds of tiles, row ends on share and tile boundaries -- for k = 8, 16, 24 and 13 (8 + 4 + 1: the packs
+    beside it), unaligned views, alpha / beta; every column against the oracle, bit for bit reproducible."""
+    dtype, vb = DT[prec]
+    rng = np.random.default_rng(2024)
+    rows = 260000
+    lens = np.minimum((rng.pareto(1.1, rows) * 6).astype(np.int64), 30000)
+    lens[1000:9000] = 0                                  # a run of empty rows across several tiles
+    lens[20000:20400] = 44                               # rows of exactly one share (fp32 k = 16), back to back
+    lens[30000:30100] = 2816                             # rows of exactly one tile's items
+    lens[40000] = 1_500_000                              # a giant row: ~530 tiles
+    lens[40001:40050] = 0
+    lens[50000:90000:7] = 1
+    csr = random_csr(rng, rows, 70000, lens, dtype)
+    assert csr.rows + csr.nnz >= (8 << 20)
+    vals, offs, cols = dev(csr.values), dev(csr.row_offsets), dev(csr.column_indices)
+    for k in (8, 16, 24, 13):
+        X = rng.uniform(-1, 1, size=(csr.cols, k)).astype(dtype)
+        Y = M.csrmm(vals, offs, cols, dev(X))
+        _check_csrmm(M, csr, X, Y.cpu().numpy())
+        assert torch.equal(Y, M.csrmm(vals, offs, cols, dev(X)))
+    k = 16
+    X = rng.uniform(-1, 1, size=(csr.cols, k)).astype(dtype)
+    Xw = torch.zeros(csr.cols, k + 3, dtype=vals.dtype, device="cuda"); Xv = Xw[:, 1:1 + k]; Xv.copy_(dev(X))
+    Y0 = rng.uniform(-1, 1, size=(csr.rows, k)).astype(dtype)
+    Yw = torch.zeros(csr.rows, k + 2, dtype=vals.dtype, device="cuda"); Yv = Yw[:, 2:2 + k]; Yv.copy_(dev(Y0))
+    M.csrmm(vals, offs, cols, Xv, Y=Yv, alpha=-1.5, beta=0.5)
     _check_csrmm(M, csr, X, Yv.cpu().numpy(), alpha=-1.5, beta=0.5, Y0=Y0)
     assert float(Yw[:, :2].abs().max()) == 0.0                      # nothing outside the view was written
 

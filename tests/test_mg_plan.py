@@ -328,11 +328,11 @@ def test_hot_columns_are_automatic():
 
 @gpu
 def test_bench_multi_rank_path_on_one_device():
-    """bench.py --gpus N (N > 1 runs BASELINE config 5, one R-MAT matrix cut N ways) end to end on this one-GPU box, at a
+    """bench.py --gpus N --workload c5 (BASELINE config 5, one R-MAT matrix cut N ways) end to end on this one-GPU box, at a
     reduced scale: (a) 2 ranks sharing the device, carries over gloo through the Python twin; (b) ONE rank forced through
     the N > 1 code path: nccl process group, shipped RCCL id, the C operator's multi-process form with its
     ncclAllGather inside the timed loop, the same-job single-GPU leg."""
-    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000")
+    small = ("--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000", "--workload", "c5")
     out = _run_bench({"MSPMV_BENCH_ONE_DEVICE": "1", "MSPMV_BENCH_BACKEND": "gloo"}, 2, *small)
     assert out["per_rank"]["tile_ms_max"] >= out["per_rank"]["tile_ms_min"] > 0 and out["per_rank"]["nnz_per_rank_max"] > 0
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f64" and out["value"] > 0
@@ -371,18 +371,24 @@ def _run_bench_plain(env_extra, *args, timeout=900):
 def test_bench_gpus_n_starts_its_own_ranks():
     """the driver's plain `python bench.py --gpus N --steps K --warmup W` must produce the line by itself.  Here
     N = 2 on this one-GPU box (MSPMV_BENCH_ONE_DEVICE=1: both ranks on cuda:0, gloo process group, the C operator with its
-    exchange falling back rccl -> hipIpc on every rank together); the JSON line is the last line of stdout."""
+    exchange falling back rccl -> hipIpc on every rank together); the JSON line is the last line of stdout.  The headline is BASELINE
+    config 2 weak-scaled (every rank holds the N = 1 line's matrix, so a scaling series compares like with like); config 5, one R-MAT
+    matrix cut N ways, rides as the `c5_strong` leg of the same job."""
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         detail = os.path.join(tmp, "detail.json")
         r = _run_bench_plain({"MSPMV_BENCH_ONE_DEVICE": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--c5-scale", "18", "--c5-edges", "3000000",
-                             "--detail", detail)
+                             "--c5-single-gpu-leg", "--detail", detail)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert len(r.stdout.splitlines()[-1].encode()) < 4096
         out = _line_and_detail(r.stdout, detail)
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["dtype"] == "f32" and out["value"] > 0
+    assert "C2 uniform CSR: 6250000 x 3125000" in out["config"]["workload"] and out["per_rank"]["nnz_per_rank_max"] == 100_000_000
     assert out["exchange"]["exchange"] == MG.EXCHANGE_IPC and out["exchange"]["fallbacks"][0]["exchange"] == "rccl"
-    assert out["per_rank"]["nnz_per_rank_max"] > 0 and out["single_gpu_same_workload"]["value"] > 0
-    cmp = out["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]
+    c5 = out["c5_strong"]
+    assert c5["n_gpus"] == 2 and c5["scaling"] == "strong" and c5["dtype"] == "f64" and c5["value"] > 0 and "C5 R-MAT scale 18" in c5["config"]["workload"]
+    assert c5["per_rank"]["nnz_per_rank_max"] > 0 and c5["single_gpu_same_workload"]["value"] > 0
+    cmp = c5["single_gpu_same_workload"]["rank0_rows_vs_single_gpu"]
     assert cmp["not_bitwise_equal"] == 0 or cmp["rows"] - cmp["first_differing_row"] <= cmp["tile_items"]
 
 
