@@ -93,7 +93,10 @@ int mspmv_csrmv_axpby_f64(void *d_temp, size_t *temp_bytes, const double *d_valu
  * the k entries X[col, :] that one column index needs are contiguous, so one gather serves a pack
  * of right-hand sides -- up to 16 bytes of them on the CsrMV-sized tiles, and 32 or 64 bytes (a whole
  * row of X) on smaller tiles when X is larger than 1 MiB, i.e. when its gathers miss the caches;
- * wider blocks run as several groups of the widest pack inside one pass over the matrix.  Same two-phase temp storage, ownership, stream and error
+ * wider blocks run as several groups of the widest pack inside one pass over the matrix.  Matrices of 8 M path items and more
+ * (X below 4 GB) take groups of 8 / 16 right-hand sides through the slot form instead (mspmv_spmm.hpp: spmm_lane_kernel -- every
+ * nonzero share of a tile walked by four or eight lanes holding 16 bytes of right-hand sides each, rows written from registers);
+ * ONE right-hand side stored as a plain vector (k = ldx = ldy = 1) is the CsrMV call.  Same two-phase temp storage, ownership, stream and error
  * conventions as mspmv_csrmv_*; with beta == 0 the old Y is never read.  Results per column are
  * within the same tolerance as CsrMV and bitwise reproducible.  No reference counterpart (the
  * reference ships CsrMV only). ---- */
