@@ -804,7 +804,9 @@ template <typename T, int K> struct MMShape {
 constexpr int MM_LANE_IPT = MSPMV_MM_LANE_IPT;
 constexpr int MM_TILES[4] = {256 * 7, 256 * 3, 128 * 3, 256 * MM_LANE_IPT};      // tile sizes in use: index 0 narrow packs, 1: 32-byte packs, 2: 64-byte, 3: the slot form
 // groups of 8 or 16 right-hand sides of at least 32 bytes run the lane-per-column kernel (spmm_lane_kernel) on the 256 x 7 tiles
-template <typename T, int K> constexpr int mm_lane_vec() { return K / 4 * (int) sizeof(T) <= 16 ? K / 4 : 16 / (int) sizeof(T); }   // right-hand sides per lane of the slot form: four lanes per slot, at most 16 bytes per lane
+// right-hand sides per lane of the slot form: four lanes per slot, at most 16 bytes per lane (32 bytes per lane, two lanes per slot:
+// 146-158 registers, 20-70 % slower on every matrix tried)
+template <typename T, int K> constexpr int mm_lane_vec() { return K / 4 * (int) sizeof(T) <= 16 ? K / 4 : 16 / (int) sizeof(T); }
 // (`lane_ok`: X spans less than 4 GB -- the slot form keeps 32-bit byte offsets of X's rows in LDS; beyond that the packs serve)
 static constexpr bool mm_lane(int width, int elem_bytes) { return width >= 8 && width * elem_bytes >= 32; }
 static constexpr int mm_ti(int width, int elem_bytes, bool lane_ok)
