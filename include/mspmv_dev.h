@@ -59,6 +59,14 @@ int mspmv_set_tuning(int32_t value_bytes, int32_t block_threads,
  *   passes < 0  never
  *   passes >= 2 always that many passes, on any call that takes the 256x11 tile or, in fp64, the 256x7 tile (tests, tuning). */
 int mspmv_set_band_passes(int32_t value_bytes, int32_t passes);
+/* Clock-scheduled column bands (csrc/mspmv_tdm.hpp): the ONE-pass form of the same organisation, offered to the same calls --
+ * a block sorts its tile's nonzeros by column band in LDS and gathers band by band, the band "on air" being read off the
+ * chip-wide 100 MHz clock, so every XCD's L2 holds a band or two of x while the CSR stream is read once.  y is bit for bit
+ * the one-sweep result (mspmv_set_band_passes(vb, -1)).
+ *   policy = 0 the library's rule (default), < 0 never (the passes as before), > 0 always where the passes are offered;
+ *   slot_permille: the on-air time of a band in per mille of the computed one (0 = 1000); lookahead_plus_1: bands after the
+ *   one on air a block may take, plus one (0 = the default, 2 bands); band_shift: log2 of the columns per band (0 = 18). */
+int mspmv_set_tdm(int32_t value_bytes, int32_t policy, int32_t slot_permille, int32_t lookahead_plus_1, int32_t band_shift);
 /* Testing aid (per HOST THREAD, like mspmv_set_tuning): how often a tile of the one-launch kernel in which a long row ENDS
  * looks for the partial sum another workgroup publishes before it computes that sum itself from the matrix (0 = the
  * library default, ~0.1 s of polling; 1 = one look; < 0 = never look, which sends every such tile down the recomputing path).  The

@@ -18,7 +18,7 @@ import os
 from typing import Optional, Tuple
 
 __all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "CsrMVPlan", "plan_bench_record", "library_path", "load_library", "launch_info",
-           "set_tuning", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
+           "set_tuning", "set_tdm", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
            "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -677,6 +677,12 @@ def profile_end() -> dict:
 def set_band_passes(value_bytes: int, passes: int = 0) -> None:
     """Column-band passes (mspmv_set_band_passes): 0 automatic, < 0 never, >= 2 always that many."""
     _setter("mspmv_set_band_passes", passes == 0, int(value_bytes), int(passes))
+
+
+def set_tdm(value_bytes: int, policy: int = 0, slot_permille: int = 0, lookahead_plus_1: int = 0, band_shift: int = 0) -> None:
+    """Clock-scheduled column bands (mspmv_set_tdm): policy 0 the library's rule, < 0 never (the passes), > 0 always where the passes are offered."""
+    _setter("mspmv_set_tdm", policy == 0 and slot_permille == 0 and lookahead_plus_1 == 0 and band_shift == 0,
+            int(value_bytes), int(policy), int(slot_permille), int(lookahead_plus_1), int(band_shift))
 
 
 def device_caches() -> dict:

@@ -19,6 +19,7 @@
 #include "../../include/mspmv.h"
 #include "mspmv_internal.hpp"
 #include "mspmv_kernels.hpp"
+#include "mspmv_tdm.hpp"
 #include "mspmv_spmm.hpp"
 
 namespace mspmv {
@@ -274,6 +275,18 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     const double r = (double) x_bytes / (double) dc.l2_bytes;
     if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : 0;
     return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : 0;
+}
+
+// Clock-scheduled column bands (mspmv_tdm.hpp) instead of the passes, for a call band_passes_for offers them to: the band width
+// (columns per band = 2^shift; 2^18 = 1 MiB of fp32 / 2 MiB of fp64 x, the prototype's best) -- widened until 32 bands cover x.
+// 0 = the passes.  Measured on C2 (tools/tdm_spmv.hip): fp32 0.64 ms against the passes' 0.83, fp64 1.02 against 1.30.
+static int tdm_shift_for(long long cols, int band_passes, const CallExtra &ex)
+{
+    if (band_passes <= 1 || ex.tune.tdm < 0) return 0;
+    int shift = ex.tune.tdm_band_shift > 0 ? ex.tune.tdm_band_shift : 18;
+    while (shift < TDM_SLOT_SHIFT && ((cols + (1LL << shift) - 1) >> shift) > TDM_MAX_BANDS) ++shift;
+    if (((cols + (1LL << shift) - 1) >> shift) > TDM_MAX_BANDS || shift > TDM_SLOT_SHIFT) return 0;
+    return shift;
 }
 
 // CU count of the current device, queried once per device (never on the hot path again).
@@ -611,6 +624,30 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                     ba.verdict = band_verdict; ba.counters = band_verdict + BAND_WINDOWS; ba.grid = (int) band_grid;
                     ba.next = reinterpret_cast<int *>(base + L.band_next_off);
                     ba.bands = ex.band_passes; ba.band_cols = ex.band_cols; ba.force = ex.band_force;
+                    if (ex.tdm_shift > 0) {
+                        // the clock-scheduled one-pass form first: it does the whole SpMV when the windows say "spread" (and the BAND
+                        // kernel below, told so by bands = 0, returns at once), and returns at once itself when they do not
+                        constexpr int per_cu = tdm_blocks_per_cu<V, BLOCK, IPT>();
+                        long long want = std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
+                        if (want >= 8) want &= ~7LL;
+                        if (want >= 8 || want == L.num_tiles) {
+                            BandArgs tb = ba; tb.grid = (int) want;
+                            TdmArgs ta; ta.band_shift = ex.tdm_shift; ta.bands = ex.tdm_bands;
+                            ta.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : 2;
+                            // a band stays on air for as long as the resident blocks need for their gathers of it at the L2 gather rate
+                            // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt), in ticks of 10 ns
+                            const double slot_us = (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
+                            const double ticks = std::max(8.0, slot_us * 100.0 * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
+                            ta.inv_slot = (float) (1.0 / ticks);
+#define MSPMV_LAUNCH_TDM(AX, NTF) hipLaunchKernelGGL((tile_kernel_tdm<V, BLOCK, IPT, AX, NTF>), dim3((unsigned) want), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, tb, ta)
+                            if (axpby) { if (nt) MSPMV_LAUNCH_TDM(true, true); else MSPMV_LAUNCH_TDM(true, false); }
+                            else if (nt) MSPMV_LAUNCH_TDM(false, true);
+                            else MSPMV_LAUNCH_TDM(false, false);
+#undef MSPMV_LAUNCH_TDM
+                            MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_tdm", (unsigned) want, BLOCK));
+                            ba.bands = 0;
+                        }
+                    }
 #define MSPMV_LAUNCH_BAND(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
                     if (axpby) { if (nt) MSPMV_LAUNCH_BAND(true, true); else MSPMV_LAUNCH_BAND(true, false); }
                     else if (nt) MSPMV_LAUNCH_BAND(false, true);
@@ -765,6 +802,8 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
     ex2.band_passes = band_passes_for(L, (long long) cols * (long long) sizeof(V), (int) sizeof(V), rows, nnz, ex, &ex2.band_force);
     ex2.band_cols = ex2.band_passes > 1 ? (cols + ex2.band_passes - 1) / ex2.band_passes : 0;
     ex2.num_cols = cols;
+    ex2.tdm_shift = tdm_shift_for(cols, ex2.band_passes, ex);
+    ex2.tdm_bands = ex2.tdm_shift > 0 ? (int) (((long long) cols + (1LL << ex2.tdm_shift) - 1) >> ex2.tdm_shift) : 0;
     return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, ex2);
 }
 template int csrmv_call<float>(void *, size_t *, const float *, const int32_t *, const int32_t *, const float *, float *, int32_t,
@@ -1179,6 +1218,15 @@ int mspmv_set_band_passes(int32_t value_bytes, int32_t passes)
 {
     if ((value_bytes != 4 && value_bytes != 8) || passes == 1 || passes > 64) return hipErrorInvalidValue;
     t_tune[value_bytes == 8].band_passes = passes < 0 ? -1 : passes;
+    return hipSuccess;
+}
+
+int mspmv_set_tdm(int32_t value_bytes, int32_t policy, int32_t slot_permille, int32_t lookahead_plus_1, int32_t band_shift)
+{
+    if ((value_bytes != 4 && value_bytes != 8) || slot_permille < 0 || lookahead_plus_1 < 0 || lookahead_plus_1 > 33 || band_shift < 0 || band_shift > TDM_SLOT_SHIFT)
+        return hipErrorInvalidValue;
+    Tune &t = t_tune[value_bytes == 8];
+    t.tdm = policy < 0 ? -1 : policy > 0 ? 1 : 0; t.tdm_slot_permille = slot_permille; t.tdm_lookahead = lookahead_plus_1; t.tdm_band_shift = band_shift;
     return hipSuccess;
 }
 

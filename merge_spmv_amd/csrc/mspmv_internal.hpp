@@ -22,7 +22,12 @@ enum { PHASE_ALL = 0, PHASE_COORDS_ONLY = 1, PHASE_SKIP_COORDS = 2 };
 // the calling host thread's development override (mspmv_set_tuning, mspmv_set_band_passes) into it once, on entry; the
 // prepared band-major plan and the multi-GPU plan always pass the defaults, so what they store at build time (tile
 // coordinates) can never disagree with what a later apply derives.
-struct Tune { int block = 0, ipt = 0, flags = 0, band_passes = 0, record_polls = 0, compact_tiles = 0; };
+struct Tune {
+    int block = 0, ipt = 0, flags = 0, band_passes = 0, record_polls = 0, compact_tiles = 0;
+    // clock-scheduled column bands (mspmv_tdm.hpp) for the calls the column-band passes are offered to: 0 = the library's rule,
+    // < 0 never (the passes as before), > 0 always; slot length in per mille of the computed one, lookahead bands (0 = defaults)
+    int tdm = 0, tdm_slot_permille = 0, tdm_lookahead = 0, tdm_band_shift = 0;
+};
 
 struct CallExtra {
     int phase = PHASE_ALL;
@@ -31,6 +36,7 @@ struct CallExtra {
                             // xcd_chunked_tile (TILE_MAP_CONTIGUOUS_CODE: one contiguous tile range per XCD)
     // column-band passes (filled in by csrmv_call, see band_passes_for): > 1 = tile_kernel_band may serve the call
     int band_passes = 0, band_cols = 0, band_force = 0, num_cols = 0;
+    int tdm_shift = 0, tdm_bands = 0;   // > 0: the clock-scheduled one-pass form serves the call when the windows say "spread" (mspmv_tdm.hpp)
     bool no_bands = false;  // callers that must not take them (the band-major plan: its stacked matrix is banded already)
     bool allow_skinny = false;   // the stateless public calls only: a large fp64 matrix of short rows over a tiny x may take the small tile shape (mspmv_api.hip: skinny_rule)
 };

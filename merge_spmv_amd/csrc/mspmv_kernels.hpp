@@ -2165,7 +2165,8 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
         asm volatile("" : "+s"(c0.x), "+v"(band_v));
         if (__popcll(__ballot(band_v != 0)) >= BAND_MAJORITY) {
             // the passes instead: run by the first ba.grid blocks of this launch, the others return
-            if ((int) blockIdx.x < ba.grid) {
+            // (bands == 0: the clock-scheduled one-pass kernel, mspmv_tdm.hpp, has served this call already)
+            if ((int) blockIdx.x < ba.grid && ba.bands > 0) {
                 if (!AXPBY) { p.alpha = (V) 1; p.beta = (V) 0; }
                 p.x_lds = 0;
                 run_band_passes<V, BLOCK, IPT, NT>(p, coords, carries, num_tiles, ba, s_end_raw, s_prod_raw, s_flag, s_wave_key, s_wave_val);
