@@ -19,7 +19,6 @@
 #include "../../include/mspmv.h"
 #include "mspmv_internal.hpp"
 #include "mspmv_kernels.hpp"
-#include "mspmv_tdm.hpp"
 #include "mspmv_spmm.hpp"
 
 namespace mspmv {
@@ -278,12 +277,12 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
 }
 
 // Clock-scheduled column bands (mspmv_tdm.hpp) instead of the passes, for a call band_passes_for offers them to: the band width
-// (columns per band = 2^shift; 2^18 = 1 MiB of fp32 / 2 MiB of fp64 x, the prototype's best) -- widened until 32 bands cover x.
+// (columns per band = 2^shift: 1 MiB of x, the best of 0.5 / 1 / 2 MiB on C2 in both precisions) -- widened until 32 bands cover x.
 // 0 = the passes.  Measured on C2 (tools/tdm_spmv.hip): fp32 0.64 ms against the passes' 0.83, fp64 1.02 against 1.30.
-static int tdm_shift_for(long long cols, int band_passes, const CallExtra &ex)
+static int tdm_shift_for(long long cols, int value_bytes, int band_passes, const CallExtra &ex)
 {
     if (band_passes <= 1 || ex.tune.tdm < 0) return 0;
-    int shift = ex.tune.tdm_band_shift > 0 ? ex.tune.tdm_band_shift : 18;
+    int shift = ex.tune.tdm_band_shift > 0 ? ex.tune.tdm_band_shift : value_bytes == 8 ? 17 : 18;      // bands of 1 MiB
     while (shift < TDM_SLOT_SHIFT && ((cols + (1LL << shift) - 1) >> shift) > TDM_MAX_BANDS) ++shift;
     if (((cols + (1LL << shift) - 1) >> shift) > TDM_MAX_BANDS || shift > TDM_SLOT_SHIFT) return 0;
     return shift;
@@ -421,7 +420,7 @@ static bool launch_dev_variant(const Layout &L, const Params<V> &p, bool axpby, 
         long long want = (long long) per_cu * device_cus();                                                \
         if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
         const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
-        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, BandArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0});   \
+        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, BandArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0, TdmArgs{0, 0, 0.f, 0}});   \
     } while (0)
     if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
     else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
@@ -524,6 +523,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
     // tile kernel (its BAND variant) runs its ordinary body or the passes
     bool band = false, band_sampled = false;
     unsigned band_grid = 0;
+    int band_resident_per_cu = 4;
     if constexpr (band_shape(BLOCK, IPT, (int) sizeof(V))) {
         if (vec && ex.band_passes > 1 && phase != PHASE_COORDS_ONLY) {
             // the passes are run by 4 (fp64: 5) blocks per CU, or as many as are resident at once if that is fewer: the gathers
@@ -538,6 +538,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                 per_cu = std::min(n, 2048 / BLOCK);
                 resident.store(per_cu, std::memory_order_relaxed);
             }
+            band_resident_per_cu = per_cu;
             const int band_per_cu = std::min(per_cu, sizeof(V) == 4 ? 4 : 5);
             long long want = std::min<long long>(L.num_tiles, (long long) band_per_cu * device_cus());
             if (want >= 8) want &= ~7LL;                                   // (8 interleaved tile sequences, one per XCD)
@@ -616,7 +617,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
 #ifdef MSPMV_DEV
             launched = launch_dev_variant<V, BLOCK, IPT>(L, p, axpby, nt, coords, carries, chunk_log2, stream);
 #endif
-            BandArgs ba; ba.verdict = nullptr; ba.counters = nullptr; ba.next = nullptr; ba.grid = 0; ba.bands = 0; ba.band_cols = 0; ba.force = 0;
+            BandArgs ba; ba.verdict = nullptr; ba.counters = nullptr; ba.next = nullptr; ba.grid = 0; ba.bands = 0; ba.band_cols = 0; ba.force = 0; ba.tdm = TdmArgs{0, 0, 0.f, 0};
             if constexpr (band_shape(BLOCK, IPT, (int) sizeof(V))) {
                 if (band && !launched) {
                     // the BAND variant: the same kernel, whose first band_grid blocks run the column-band passes instead
@@ -625,33 +626,34 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                     ba.next = reinterpret_cast<int *>(base + L.band_next_off);
                     ba.bands = ex.band_passes; ba.band_cols = ex.band_cols; ba.force = ex.band_force;
                     if (ex.tdm_shift > 0) {
-                        // the clock-scheduled one-pass form first: it does the whole SpMV when the windows say "spread" (and the BAND
-                        // kernel below, told so by bands = 0, returns at once), and returns at once itself when they do not
-                        constexpr int per_cu = tdm_blocks_per_cu<V, BLOCK, IPT>();
-                        long long want = std::min<long long>(L.num_tiles, (long long) per_cu * device_cus());
-                        if (want >= 8) want &= ~7LL;
-                        if (want >= 8 || want == L.num_tiles) {
-                            BandArgs tb = ba; tb.grid = (int) want;
-                            TdmArgs ta; ta.band_shift = ex.tdm_shift; ta.bands = ex.tdm_bands;
-                            ta.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : 2;
-                            // a band stays on air for as long as the resident blocks need for their gathers of it at the L2 gather rate
-                            // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt), in ticks of 10 ns
-                            const double slot_us = (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
-                            const double ticks = std::max(8.0, slot_us * 100.0 * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
-                            ta.inv_slot = (float) (1.0 / ticks);
-#define MSPMV_LAUNCH_TDM(AX, NTF) hipLaunchKernelGGL((tile_kernel_tdm<V, BLOCK, IPT, AX, NTF>), dim3((unsigned) want), dim3(BLOCK), 0, stream, p, coords, carries, L.num_tiles, tb, ta)
-                            if (axpby) { if (nt) MSPMV_LAUNCH_TDM(true, true); else MSPMV_LAUNCH_TDM(true, false); }
-                            else if (nt) MSPMV_LAUNCH_TDM(false, true);
-                            else MSPMV_LAUNCH_TDM(false, false);
-#undef MSPMV_LAUNCH_TDM
-                            MSPMV_CHECK(after_launch(stream, debug_sync, "tile_kernel_tdm", (unsigned) want, BLOCK));
-                            ba.bands = 0;
-                        }
+                        // clock-scheduled column bands instead of the passes (mspmv_tdm.hpp): every block of the launch stages its one tile
+                        // band by band.  Blocks resident per CU: what the kernel's occupancy says (LDS, registers).
+                        const int per_cu = std::max(1, (int) std::min<long long>((L.num_tiles + device_cus() - 1) / device_cus(), band_resident_per_cu));
+                        ba.tdm.band_shift = ex.tdm_shift; ba.tdm.bands = ex.tdm_bands;
+                        ba.tdm.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : ex.tdm_bands <= 16 ? 2 : 3;
+                        // A band stays on air for as long as the resident blocks need for their gathers of it at the L2 gather rate
+                        // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt) and a quarter more -- or, if
+                        // that is longer, for as long as every XCD needs to fetch the band over the fabric (7.3 TB/s for all of them):
+                        // C2 fp32 2.0 us (12 bands of 1 MiB), fp64 1.15 us (24 bands); both read off sweeps of the slot length
+                        // (tools/tdm_check.py sweep).  In ticks of 10 ns.
+                        const double gather_us = 1.25 * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
+                        const double fabric_us = (double) sizeof(V) * (double) (1u << ex.tdm_shift) * device_caches().xcds / 7.3e6;
+                        const double ticks = std::max(8.0, std::max(gather_us, fabric_us) * 100.0 * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
+                        ba.tdm.inv_slot = (float) (1.0 / ticks);
                     }
-#define MSPMV_LAUNCH_BAND(AX, NTF) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false, true>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
-                    if (axpby) { if (nt) MSPMV_LAUNCH_BAND(true, true); else MSPMV_LAUNCH_BAND(true, false); }
-                    else if (nt) MSPMV_LAUNCH_BAND(false, true);
-                    else MSPMV_LAUNCH_BAND(false, false);
+#define MSPMV_LAUNCH_BAND(AX, NTF, TD) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false, true, TD>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
+                    if (ex.tdm_shift > 0) {
+                        // (fp64: ordinary loads whatever the size -- the line-wise non-temporal form of the value loads costs the clocked
+                        //  staging six registers more than the kernel has at five waves per SIMD)
+                        constexpr bool NT_OK = sizeof(V) == 4;
+                        if (axpby) { if (nt && NT_OK) MSPMV_LAUNCH_BAND(true, NT_OK, true); else MSPMV_LAUNCH_BAND(true, false, true); }
+                        else if (nt && NT_OK) MSPMV_LAUNCH_BAND(false, NT_OK, true);
+                        else MSPMV_LAUNCH_BAND(false, false, true);
+                    } else {
+                        if (axpby) { if (nt) MSPMV_LAUNCH_BAND(true, true, false); else MSPMV_LAUNCH_BAND(true, false, false); }
+                        else if (nt) MSPMV_LAUNCH_BAND(false, true, false);
+                        else MSPMV_LAUNCH_BAND(false, false, false);
+                    }
 #undef MSPMV_LAUNCH_BAND
                     launched = true;
                 }
@@ -802,7 +804,7 @@ int csrmv_call(void *d_temp, size_t *temp_bytes, const V *d_values, const int32_
     ex2.band_passes = band_passes_for(L, (long long) cols * (long long) sizeof(V), (int) sizeof(V), rows, nnz, ex, &ex2.band_force);
     ex2.band_cols = ex2.band_passes > 1 ? (cols + ex2.band_passes - 1) / ex2.band_passes : 0;
     ex2.num_cols = cols;
-    ex2.tdm_shift = tdm_shift_for(cols, ex2.band_passes, ex);
+    ex2.tdm_shift = tdm_shift_for(cols, (int) sizeof(V), ex2.band_passes, ex);
     ex2.tdm_bands = ex2.tdm_shift > 0 ? (int) (((long long) cols + (1LL << ex2.tdm_shift) - 1) >> ex2.tdm_shift) : 0;
     return (int) dispatch_shape<V>(L, d_temp, p, axpby, stream, debug_sync, ex2);
 }

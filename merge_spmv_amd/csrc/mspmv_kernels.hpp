@@ -2014,6 +2014,19 @@ __device__ __forceinline__ int compact_tile(int b, int num_tiles, int map)
     return map ? contiguous : b;                  // (scalar arithmetic and a select: nothing between the wave's start and its hint request)
 }
 
+// Clock-scheduled column bands (mspmv_tdm.hpp): the one-pass form of the same organisation.  band_shift == 0: the passes.
+struct TdmArgs {
+    int band_shift;        // band = column >> band_shift
+    int bands;             // ceil(cols / 2^band_shift) <= TDM_MAX_BANDS
+    float inv_slot;        // 1 / (ticks of the 100 MHz clock a band stays on air)
+    int lookahead;         // bands after the one on air that may be taken too
+};
+template <typename V, int BLOCK, int IPT, bool NT>
+__device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c0, const Coord c1, const TileRegs<V, BLOCK, IPT> &regs,
+                                               end16_t *s_end_raw, V *s_prod_raw, int last_full_nz, int last_full_ro, unsigned *s_flag,
+                                               int *s_start, int *s_wave_sum, const TdmArgs &ta, int tid);
+constexpr int TDM_MAX_BANDS = 32;
+
 // What the tile kernel needs to know about them (BAND variants of tile_kernel_vec; verdict == nullptr otherwise)
 struct BandArgs {
     const int *verdict;        // BAND_WINDOWS verdicts of band_detect_block
@@ -2022,6 +2035,7 @@ struct BandArgs {
     int grid;                  // blocks that run the passes (4-5 per CU, a multiple of 8); the others return
     int bands, band_cols;
     int force;                 // 1: passes whatever the verdicts say (mspmv_set_band_passes)
+    TdmArgs tdm;               // band_shift > 0: clock-scheduled bands instead of the passes
 };
 
 // The column-band passes of one call, run by the first `grid` blocks of the tile kernel's launch.
@@ -2104,8 +2118,8 @@ __device__ __forceinline__ void run_band_passes(Params<V> p, const Coord *__rest
 __device__ unsigned long long *g_mspmv_trace = nullptr;
 #endif
 
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false, bool BAND = false>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
+template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false, bool BAND = false, bool TDM = false>
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>() - (TDM && sizeof(V) == 4 ? 1 : 0))) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2,
                                                                 BandArgs ba)
 {
@@ -2125,6 +2139,7 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
     int band_v = 0;
     if constexpr (BAND) {
         static_assert(FL && !PERSIST && ABLATE == 0 && !XCD_REMAP, "band passes: production variant only");
+    static_assert(BAND || !TDM, "clock-scheduled bands: a BAND variant");
         band_v = ba.force ? 1 : ba.verdict[threadIdx.x & (WAVE - 1)];
     }
     constexpr bool TRACE = ABLATE == 6;
@@ -2164,14 +2179,27 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
         // 99 M-nonzero matrix the passes do not serve: +8 us per call that way, +2 us this way.)
         asm volatile("" : "+s"(c0.x), "+v"(band_v));
         if (__popcll(__ballot(band_v != 0)) >= BAND_MAJORITY) {
-            // the passes instead: run by the first ba.grid blocks of this launch, the others return
-            // (bands == 0: the clock-scheduled one-pass kernel, mspmv_tdm.hpp, has served this call already)
-            if ((int) blockIdx.x < ba.grid && ba.bands > 0) {
-                if (!AXPBY) { p.alpha = (V) 1; p.beta = (V) 0; }
+            if constexpr (TDM) {
+                // clock-scheduled column bands (mspmv_tdm.hpp): one tile per block as in the ordinary body, the x gathers band by band
+                // (a kernel of its own, chosen by the host: with the passes in the same kernel the scalar registers do not go round)
+                __shared__ int s_tdm_start[TDM_MAX_BANDS + 1];
                 p.x_lds = 0;
-                run_band_passes<V, BLOCK, IPT, NT>(p, coords, carries, num_tiles, ba, s_end_raw, s_prod_raw, s_flag, s_wave_key, s_wave_val);
+                TileRegs<V, BLOCK, IPT> tregs;
+                issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, tregs);
+                stage_tile_tdm<V, BLOCK, IPT, NT>(p, c0, c1, tregs, s_end_raw, s_prod_raw, (p.nnz & ~3) - 4, ((p.rows + 1) & ~3) - 4, s_flag,
+                                                  s_tdm_start, s_wave_key, ba.tdm, (int) threadIdx.x);
+                consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + ((c0.x + 1) - ((c0.x + 1) & ~3)), s_prod_raw, s_flag,
+                                                         s_wave_key, s_wave_val, carries + tile, c0.y - (c0.y & ~3));
+                return;
+            } else {
+                // the passes instead: run by the first ba.grid blocks of this launch, the others return
+                if ((int) blockIdx.x < ba.grid) {
+                    if (!AXPBY) { p.alpha = (V) 1; p.beta = (V) 0; }
+                    p.x_lds = 0;
+                    run_band_passes<V, BLOCK, IPT, NT>(p, coords, carries, num_tiles, ba, s_end_raw, s_prod_raw, s_flag, s_wave_key, s_wave_val);
+                }
+                return;
             }
-            return;
         }
     }
     TileRegs<V, BLOCK, IPT> regs;
@@ -3035,3 +3063,5 @@ __global__ void mg_apply_kernel(V *__restrict__ y_local, const V *__restrict__ c
 }
 
 }  // namespace mspmv
+
+#include "mspmv_tdm.hpp"

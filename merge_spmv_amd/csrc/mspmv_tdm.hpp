@@ -21,24 +21,9 @@
 
 namespace mspmv {
 
-constexpr int TDM_MAX_BANDS = 32;
 constexpr int TDM_COPIES = 8;              // counters per (band, wave): lanes 8 apart share one
 constexpr int TDM_SLOT_SHIFT = 20;         // sorted word = slot in the tile's raw product array (12 bits) << 20 | column inside its band
 
-struct TdmArgs {
-    int band_shift;        // band = column >> band_shift  (<= TDM_SLOT_SHIFT)
-    int bands;             // ceil(cols / 2^band_shift) <= TDM_MAX_BANDS
-    float inv_slot;        // 1 / (ticks of the 100 MHz clock a band stays on air)
-    int lookahead;         // bands after the one on air that may be taken too
-};
-
-template <typename V, int BLOCK, int IPT>
-constexpr int tdm_blocks_per_cu()
-{
-    constexpr int by_lds = tile_blocks_per_cu<V, BLOCK, IPT>();
-    constexpr int by_regs = sizeof(V) == 4 ? 7 : 6;          // 72 / 80 vector registers per lane
-    return by_lds < by_regs ? by_lds : by_regs;
-}
 
 // the tile's products, row ends and row-start bits in LDS, as stage_tile_careful leaves them -- x gathered band by band
 template <typename V, int BLOCK, int IPT, bool NT>
@@ -123,11 +108,13 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
 #pragma unroll
     for (int k = 0; k < IPT; ++k) ent[k] = s_exch[k * BLOCK + tid];
     // band of the first entry of each of the wave's IPT windows (window k = entries k * BLOCK + wave * 64 ... + 63): wave-uniform
-    int wq[IPT];
+    // (five bits each, in one 64-bit scalar: eleven separate ones were eleven more scalar registers than the kernel has)
+    static_assert(IPT * 5 <= 64 && TDM_MAX_BANDS <= 32, "window bands packed five bits each");
+    unsigned long long wqp = 0ull;
     {
         const int st = lane < ta.bands ? s_start[lane + 1] : 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) wq[k] = __popcll(__ballot(st <= k * BLOCK + wave * WAVE));
+        for (int k = 0; k < IPT; ++k) wqp |= (unsigned long long) (__popcll(__ballot(st <= k * BLOCK + wave * WAVE)) & 31) << (5 * k);
     }
     __syncthreads();                          // every sorted word is in registers: the product array may take the x values
     // ---- 4. band by band, as the clock says; every wave on its own
@@ -145,11 +132,12 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
 #pragma unroll
             for (int k = 0; k < IPT; ++k) {
                 if ((done >> k) & 1u) continue;
-                int d = wq[k] - on_air; if (d < 0) d += ta.bands;
+                const int wq = (int) ((wqp >> (5 * k)) & 31ull);
+                int d = wq - on_air; if (d < 0) d += ta.bands;
                 if (d > ta.lookahead) continue;
                 const int idx = k * BLOCK + tid;
                 if (idx < sorted) {
-                    int q = wq[k];
+                    int q = wq;
                     while (q + 1 < ta.bands && idx >= s_start[q + 1]) ++q;         // (a window seldom spans more than two bands)
                     const unsigned e = ent[k];
                     s_prod_raw[prod_slot<V, CPT>((int) (e >> TDM_SLOT_SHIFT))] = p.x[((unsigned) q << ta.band_shift) | (e & col_mask)];
@@ -172,18 +160,16 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
     }
     __syncthreads();
     // ---- 5. products: every thread its own chunks again (x value in place -> product in place)
-    Vec4<V> own_val[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) own_val[k] = vals_linewise<V, NT, false>() ? linewise_own(regs.val[k]) : regs.val[k];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
+        const Vec4<V> own_val = vals_linewise<V, NT, false>() ? linewise_own(regs.val[k]) : regs.val[k];      // (wave-uniform control flow here)
         constexpr int EPU = 16 / (int) sizeof(V);
         V xv[4], prod[4];
 #pragma unroll
         for (int u = 0; u < 4 / EPU; ++u) ld_unit(&s_prod_raw[prod_unit<V, CPT>(chunk * (4 / EPU) + u) * EPU], &xv[u * EPU]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) prod[i] = ((in_mask >> (4 * k + i)) & 1u) ? own_val[k].get(i) * xv[i] : (V) 0;
+        for (int i = 0; i < 4; ++i) prod[i] = ((in_mask >> (4 * k + i)) & 1u) ? own_val.get(i) * xv[i] : (V) 0;
         st_prod_chunk<CPT>(s_prod_raw, chunk, prod, false);
     }
     // ---- 6. row ends and row-start bits (the counters' space is free again)
@@ -224,62 +210,6 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
         }
     }
     __syncthreads();
-}
-
-// One launch of ba.grid persistent blocks between the coordinate pass and the BAND tile kernel: when the sampled windows say
-// "spread" it does the whole SpMV (the BAND kernel then returns at once: BandArgs::bands == 0), otherwise it returns at once.
-template <typename V, int BLOCK, int IPT, bool AXPBY, bool NT>
-__global__ __launch_bounds__(BLOCK, (tdm_blocks_per_cu<V, BLOCK, IPT>() * BLOCK + 255) / 256) void tile_kernel_tdm(Params<V> p, const Coord *__restrict__ coords,
-                                                                                         Carry<V> *__restrict__ carries, int num_tiles, BandArgs ba, TdmArgs ta)
-{
-    constexpr int NW = BLOCK / WAVE;
-    constexpr int CPT = IPT / 4 + 1;
-    constexpr int SLOTS = CPT * BLOCK * 4;
-    __shared__ __attribute__((aligned(16))) end16_t s_end_raw[SLOTS];
-    __shared__ __attribute__((aligned(16))) V s_prod_raw[SLOTS];
-    __shared__ unsigned s_flag[SLOTS / 32 + 1];
-    __shared__ int s_wave_key[NW];
-    __shared__ V s_wave_val[NW];
-    __shared__ int s_start[TDM_MAX_BANDS + 1];
-    __shared__ int s_next;
-    const int tid = threadIdx.x;
-    const int band_v = ba.force ? 1 : ba.verdict[tid & (WAVE - 1)];
-    if (__popcll(__ballot(band_v != 0)) < BAND_MAJORITY) return;
-    if (tid < SLOTS / 32 + 1) s_flag[tid] = 0u;
-    if (tid == 0) s_next = blockIdx.x;
-    if (!AXPBY) { p.alpha = (V) 1; p.beta = (V) 0; }
-    p.x_lds = 0;
-    const int last_full_nz = (p.nnz & ~3) - 4;
-    const int last_full_ro = ((p.rows + 1) & ~3) - 4;
-    const int first_n = ba.grid / 8;
-    int seq = (int) blockIdx.x & 7;            // thread 0: the sequence it claims from (run_band_passes, pass 0)
-    __syncthreads();
-    for (;;) {
-        const int tile = s_next;
-        if (tile >= num_tiles) break;
-        int following = num_tiles;
-        if (tid == 0 && ba.grid >= 8)
-            for (int tries = 0; tries < 8; ++tries) {
-                const int n = first_n + atomicAdd(ba.counters + seq * BAND_COUNTER_STRIDE, 1);
-                following = 8 * n + seq;
-                if (following < num_tiles) break;
-                following = num_tiles; seq = (seq + 1) & 7;
-            }
-        int t = tid;
-        asm volatile("" : "+v"(t));             // (see run_band_passes: what derives from the thread index is recomputed per tile)
-        __builtin_assume(t >= 0 && t < BLOCK);
-        const Coord c0 = coords[tile];
-        const Coord c1 = coords[tile + 1];
-        TileRegs<V, BLOCK, IPT> regs;
-        issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, regs, t);
-        stage_tile_tdm<V, BLOCK, IPT, NT>(p, c0, c1, regs, s_end_raw, s_prod_raw, last_full_nz, last_full_ro, s_flag, s_start, s_wave_key, ta, t);
-        const int pshift = c0.y - (c0.y & ~3);
-        const int eshift = (c0.x + 1) - ((c0.x + 1) & ~3);
-        consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + eshift, s_prod_raw, s_flag,
-                                                 s_wave_key, s_wave_val, carries + tile, pshift, nullptr, nullptr, 0, false, 0, t);
-        if (tid == 0) s_next = following;
-        __syncthreads();
-    }
 }
 
 }  // namespace mspmv

@@ -36,9 +36,9 @@ def banded(n, w, dt):
 def cases():
     yield "c2_f32", lambda: G.uniform_csr(3_125_000, 3_125_000, 32, dtype=f32)
     yield "c2_f64", lambda: G.uniform_csr(3_125_000, 3_125_000, 32, dtype=f64)
-    for mb in (4, 6, 8, 12, 16, 24, 32):
+    for mb in (4, 6, 8, 12, 16, 24, 32, 48, 64):
         yield f"u{mb}MB_f32", (lambda n=mb * 2**20 // 4: G.uniform_csr(3_000_000, n, 32, dtype=f32))
-    for mb in (8, 12, 16, 24, 32):
+    for mb in (4, 8, 12, 16, 24, 32, 48, 64):
         yield f"u{mb}MB_f64", (lambda n=mb * 2**20 // 8: G.uniform_csr(3_000_000, n, 32, dtype=f64))
     # 160-256 MB of CSR stream: ordinary loads, the matrix stays in the Infinity Cache from pass to pass
     yield "u24Mnnz_7.6MB_f32", lambda: G.uniform_csr(1_000_000, 2_000_000, 24, dtype=f32)
@@ -82,8 +82,9 @@ def sweep(only):
         tol = 2.0 * (torch.ceil(torch.log2(lens.double() + 1)) + 32) * eps * s
         out = []
         forced = [int(v) for v in os.environ.get("BAND_FORCE", "2,3,4").split(",") if v]
-        for label, passes in [("never", -1), ("auto", 0)] + [(f"force{b}", b) for b in forced]:
-            M.set_band_passes(vb, passes)
+        for label, passes in [("never", -1), ("auto", 0), ("passes", 0)] + [(f"force{b}", b) for b in forced] + [("force_clocked", 4)]:
+            # auto / force_clocked: the clock-scheduled one-pass form (csrc/mspmv_tdm.hpp) where the passes are offered / on any call; passes, forceN: the passes
+            M.set_band_passes(vb, passes); M.set_tdm(vb, 0 if label in ("auto", "never") else 1 if label == "force_clocked" else -1)
             y.fill_(float("nan")); call(); torch.cuda.synchronize()
             bad = int(((y.double() - g).abs() > tol).sum()) + int(torch.isnan(y).sum())
             y2 = y.clone(); call(); torch.cuda.synchronize()
@@ -96,7 +97,7 @@ def sweep(only):
                 if offered: extra += f", windows {int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())}/64"
                 extra += ") " + fmt(profile(call, 20))
             out.append(f"{label} {ms:7.4f}{'' if bad == 0 else ' BAD=' + str(bad)}{'' if rep else ' NONREPRO'}{extra}")
-        M.set_band_passes(vb, 0)
+        M.set_band_passes(vb, 0); M.set_tdm(vb, 0)
         print(f"{name:18s} x {A.cols * vb / 2**20:5.1f} MiB nnz {A.nnz/1e6:5.1f}M: " + "  ".join(out), flush=True)
         del A, x, y, ws, g, s
 
