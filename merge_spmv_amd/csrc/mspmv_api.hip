@@ -272,8 +272,11 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
     if (stream_bytes < 5ull * (unsigned long long) dc.xcds * (unsigned long long) dc.l2_bytes) return 0;
     const double r = (double) x_bytes / (double) dc.l2_bytes;
-    if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : 0;
-    return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : 0;
+    // (beyond 10 / 9 L2 the passes lose; the clock-scheduled one-pass form, mspmv_tdm.hpp, which serves every offered call unless
+    //  switched off, still wins up to 16 / 12 L2: 48 MiB of fp32 x 1.68 -> 1.16 ms, 64 MiB 1.73 -> 1.53, 48 MiB of fp64 x 1.72 -> 1.57)
+    const bool clocked = ex.tune.tdm >= 0;
+    if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : (clocked && r <= 16) ? 4 : 0;
+    return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : (clocked && r <= 12) ? 4 : 0;
 }
 
 // Clock-scheduled column bands (mspmv_tdm.hpp) instead of the passes, for a call band_passes_for offers them to: the band width
@@ -630,14 +633,15 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                         // band by band.  Blocks resident per CU: what the kernel's occupancy says (LDS, registers).
                         const int per_cu = std::max(1, (int) std::min<long long>((L.num_tiles + device_cus() - 1) / device_cus(), band_resident_per_cu));
                         ba.tdm.band_shift = ex.tdm_shift; ba.tdm.bands = ex.tdm_bands;
-                        ba.tdm.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : ex.tdm_bands <= 16 ? 2 : 3;
+                        ba.tdm.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : 2;
                         // A band stays on air for as long as the resident blocks need for their gathers of it at the L2 gather rate
-                        // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt) and a quarter more -- or, if
-                        // that is longer, for as long as every XCD needs to fetch the band over the fabric (7.3 TB/s for all of them):
-                        // C2 fp32 2.0 us (12 bands of 1 MiB), fp64 1.15 us (24 bands); both read off sweeps of the slot length
-                        // (tools/tdm_check.py sweep).  In ticks of 10 ns.
-                        const double gather_us = 1.25 * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
-                        const double fabric_us = (double) sizeof(V) * (double) (1u << ex.tdm_shift) * device_caches().xcds / 7.3e6;
+                        // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt) and a sixth more -- or, if
+                        // that is longer, for as long as every XCD needs to fetch the band over the fabric (7.8 TB/s for all of them):
+                        // C2 fp32 2.13 us (12 bands of 1 MiB, 8 blocks per CU by the occupancy query), fp64 1.08 us (24 bands); both
+                        // constants read off sweeps of the slot length (tools/tdm_check.py sweep: the minimum is sharp, +-10 % of the
+                        // slot cost 3-5 % -- a block that misses a band's slot waits for the next rotation).  In ticks of 10 ns.
+                        const double gather_us = 1.16 * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
+                        const double fabric_us = (double) sizeof(V) * (double) (1u << ex.tdm_shift) * device_caches().xcds / 7.8e6;
                         const double ticks = std::max(8.0, std::max(gather_us, fabric_us) * 100.0 * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
                         ba.tdm.inv_slot = (float) (1.0 / ticks);
                     }

@@ -49,7 +49,7 @@ def _product_library_by_default():
         try:
             M.use_library("dev")
             for vb in (4, 8):
-                M.set_tuning(vb); M.set_band_passes(vb, 0)
+                M.set_tuning(vb); M.set_band_passes(vb, 0); M.set_tdm(vb, 0)
             M.set_record_polls(0); M.set_compact_tiles(0)
         except Exception:  # noqa: BLE001 - (no development library in this checkout: nothing to reset)
             pass

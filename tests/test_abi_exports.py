@@ -50,14 +50,14 @@ def test_the_product_library_has_no_setters_and_reads_no_environment():
     assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", dev], capture_output=True, text=True, check=True).stdout
     strings = subprocess.run(["strings", prod], capture_output=True, text=True, check=True).stdout
     assert not re.findall(r"^MSPMV_[A-Z0-9_]+$", strings, flags=re.M)
-    setters = ["mspmv_set_band_passes", "mspmv_set_compact_tiles", "mspmv_set_record_polls", "mspmv_set_tuning"]
+    setters = ["mspmv_set_band_passes", "mspmv_set_compact_tiles", "mspmv_set_record_polls", "mspmv_set_tdm", "mspmv_set_tuning"]
     assert exported(dev) == sorted(names + setters)
     assert sorted(set(declared_symbols("mspmv_dev.h")) - set(names)) == setters
 
 
 def test_setters_switch_to_the_development_library_and_defaults_do_not():
     assert M.active_library() == "product"
-    M.set_tuning(4); M.set_band_passes(8, 0); M.set_record_polls(0); M.set_compact_tiles(0)        # defaults: no-ops on the product
+    M.set_tuning(4); M.set_band_passes(8, 0); M.set_tdm(4, 0); M.set_record_polls(0); M.set_compact_tiles(0)        # defaults: no-ops on the product
     assert M.active_library() == "product"
     M.set_tuning(4, 256, 11)
     assert M.active_library() == "dev" and M.launch_info(10, 10, 4)["items_per_thread"] == 11
