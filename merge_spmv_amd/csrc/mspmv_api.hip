@@ -272,11 +272,11 @@ static int band_passes_for(const Layout &L, long long x_bytes, int value_bytes, 
     const unsigned long long stream_bytes = (unsigned long long) nnz * (value_bytes + 4) + 4ull * rows;
     if (stream_bytes < 5ull * (unsigned long long) dc.xcds * (unsigned long long) dc.l2_bytes) return 0;
     const double r = (double) x_bytes / (double) dc.l2_bytes;
-    // (beyond 10 / 9 L2 the passes lose; the clock-scheduled one-pass form, mspmv_tdm.hpp, which serves every offered call unless
-    //  switched off, still wins up to 16 / 12 L2: 48 MiB of fp32 x 1.68 -> 1.16 ms, 64 MiB 1.73 -> 1.53, 48 MiB of fp64 x 1.72 -> 1.57)
-    const bool clocked = ex.tune.tdm >= 0;
-    if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : (clocked && r <= 16) ? 4 : 0;
-    return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : (clocked && r <= 12) ? 4 : 0;
+    // (The clock-scheduled one-pass form that serves the offered calls since round 6, mspmv_tdm.hpp, would still win beyond 10 / 9 L2 --
+    //  48 MiB of fp32 x 1.68 -> 1.16 ms, 64 MiB 1.73 -> 1.53, 48 MiB of fp64 x 1.72 -> 1.57 -- but being a candidate costs every
+    //  matrix the windows then refuse the one-launch kernel: a circuit-shaped matrix with 44 MB of x 0.269 -> 0.28 ms.  Not widened.)
+    if (value_bytes == 4) return r < 1.375 ? 0 : r < 2.625 ? 2 : r < 5 ? 3 : r <= 10 ? 4 : 0;
+    return r < 1.75 ? 0 : r < 3.5 ? 2 : r < 5 ? 3 : r <= 9 ? 4 : 0;
 }
 
 // Clock-scheduled column bands (mspmv_tdm.hpp) instead of the passes, for a call band_passes_for offers them to: the band width
@@ -633,11 +633,11 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                         // band by band.  Blocks resident per CU: what the kernel's occupancy says (LDS, registers).
                         const int per_cu = std::max(1, (int) std::min<long long>((L.num_tiles + device_cus() - 1) / device_cus(), band_resident_per_cu));
                         ba.tdm.band_shift = ex.tdm_shift; ba.tdm.bands = ex.tdm_bands;
-                        ba.tdm.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : 2;
+                        ba.tdm.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : std::max(1, ex.tdm_bands / 8);      // (an eighth of x ahead of the clock: 1 of 12 bands, 3 of 24)
                         // A band stays on air for as long as the resident blocks need for their gathers of it at the L2 gather rate
                         // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt) and a sixth more -- or, if
                         // that is longer, for as long as every XCD needs to fetch the band over the fabric (7.8 TB/s for all of them):
-                        // C2 fp32 2.13 us (12 bands of 1 MiB, 8 blocks per CU by the occupancy query), fp64 1.08 us (24 bands); both
+                        // C2 fp32 2.13 us (12 bands of 1 MiB, 8 blocks per CU), fp64 1.08 us (24 bands, 5 blocks per CU); both
                         // constants read off sweeps of the slot length (tools/tdm_check.py sweep: the minimum is sharp, +-10 % of the
                         // slot cost 3-5 % -- a block that misses a band's slot waits for the next rotation).  In ticks of 10 ns.
                         const double gather_us = 1.16 * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
@@ -647,11 +647,8 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                     }
 #define MSPMV_LAUNCH_BAND(AX, NTF, TD) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false, true, TD>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
                     if (ex.tdm_shift > 0) {
-                        // (fp64: ordinary loads whatever the size -- the line-wise non-temporal form of the value loads costs the clocked
-                        //  staging six registers more than the kernel has at five waves per SIMD)
-                        constexpr bool NT_OK = sizeof(V) == 4;
-                        if (axpby) { if (nt && NT_OK) MSPMV_LAUNCH_BAND(true, NT_OK, true); else MSPMV_LAUNCH_BAND(true, false, true); }
-                        else if (nt && NT_OK) MSPMV_LAUNCH_BAND(false, NT_OK, true);
+                        if (axpby) { if (nt) MSPMV_LAUNCH_BAND(true, true, true); else MSPMV_LAUNCH_BAND(true, false, true); }
+                        else if (nt) MSPMV_LAUNCH_BAND(false, true, true);
                         else MSPMV_LAUNCH_BAND(false, false, true);
                     } else {
                         if (axpby) { if (nt) MSPMV_LAUNCH_BAND(true, true, false); else MSPMV_LAUNCH_BAND(true, false, false); }

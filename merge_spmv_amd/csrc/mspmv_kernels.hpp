@@ -1597,7 +1597,7 @@ __device__ __forceinline__ WirePos wire_pos(int q, int tid)
 //  result was mixed -- grid3d-200 -2.3 %, band5 -3 %, but the circuit-shaped matrix +8 %, dense32 fp64 +3.5 %, dense5 +2 %:
 //  profiles/r05_ab_wave_skip_general_kernel.txt.  The compact front end, whose loads are few and whose tiles share a CU in small
 //  numbers, keeps it.)
-template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true>
+template <typename V, int BLOCK, int IPT, bool NT, bool VALS = true, bool LINEWISE_OK = true>
 __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Coord c0, const Coord c1,
                                                     TileRegs<V, BLOCK, IPT> &r, int tid_in = -1)
 {
@@ -1614,7 +1614,7 @@ __device__ __forceinline__ void issue_nonzero_loads(const Params<V> &p, const Co
         // cached address), so no byte of HBM traffic is spent on data this tile does not use
         e0 = (e0 < c1.y && e0 <= last_full) ? e0 : safe;
         r.col[k] = ld_stream4<NT>(p.cols + e0);
-        if constexpr (VALS && vals_linewise<V, NT, false>()) {     // (ordinary loads: the second half hits the CU's cache anyway, and the swaps cost 3 % on dense5)
+        if constexpr (VALS && LINEWISE_OK && vals_linewise<V, NT, false>()) {     // (ordinary loads: the second half hits the CU's cache anyway, and the swaps cost 3 % on dense5)
             int e1 = a0 + 4 * ((tid ^ 32) + k * BLOCK);          // the chunk of the lane 32 away, by the same rule
             e1 = (e1 < c1.y && e1 <= last_full) ? e1 : safe;
             r.val[k] = ld_stream4_linewise<NT>(p.values, e0, e1, tid);
@@ -2119,7 +2119,7 @@ __device__ unsigned long long *g_mspmv_trace = nullptr;
 #endif
 
 template <typename V, int BLOCK, int IPT, bool AXPBY, bool XCD_REMAP, bool NT, int ABLATE = 0, bool PERSIST = false, bool BAND = false, bool TDM = false>
-__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>() - (TDM && sizeof(V) == 4 ? 1 : 0))) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
+__global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST, ABLATE == 7>())) void tile_kernel_vec(Params<V> p, const Coord *__restrict__ coords,
                                                                 Carry<V> *__restrict__ carries, int num_tiles, int xcd_chunk_log2,
                                                                 BandArgs ba)
 {
@@ -2185,7 +2185,10 @@ __global__ __launch_bounds__(BLOCK, (tile_waves_per_simd<V, BLOCK, IPT, !PERSIST
                 __shared__ int s_tdm_start[TDM_MAX_BANDS + 1];
                 p.x_lds = 0;
                 TileRegs<V, BLOCK, IPT> tregs;
-                issue_nonzero_loads<V, BLOCK, IPT, NT>(p, c0, c1, tregs);
+                // (values by plain 16-byte loads, also where the ordinary body fetches them line by line: the two bodies then share no
+                //  loads, the ordinary one compiles as it does in the kernel of the passes, and this one needs no lane swaps)
+                asm volatile("" : "+s"(p.nnz));       // (nothing of this body is merged with the ordinary one's)
+                issue_nonzero_loads<V, BLOCK, IPT, NT, true, false>(p, c0, c1, tregs);
                 stage_tile_tdm<V, BLOCK, IPT, NT>(p, c0, c1, tregs, s_end_raw, s_prod_raw, (p.nnz & ~3) - 4, ((p.rows + 1) & ~3) - 4, s_flag,
                                                   s_tdm_start, s_wave_key, ba.tdm, (int) threadIdx.x);
                 consume_tile_flags<V, BLOCK, IPT, AXPBY>(p, c0, c1.x - c0.x, c1.y - c0.y, s_end_raw + ((c0.x + 1) - ((c0.x + 1) & ~3)), s_prod_raw, s_flag,

@@ -163,7 +163,7 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int chunk = tid + k * BLOCK;
-        const Vec4<V> own_val = vals_linewise<V, NT, false>() ? linewise_own(regs.val[k]) : regs.val[k];      // (wave-uniform control flow here)
+        const Vec4<V> own_val = regs.val[k];                   // (plain loads: issue_nonzero_loads<..., LINEWISE_OK = false>)
         constexpr int EPU = 16 / (int) sizeof(V);
         V xv[4], prod[4];
 #pragma unroll

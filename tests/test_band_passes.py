@@ -53,9 +53,8 @@ def test_automatic_policy_table():
     assert M.band_passes(*C2, 4) == 3 and M.band_passes(*C2, 8) == 4           # 11.9 / 23.8 MiB of x
     mib = lambda m, vb: m * 2**20 // vb
     rows, nnz = 3_000_000, 96_000_000
-    # (beyond 40 / 36 MiB the passes lose; the clock-scheduled one-pass form that serves every offered call still wins up to 64 / 48 MiB)
-    assert [M.band_passes(rows, mib(m, 4), nnz, 4) for m in (4, 6, 8, 12, 16, 24, 32, 48, 64, 80)] == [0, 2, 2, 3, 3, 4, 4, 4, 4, 0]
-    assert [M.band_passes(rows, mib(m, 8), nnz, 8) for m in (4, 8, 12, 16, 24, 32, 48, 64)] == [0, 2, 2, 3, 4, 4, 4, 0]
+    assert [M.band_passes(rows, mib(m, 4), nnz, 4) for m in (4, 6, 8, 12, 16, 24, 32, 48)] == [0, 2, 2, 3, 3, 4, 4, 0]
+    assert [M.band_passes(rows, mib(m, 8), nnz, 8) for m in (4, 8, 12, 16, 24, 32, 48)] == [0, 2, 2, 3, 4, 4, 0]
     # a pass must be the CSR stream and little else: >= 160 MiB of it (what asking costs a refused matrix must stay small),
     # >= 8 nonzeros per row
     assert M.band_passes(1_000_000, mib(12, 4), 16_000_000, 4) == 0
@@ -65,9 +64,6 @@ def test_automatic_policy_table():
     assert M.band_passes(3_125_000, 32, 100_000_000, 4) == 0
     assert M.band_passes(1 << 26, 1 << 26, 2_000_000_000, 8) == 0
     try:
-        M.set_tdm(4, -1); M.set_tdm(8, -1)          # the passes alone: their own range
-        assert [M.band_passes(rows, mib(m, 4), nnz, 4) for m in (32, 48)] == [4, 0] and [M.band_passes(rows, mib(m, 8), nnz, 8) for m in (32, 48)] == [4, 0]
-        M.set_tdm(4, 0); M.set_tdm(8, 0)
         M.set_band_passes(4, -1)
         assert M.band_passes(*C2, 4) == 0
         M.set_band_passes(4, 5)
@@ -97,11 +93,11 @@ def test_policy_follows_the_l2_it_is_told_about():
         return json.loads(r.stdout.strip().splitlines()[-1])
     base = run({"MSPMV_FAKE_L2_MIB": "4", "MSPMV_FAKE_XCDS": "8"})          # the MI355X figures, spelled out
     assert base["caches"]["l2_bytes_per_xcd"] == 4 << 20 and base["caches"]["xcds"] == 8
-    assert base["c2"] == [3, 4] and base["f32"] == [0, 0, 0, 2, 2, 3, 3, 4, 4, 4] and base["small_stream"] == 0      # (48 MiB = 12 L2: the clocked form's range)
+    assert base["c2"] == [3, 4] and base["f32"] == [0, 0, 0, 2, 2, 3, 3, 4, 4, 0] and base["small_stream"] == 0
     half = run({"MSPMV_FAKE_L2_MIB": "2", "MSPMV_FAKE_XCDS": "8"})
     assert half["caches"]["l2_bytes_per_xcd"] == 2 << 20
-    assert half["f32"] == [0, 2, 2, 3, 3, 4, 4, 4, 4, 0]                         # every threshold at half the x (24, 32 MiB = 12, 16 L2: the clocked form's range)
-    assert half["c2"] == [4, 4]                                                  # 11.9 MiB = 5.96 L2; 23.8 MiB fp64 = 11.9 L2: the clocked form's range
+    assert half["f32"] == [0, 2, 2, 3, 3, 4, 4, 0, 0, 0]                         # every threshold at half the x
+    assert half["c2"] == [4, 0]                                                  # 11.9 MiB = 5.96 L2; 23.8 MiB fp64 = 11.9 L2: beyond
     assert half["small_stream"] == 4                                             # 92 MiB of stream >= 5 x 8 x 2 MiB now (x = 6 L2)
     big = run({"MSPMV_FAKE_L2_MIB": "16", "MSPMV_FAKE_XCDS": "2"})
     assert big["c2"] == [0, 0] and big["f32"][-3:] == [2, 2, 3]                  # 24 / 32 / 48 MiB = 1.5 / 2 / 3 L2

@@ -107,7 +107,7 @@ def c2(sweep=False):
         print(f"fp{vb * 8} C2: one sweep {t_one:.4f} ms | column-band passes {t_pass:.4f} ms", flush=True)
         grid = [(0, 0, 0, 11)]
         if sweep:
-            grid = [(sp, la, sh, ipt) for ipt in (11,) for sh in ((18,) if vb == 4 else (17,)) for sp in (700, 800, 875, 950, 1000, 1050, 1125, 1200) for la in (3, 4, 5)]
+            grid = [(sp, la, sh, ipt) for ipt in (11,) for sh in ((18,) if vb == 4 else (17,)) for sp in (700, 800, 875, 950, 1000, 1050, 1125, 1200) for la in (2, 3, 4)]
         for sp, la, sh, ipt in grid:
             M.set_band_passes(vb, 0 if ipt == 11 else 4); M.set_tdm(vb, 1, sp, la, sh)
             if ipt != 11:
