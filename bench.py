@@ -239,13 +239,17 @@ def roofline_record(M, A, cols, prof, ms, ws, workload_label, dtype_name):
     tile_s = prof["tile_ms"] * 1e-3
     achieved = b_alg / tile_s / 1e9 if tile_s > 0 else 0.0
     offered = M.band_passes(A.rows, cols, A.nnz, vb)
-    passes = 0
+    passes = clocked = 0
     if offered > 1:
+        # a candidate for the banded form: the device-side windows decide; since round 6 the form is the one-pass clock-scheduled bands
+        # (csrc/mspmv_tdm.hpp) -- `band_passes` stays in the record as the count the passes WOULD have taken (0: the windows refused)
         spread = int(M.debug_band_windows(ws, A.rows, A.nnz, vb).sum())
         passes = offered if spread >= 56 else 0
-    rec = {"kernel": "tile_kernel_vec<BAND>" if offered > 1 else "tile_kernel_snap", "achieved": round(achieved, 1), **roofline_bound(M, b_alg, achieved),
+        clocked = M.clocked_bands(A.rows, cols, A.nnz, vb)[0] if passes else 0
+    kernel = "tile_kernel_vec<BAND,TDM>" if clocked else "tile_kernel_vec<BAND>" if offered > 1 else "tile_kernel_snap"
+    rec = {"kernel": kernel, "achieved": round(achieved, 1), **roofline_bound(M, b_alg, achieved),
            "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(prof["tile_ms"], 5), "search_ms": round(prof["search_ms"], 5),
-           "fixup_ms": round(prof["fixup_ms"], 5), "launches_timed": prof["calls"], "band_passes": passes}
+           "fixup_ms": round(prof["fixup_ms"], 5), "launches_timed": prof["calls"], "band_passes": passes, "clocked_bands": clocked}
     tr, src = replayed_traffic(workload_label, dtype_name)
     rec["traffic"] = tr
     rec["traffic_over_algorithmic"] = round(tr / b_alg, 3) if tr else None
@@ -310,7 +314,7 @@ def config_records(M, torch, G, dev, steps, warmup, budget_s, mtx_dir=None, full
 # ---- the final line ------------------------------------------------------------------------------------------------------------
 
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "ic_resident", "frac_ic", "traffic", "traffic_over_algorithmic", "traffic_src",
-              "algorithmic_bytes_per_launch", "kernel_ms", "band_passes")
+              "algorithmic_bytes_per_launch", "kernel_ms", "band_passes", "clocked_bands")
 
 
 def _compact_config(c):

@@ -300,15 +300,24 @@ int mspmv_get_device_caches(int64_t *l2_bytes_per_xcd, int32_t *xcds, int32_t *c
  * in the Infinity Cache it gives the rate a cache-resident SpMV's algorithmic bytes are to be read against -- the HBM peak is not
  * the bound of such a call (bench.py: `roofline.bound` = "infinity_cache"). */
 int mspmv_probe_read_stream(const void *d_buf, size_t bytes, int32_t nontemporal, mspmv_stream_t stream);
-/* Column-band passes (extension).  A large matrix whose columns are spread uniformly over an x of 1.375-10 x one XCD's L2
- * (fp32; 1.75-9 x in fp64: 5.5-40 / 7-36 MiB on MI355X) is gather-bound at the Infinity-Cache rate; streaming it 2-4 times, each pass
- * multiplying the nonzeros of one column band (an x slice that stays in every XCD's L2), is 10-29 % faster.  The call stays stateless,
- * asynchronous and three launches: 64 blocks added to the coordinate launch sample 64 windows of 2048 consecutive column indices, and
- * the tile kernel reads their verdicts and runs either its ordinary body or the passes.  Results stay within the strict bound and are
- * bitwise reproducible; rounding differs from the one-sweep result in the last bits (a re-association).
- * *passes = how many passes a call of these sizes is offered (0: none; the aligned, vectorised path is assumed; csrc/mspmv_api.hip:
- * band_passes_for); the device-side verdicts have the last word. */
+/* Column bands (extension).  A large matrix whose columns are spread uniformly over an x of 1.375-10 x one XCD's L2 (fp32;
+ * 1.75-9 x in fp64: 5.5-40 / 7-36 MiB on MI355X) is gather-bound at the Infinity-Cache rate when x is gathered as it comes.  Such a call
+ * (a CANDIDATE by its sizes: *passes > 1 below) stays stateless, asynchronous and three launches: 64 blocks added to the coordinate
+ * launch sample 64 windows of 2048 consecutive column indices, and the tile kernel reads their verdicts and runs either its ordinary
+ * body or, when the columns are spread, the banded form:
+ *   CLOCK-SCHEDULED BANDS (round 6; csrc/mspmv_tdm.hpp; what the library runs): one pass.  A block sorts its tile's nonzeros by column
+ *     band (1 MiB of x) in LDS and gathers band by band, the band "on air" being read off the chip-wide 100 MHz clock -- blocks never
+ *     talk to each other, yet at any moment every XCD gathers from a band or two of x, which its L2 keeps.  y is BIT FOR BIT the
+ *     classic three-launch result without bands.  C2: 1.22 -> 0.64 ms (fp32), 1.57 -> 1.00 ms (fp64).
+ *   COLUMN-BAND PASSES (rounds 2-5; development library only since: mspmv_set_tdm(vb, -1)): the CSR stream read 2-4 times, each pass
+ *     multiplying the nonzeros of one band; a re-association of the sums (0.84 / 1.30 ms on C2).
+ * Either way results stay within the strict bound and are bitwise reproducible.
+ * *passes = how many passes a call of these sizes would be offered (0: none, not a candidate; the aligned, vectorised path is
+ * assumed; csrc/mspmv_api.hip: band_passes_for); the device-side verdicts have the last word. */
 int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *passes);
+/* The bands of the clock-scheduled form for a call of these sizes: *bands = how many (0: not a candidate), *band_cols = columns per
+ * band (a power of two: 1 MiB of x, widened until 32 bands cover it). */
+int mspmv_get_clocked_bands(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *bands, int32_t *band_cols);
 /* The 64 window verdicts (1 = columns look uniformly spread) the last automatic call left in d_temp -> HOST
  * array of 64 int32 (synchronises `stream`); at least 56 ones select the band passes. */
 int mspmv_debug_band_windows(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes,

@@ -18,7 +18,7 @@ import os
 from typing import Optional, Tuple
 
 __all__ = ["DeviceSpmv", "csrmv", "csrmm", "CsrMVWorkspace", "CsrMVPlan", "plan_bench_record", "library_path", "load_library", "launch_info",
-           "set_tuning", "set_tdm", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
+           "set_tuning", "set_tdm", "clocked_bands", "debug_read_tiles", "profile_begin", "profile_end", "MspmvError",
            "TUNE_ATOMIC_FIX", "TUNE_NO_VEC"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -727,6 +727,16 @@ def set_compact_tiles(max_tiles: int = 0) -> None:
     """Testing / tuning aid (mspmv_set_compact_tiles): up to how many tiles a call of the small tile shape runs the one-launch kernel
     behind its compact front end (0 = library default, > 0 = that many, < 0 = never).  y is bit for bit the same either way."""
     _setter("mspmv_set_compact_tiles", max_tiles == 0, int(max_tiles))
+
+
+def clocked_bands(rows: int, cols: int, nnz: int, value_bytes: int):
+    """(bands, columns per band) of the clock-scheduled form for a call of these sizes (mspmv_get_clocked_bands); (0, 0): not a candidate."""
+    b = ctypes.c_int32(0); c = ctypes.c_int32(0)
+    lib = load_library()
+    lib.mspmv_get_clocked_bands.restype = ctypes.c_int
+    lib.mspmv_get_clocked_bands.argtypes = [ctypes.c_int32] * 4 + [ctypes.POINTER(ctypes.c_int32)] * 2
+    _check(lib.mspmv_get_clocked_bands(int(rows), int(cols), int(nnz), int(value_bytes), ctypes.byref(b), ctypes.byref(c)), "mspmv_get_clocked_bands")
+    return b.value, c.value
 
 
 def band_passes(rows: int, cols: int, nnz: int, value_bytes: int) -> int:

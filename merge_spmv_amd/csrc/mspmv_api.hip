@@ -1280,6 +1280,19 @@ int mspmv_get_band_passes(int32_t rows, int32_t cols, int32_t nnz, int32_t value
     return hipSuccess;
 }
 
+int mspmv_get_clocked_bands(int32_t rows, int32_t cols, int32_t nnz, int32_t value_bytes, int32_t *bands, int32_t *band_cols)
+{
+    int32_t passes = 0;
+    if (!bands || !band_cols) return hipErrorInvalidValue;
+    const int st = mspmv_get_band_passes(rows, cols, nnz, value_bytes, &passes);
+    if (st != hipSuccess) return st;
+    CallExtra ex; ex.tune = thread_tune(value_bytes);
+    const int shift = tdm_shift_for(cols, value_bytes, passes, ex);
+    *bands = shift > 0 ? (int32_t) (((long long) cols + (1LL << shift) - 1) >> shift) : 0;
+    *band_cols = shift > 0 ? (int32_t) (1 << shift) : 0;
+    return hipSuccess;
+}
+
 int mspmv_debug_band_windows(const void *d_temp, int32_t rows, int32_t nnz, int32_t value_bytes, int32_t *h_verdicts,
                              mspmv_stream_t stream_)
 {
