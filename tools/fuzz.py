@@ -2,7 +2,7 @@
 """tools/fuzz.py [seconds] -- randomized differential test of the C ABI on the GPU: random CSR shapes
 (row-length families, empty rows, giant rows), precisions, array alignments (views at element offsets
 0..3: the unaligned ones take the scalar fallback), tuning flags, alpha/beta, SpMM widths and leading
-dimensions, forced column-band passes, the prepared band-major plan (random band counts, sorted and unsorted rows, alpha/beta) and the C multi-GPU
+dimensions, forced column bands (the clock-scheduled one-pass form under random clocks, or the passes), the prepared band-major plan (random band counts, sorted and unsorted rows, alpha/beta) and the C multi-GPU
 operator (1..8 parts on this device, peer exchange); results compared with an fp64 segment-sum on the GPU under the strict
 per-row bound."""
 import os, sys, time
@@ -99,6 +99,10 @@ def main():
         try:
             M.set_tuning(vb, shape[0], shape[1], flags)
             M.set_band_passes(vb, passes)
+            # a banded call runs the clock-scheduled one-pass form (csrc/mspmv_tdm.hpp; any band width, slot length, lookahead: the clock
+            # must not matter) or, with that switched off, the passes
+            if rng.random() < 0.35: M.set_tdm(vb, -1)
+            else: M.set_tdm(vb, int(rng.choice([0, 1])), int(rng.choice([0, 0, 1, 300, 3000, 100000])), int(rng.choice([0, 0, 1, 2, 5, 33])), int(rng.choice([0, 0, 3, 8, 11, 14, 17, 20])))
             polls = int(rng.choice([0, 0, 0, 1, -1]))
             M.set_record_polls(polls)       # default / one look / never look at the published records: the recomputing path
             mode = rng.integers(0, 5)
@@ -205,6 +209,7 @@ def main():
         finally:
             M.set_tuning(vb)
             M.set_band_passes(vb, 0)
+            M.set_tdm(vb, 0)
             M.set_record_polls(0)
             M.set_compact_tiles(0)
         cases += 1
