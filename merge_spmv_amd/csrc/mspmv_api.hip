@@ -305,6 +305,21 @@ static int device_cus()
     return v;
 }
 
+// ticks per microsecond of the counter s_memrealtime reads (hipDeviceAttributeWallClockRate, kHz; 100 MHz on MI300 / MI355X), queried
+// once per device: the slots of the clock-scheduled column bands are lengths of time, not tick counts
+static double device_wall_clock_ticks_per_us()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 100.0;
+    int khz = cached[dev].load(std::memory_order_relaxed);
+    if (khz == 0) {
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) { (void) hipGetLastError(); khz = 100000; }
+        cached[dev].store(khz, std::memory_order_relaxed);
+    }
+    return khz * 1e-3;
+}
+
 // opt-in per-kernel event timing (mspmv_profile_begin/_end).  Process-global and meant for ONE
 // measuring host thread (mspmv.h says so); the mutex only keeps concurrent callers from corrupting it.
 constexpr int PROF_EVENTS = 4;
@@ -639,10 +654,10 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                         // that is longer, for as long as every XCD needs to fetch the band over the fabric (7.8 TB/s for all of them):
                         // C2 fp32 2.13 us (12 bands of 1 MiB, 8 blocks per CU), fp64 1.08 us (24 bands, 5 blocks per CU); both
                         // constants read off sweeps of the slot length (tools/tdm_check.py sweep: the minimum is sharp, +-10 % of the
-                        // slot cost 3-5 % -- a block that misses a band's slot waits for the next rotation).  In ticks of 10 ns.
+                        // slot cost 3-5 % -- a block that misses a band's slot waits for the next rotation).  In ticks of the wall clock (10 ns here).
                         const double gather_us = 1.16 * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
                         const double fabric_us = (double) sizeof(V) * (double) (1u << ex.tdm_shift) * device_caches().xcds / 7.8e6;
-                        const double ticks = std::max(8.0, std::max(gather_us, fabric_us) * 100.0 * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
+                        const double ticks = std::max(8.0, std::max(gather_us, fabric_us) * device_wall_clock_ticks_per_us() * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
                         ba.tdm.inv_slot = (float) (1.0 / ticks);
                     }
 #define MSPMV_LAUNCH_BAND(AX, NTF, TD) hipLaunchKernelGGL((tile_kernel_vec<V, BLOCK, IPT, AX, false, NTF, 0, false, true, TD>), dim3(grid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, ba)
