@@ -438,7 +438,7 @@ static bool launch_dev_variant(const Layout &L, const Params<V> &p, bool axpby, 
         long long want = (long long) per_cu * device_cus();                                                \
         if (!forced) want = std::max<long long>(want, (L.num_tiles + tpb - 1) / tpb);                      \
         const unsigned pgrid = (unsigned) std::min<long long>(L.num_tiles, want);                          \
-        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, BandArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0, TdmArgs{0, 0, 0.f, 0, 0}});   \
+        hipLaunchKernelGGL(kernel, dim3(pgrid), dim3(BLOCK), (size_t) p.x_lds * sizeof(V), stream, p, coords, carries, L.num_tiles, chunk_log2, BandArgs{nullptr, nullptr, nullptr, 0, 0, 0, 0, TdmArgs{0, 0, 0.f, 0}});   \
     } while (0)
     if (ablate == 1) MSPMV_LAUNCH_P(false, false, true, 1, true);
     else if (ablate == 6) MSPMV_LAUNCH_P(false, false, true, 6, true);
@@ -635,7 +635,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
 #ifdef MSPMV_DEV
             launched = launch_dev_variant<V, BLOCK, IPT>(L, p, axpby, nt, coords, carries, chunk_log2, stream);
 #endif
-            BandArgs ba; ba.verdict = nullptr; ba.counters = nullptr; ba.next = nullptr; ba.grid = 0; ba.bands = 0; ba.band_cols = 0; ba.force = 0; ba.tdm = TdmArgs{0, 0, 0.f, 0, 0};
+            BandArgs ba; ba.verdict = nullptr; ba.counters = nullptr; ba.next = nullptr; ba.grid = 0; ba.bands = 0; ba.band_cols = 0; ba.force = 0; ba.tdm = TdmArgs{0, 0, 0.f, 0};
             if constexpr (band_shape(BLOCK, IPT, (int) sizeof(V))) {
                 if (band && !launched) {
                     // the BAND variant: the same kernel, whose first band_grid blocks run the column-band passes instead
@@ -648,8 +648,7 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                         // band by band.  Blocks resident per CU: what the kernel's occupancy says (LDS, registers).
                         const int per_cu = std::max(1, (int) std::min<long long>((L.num_tiles + device_cus() - 1) / device_cus(), band_resident_per_cu));
                         ba.tdm.band_shift = ex.tdm_shift; ba.tdm.bands = ex.tdm_bands;
-                        ba.tdm.lookahead = (ex.tune.tdm_lookahead & 0xff) > 0 ? (ex.tune.tdm_lookahead & 0xff) - 1 : std::max(1, ex.tdm_bands / 8);      // (an eighth of x ahead of the clock: 1 of 12 bands, 3 of 24)
-                        ba.tdm.lookback = ex.tune.tdm_lookahead > 0xff ? (ex.tune.tdm_lookahead >> 8) - 1 : 0;
+                        ba.tdm.lookahead = ex.tune.tdm_lookahead > 0 ? ex.tune.tdm_lookahead - 1 : std::max(1, ex.tdm_bands / 8);      // (an eighth of x ahead of the clock: 1 of 12 bands, 3 of 24)
                         // A band stays on air for as long as the resident blocks need for their gathers of it at the L2 gather rate
                         // (1.02 G gathers/s per CU: 262 G/s over 256 CUs, profiles/r02_hw_ceilings.txt) and a sixth more -- or, if
                         // that is longer, for as long as every XCD needs to fetch the band over the fabric (7.8 TB/s for all of them):
@@ -1242,7 +1241,7 @@ int mspmv_set_band_passes(int32_t value_bytes, int32_t passes)
 
 int mspmv_set_tdm(int32_t value_bytes, int32_t policy, int32_t slot_permille, int32_t lookahead_plus_1, int32_t band_shift)
 {
-    if ((value_bytes != 4 && value_bytes != 8) || slot_permille < 0 || lookahead_plus_1 < 0 || (lookahead_plus_1 & 0xff) > 33 || (lookahead_plus_1 >> 8) > 33 || band_shift < 0 || band_shift > TDM_SLOT_SHIFT)
+    if ((value_bytes != 4 && value_bytes != 8) || slot_permille < 0 || lookahead_plus_1 < 0 || lookahead_plus_1 > 33 || band_shift < 0 || band_shift > TDM_SLOT_SHIFT)
         return hipErrorInvalidValue;
     Tune &t = t_tune[value_bytes == 8];
     t.tdm = policy < 0 ? -1 : policy > 0 ? 1 : 0; t.tdm_slot_permille = slot_permille; t.tdm_lookahead = lookahead_plus_1; t.tdm_band_shift = band_shift;

@@ -2020,7 +2020,6 @@ struct TdmArgs {
     int bands;             // ceil(cols / 2^band_shift) <= TDM_MAX_BANDS
     float inv_slot;        // 1 / (ticks of the 100 MHz clock a band stays on air)
     int lookahead;         // bands after the one on air that may be taken too
-    int lookback;          // ... and before it (they were on air a moment ago: a wave that comes late for a band still finds it in L2)
 };
 template <typename V, int BLOCK, int IPT, bool NT>
 __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c0, const Coord c1, const TileRegs<V, BLOCK, IPT> &regs,

@@ -136,7 +136,8 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
                 if ((done >> k) & 1u) continue;
                 const int wq = (int) ((wqp >> (5 * k)) & 31ull);
                 int d = wq - on_air; if (d < 0) d += ta.bands;
-                if (d > ta.lookahead && d < ta.bands - ta.lookback) continue;
+                // (a window that also reaches BACK from the band on air is the same thing with the clock shifted: measured, only its width matters)
+                if (d > ta.lookahead) continue;
                 const int idx = k * BLOCK + tid;
                 if (idx < sorted) {
                     int q = wq;

@@ -107,7 +107,7 @@ def c2(sweep=False):
         print(f"fp{vb * 8} C2: one sweep {t_one:.4f} ms | column-band passes {t_pass:.4f} ms", flush=True)
         grid = [(0, 0, 0, 11)]
         if sweep:
-            grid = [(sp, la, sh, ipt) for ipt in (11,) for sh in ((18,) if vb == 4 else (17,)) for sp in (600, 700, 800, 900, 1000, 1100) for la in (1, 2, 3, 1 + 0x200, 2 + 0x200, 3 + 0x200, 1 + 0x300, 2 + 0x300, 2 + 0x400)]
+            grid = [(sp, la, sh, ipt) for ipt in (11,) for sh in ((18,) if vb == 4 else (17,)) for sp in (700, 800, 875, 950, 1000, 1050, 1125, 1200) for la in (2, 3, 4)]
         for sp, la, sh, ipt in grid:
             M.set_band_passes(vb, 0 if ipt == 11 else 4); M.set_tdm(vb, 1, sp, la, sh)
             if ipt != 11:
@@ -115,7 +115,7 @@ def c2(sweep=False):
                 ref7, _ = run(val, off, col, x, cols)
                 M.set_tuning(vb, 256, ipt); M.set_band_passes(vb, 4)
             y, t = run(val, off, col, x, cols, reps=30)
-            print(f"fp{vb * 8} C2: clocked bands 256x{ipt} slot {sp or 1000:5d} per mille, lookahead {(la & 255) - 1 if la else 2} lookback {(la >> 8) - 1 if la > 255 else 0}, band shift {sh or 18}: {t:.4f} ms  bitwise the one-sweep y: {torch.equal(y, ref if ipt == 11 else ref7)}", flush=True)
+            print(f"fp{vb * 8} C2: clocked bands 256x{ipt} slot {sp or 1000:5d} per mille, lookahead {la - 1 if la else 2}, band shift {sh or 18}: {t:.4f} ms  bitwise the one-sweep y: {torch.equal(y, ref if ipt == 11 else ref7)}", flush=True)
             M.set_tuning(vb)
         M.set_band_passes(vb, 0); M.set_tdm(vb, 0)
 
