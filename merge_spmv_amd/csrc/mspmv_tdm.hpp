@@ -3,11 +3,12 @@
 // The column-band passes (run_band_passes, mspmv_kernels.hpp) read the whole CSR stream once per band so that at any moment
 // every XCD gathers from one slice of x, which its 4 MiB L2 keeps.  Here the stream is read ONCE.  A block
 //   1. loads its merge-path tile's (column, value) chunks as every tile kernel does,
-//   2. sorts the tile's nonzeros by column band THROUGH LDS (replicated counters, one exclusive scan, one scatter; the
-//      sorted (slot | column-in-band) words come back into registers, striped over the block),
+//   2. sorts the tile's nonzeros by column band THROUGH LDS (replicated counters filled by LDS atomics, one exclusive scan, a second
+//      round of atomics that hands out positions; the sorted (slot | column-in-band) words pass through the product array and come
+//      back into registers, striped over the block: no LDS beyond what the tile kernel has anyway),
 //   3. gathers band by band -- and WHEN it may gather from a band is read off the chip-wide 100 MHz clock (s_memrealtime):
 //      band (t / slot) % B is "on air".  Blocks never talk to each other: whatever tile a block holds and whenever it got
-//      it, its gathers of band b happen while the other blocks of its XCD gather from band b (or the one after), so the
+//      it, its gathers of band b happen while the other blocks of its XCD gather from band b (or the ones just after), so the
 //      XCD's L2 holds a band or two of x and the gathers hit.  The x values land in the product array at the nonzeros'
 //      own slots,
 //   4. multiplies (every thread its own chunks again), stages the row ends, and hands over to the ordinary reduction
@@ -15,7 +16,11 @@
 // The clock is a cache-affinity schedule, not a protocol: a block may gather any band at any time and the result is the
 // same -- bit for bit the one-sweep tile_kernel_vec's, since products and reduction are the same (unlike the passes,
 // which add band partials).  Nothing waits for another workgroup; a wave with nothing on air sleeps and looks again.
-// Measured (tools/tdm_spmv.hip, the prototype): C2 fp32 0.64 ms against the passes' 0.83, fp64 1.02 against 1.30.
+// Carrier: tile_kernel_vec<..., BAND, TDM> (mspmv_kernels.hpp) -- one tile per block, the verdict of the 64 sampled windows chooses
+// between this staging and the ordinary one; the slot length comes from the dispatcher (mspmv_api.hip).
+// Measured: C2 fp32 0.64 ms against the passes' 0.83, fp64 0.98-1.00 against 1.30 (profiles/r06_c2_f32, r06_c2_f64); the prototype
+// (tools/tdm_spmv.hip), a persistent kernel of its own and the staging inside the one-launch kernel, all measured and dropped, are
+// in docs/history/round6.md.
 #pragma once
 #include "mspmv_kernels.hpp"
 
@@ -23,7 +28,6 @@ namespace mspmv {
 
 constexpr int TDM_COPIES = 8;              // counters per (band, wave): lanes 8 apart share one
 constexpr int TDM_SLOT_SHIFT = 20;         // sorted word = slot in the tile's raw product array (12 bits) << 20 | column inside its band
-
 
 // the tile's products, row ends and row-start bits in LDS, as stage_tile_careful leaves them -- x gathered band by band
 template <typename V, int BLOCK, int IPT, bool NT>
