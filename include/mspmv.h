@@ -55,7 +55,7 @@ extern "C" {
  * no HIP headers (NULL = the default stream). */
 typedef void *mspmv_stream_t;
 
-#define MSPMV_VERSION 101 /* 0.1.1: mspmv_launch_info_t grew (records_offset, layout_offset); the setters moved to mspmv_dev.h */
+#define MSPMV_VERSION 102 /* 0.1.2: + mspmv_get_clocked_bands (the clock-scheduled column bands serve the column-band candidates); 0.1.1: mspmv_launch_info_t grew (records_offset, layout_offset), the setters moved to mspmv_dev.h */
 int mspmv_version(void);
 
 /* hipGetErrorString for codes returned by this library. */
