@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert "mspmv_csrmv_f32" in names and "mspmv_csrmv_f64" in names and len(names) >= 10
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.mspmv_version() == 101
+    assert lib.mspmv_version() == 102
     # ... and nothing else: what is exported is what include/mspmv.h declares
     assert exported(M.library_path("product")) == names
 
