@@ -655,7 +655,9 @@ static hipError_t run_shape(const Layout &L, void *d_temp, const Params<V> &p, b
                         // C2 fp32 2.13 us (12 bands of 1 MiB, 8 blocks per CU), fp64 1.08 us (24 bands, 5 blocks per CU); both
                         // constants read off sweeps of the slot length (tools/tdm_check.py sweep: the minimum is sharp, +-10 % of the
                         // slot cost 3-5 % -- a block that misses a band's slot waits for the next rotation).  In ticks of the wall clock (10 ns here).
-                        const double gather_us = 1.16 * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
+                        // (a tile's BLOCK * IPT path items are nonzeros and row ends: rows of 8 leave 2503 gathers per tile, and the optimum moves with them)
+                        const double nz_share = (double) p.nnz / ((double) p.nnz + (double) p.rows);
+                        const double gather_us = 1.16 * nz_share * (double) per_cu * BLOCK * IPT / ex.tdm_bands / 1.02e3;
                         const double fabric_us = (double) sizeof(V) * (double) (1u << ex.tdm_shift) * device_caches().xcds / 7.8e6;
                         const double ticks = std::max(8.0, std::max(gather_us, fabric_us) * device_wall_clock_ticks_per_us() * (ex.tune.tdm_slot_permille > 0 ? ex.tune.tdm_slot_permille * 1e-3 : 1.0));
                         ba.tdm.inv_slot = (float) (1.0 / ticks);

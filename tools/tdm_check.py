@@ -120,8 +120,28 @@ def c2(sweep=False):
         M.set_band_passes(vb, 0); M.set_tdm(vb, 0)
 
 
+def rows8():
+    """rows of 8 (a tile holds 313 rows and 2503 nonzeros): where does the slot's optimum sit against the model's?"""
+    for dtype, vb in ((torch.float32, 4), (torch.float64, 8)):
+        val, off, col, x = uniform_csr(12_500_000, 3_125_000, 8, dtype)
+        cols = 3_125_000
+        M.set_band_passes(vb, -1); M.set_tdm(vb, 0)
+        _, t_one = run(val, off, col, x, cols, reps=20)
+        M.set_band_passes(vb, 0); M.set_tdm(vb, -1)
+        _, t_pass = run(val, off, col, x, cols, reps=20)
+        print(f"fp{vb * 8} rows of 8: one launch {t_one:.4f} ms | column-band passes {t_pass:.4f} ms (offered {M.band_passes(12_500_000, cols, 100_000_000, vb)})", flush=True)
+        for sp in (700, 800, 850, 900, 950, 1000, 1100):
+            M.set_band_passes(vb, 0); M.set_tdm(vb, 1, sp, 0, 0)
+            _, t = run(val, off, col, x, cols, reps=20)
+            print(f"fp{vb * 8} rows of 8: clocked bands slot {sp} per mille: {t:.4f} ms", flush=True)
+        M.set_band_passes(vb, 0); M.set_tdm(vb, 0)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "quick"
     if what == "quick":
         sys.exit(0 if quick() else 1)
-    c2(sweep=what == "sweep")
+    if what == "rows8":
+        rows8()
+    else:
+        c2(sweep=what == "sweep")
