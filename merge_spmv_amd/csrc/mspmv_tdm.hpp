@@ -128,6 +128,10 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
 #pragma unroll
         for (int k = 0; k < IPT; ++k) if (k * BLOCK + wave * WAVE >= sorted) done |= 1u << k;
         const unsigned all = (1u << IPT) - 1u;
+        // (a safety valve, not a schedule: a wave that has found nothing on air 4096 times in a row -- ~0.6 ms, twenty rotations and
+        //  more -- stops asking the clock and takes what is left; it never fires under a clock that runs, and no launch can hang on one
+        //  that does not)
+        int idle = 0;
         while (done != all) {
             // (24 bits of the clock: exact in a float; the wrap every 0.17 s costs one odd slot)
             const unsigned slot = (unsigned) ((float) ((unsigned) wall_clock64() & 0xFFFFFFu) * ta.inv_slot);
@@ -141,7 +145,7 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
                 const int wq = (int) ((wqp >> (5 * k)) & 31ull);
                 int d = wq - on_air; if (d < 0) d += ta.bands;
                 // (a window that also reaches BACK from the band on air is the same thing with the clock shifted: measured, only its width matters)
-                if (d > ta.lookahead) continue;
+                if (d > ta.lookahead && idle <= 4096) continue;
                 const int idx = k * BLOCK + tid;
                 if (idx < sorted) {
                     int q = wq;
@@ -151,7 +155,7 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
                 }
                 done |= 1u << k; any = true;
             }
-            if (!any) __builtin_amdgcn_s_sleep(4);
+            if (!any) { ++idle; __builtin_amdgcn_s_sleep(4); } else idle = 0;
         }
     }
     // row ends of the tile: requested behind the gathers (12 registers the gather phase does without), staged below
