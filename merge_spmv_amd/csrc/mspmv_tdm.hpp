@@ -115,10 +115,15 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
     // (five bits each, in one 64-bit scalar: eleven separate ones were eleven more scalar registers than the kernel has)
     static_assert(IPT * 5 <= 64 && TDM_MAX_BANDS <= 32, "window bands packed five bits each");
     unsigned long long wqp = 0ull;
+    int lookahead = ta.lookahead;
     {
         const int st = lane < ta.bands ? s_start[lane + 1] : 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < IPT; ++k) wqp |= (unsigned long long) (__popcll(__ballot(st <= k * BLOCK + wave * WAVE)) & 31) << (5 * k);
+        // a tile whose nonzeros lie in one or two bands (a local stretch of a matrix the sampled windows called spread) has nothing to
+        // schedule: waiting for its bands' slots would cost it up to a rotation, its gathers are neighbours anyway -- it takes them at once
+        const int lo = lane < ta.bands ? s_start[lane] : 0x7fffffff;
+        if (__popcll(__ballot(lane < ta.bands && st > lo)) <= 2) lookahead = ta.bands;
     }
     __syncthreads();                          // every sorted word is in registers: the product array may take the x values
     // ---- 4. band by band, as the clock says; every wave on its own
@@ -145,7 +150,7 @@ __device__ __forceinline__ void stage_tile_tdm(const Params<V> &p, const Coord c
                 const int wq = (int) ((wqp >> (5 * k)) & 31ull);
                 int d = wq - on_air; if (d < 0) d += ta.bands;
                 // (a window that also reaches BACK from the band on air is the same thing with the clock shifted: measured, only its width matters)
-                if (d > ta.lookahead && idle <= 4096) continue;
+                if (d > lookahead && idle <= 4096) continue;
                 const int idx = k * BLOCK + tid;
                 if (idx < sorted) {
                     int q = wq;

@@ -105,6 +105,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((sizeof(V
             v[k] = __builtin_nontemporal_load(reinterpret_cast<const V4*>(val) + g);
         }
         if constexpr (!SORTED) {
+          if (a.mode == 4) {
+            // NO SORT: every thread keeps its own nonzeros and gathers each one when its band is on air (a gather instruction per item
+            // and slot, a twelfth of its lanes active) -- does the texture path charge by instruction or by active lane?
+            V xv[CPT][4];
+            unsigned pend = 0u;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xv[k][i] = (V) 0; if (tid + k * BLOCK < CH) pend |= 1u << (4 * k + i); }
+            while (__ballot(pend != 0u) != 0ull) {
+                const unsigned slot = (unsigned) ((float) ((unsigned) wall_clock64() & 0xFFFFFFu) * a.inv_slot);
+                const int on_air = (int) (slot % (unsigned) a.bands);
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if ((pend >> (4 * k + i)) & 1u) {
+                            int d = (int) ((unsigned) c[k][i] >> a.band_shift) - on_air; if (d < 0) d += a.bands;
+                            if (d <= a.lookahead) { xv[k][i] = x[c[k][i]]; pend &= ~(1u << (4 * k + i)); any = true; }
+                        }
+                    }
+                if (__ballot(any) == 0ull) __builtin_amdgcn_s_sleep(4);
+            }
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int ch = tid + k * BLOCK;
+                V p = (V) 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p += v[k][i] * xv[k][i];
+                for (int d = 1; d < chunks_per_row; d <<= 1) p += __shfl_xor(p, d);
+                if (ch < CH && (ch % chunks_per_row) == 0) y[(size_t) tile * rows_per_tile + ch / chunks_per_row] = p;
+            }
+            __syncthreads();
+            continue;
+          }
             // baseline in the same harness: one pass, every gather where it falls
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
@@ -247,7 +283,7 @@ static void run(int rows_in, int cols, int npr, const char* only)
         CK(hipMemset(y, 0xFF, (size_t) rows * sizeof(V)));
         auto L = [&] {
             CK(hipMemsetAsync(claim, 0, 8 * 64 * 4));
-            if (mode == 2) hipLaunchKernelGGL((k_tdm<V, IPT, false>), dim3(grid), dim3(BLOCK), 0, 0, col, val, x, y, a);
+            if (mode == 2 || mode == 4) hipLaunchKernelGGL((k_tdm<V, IPT, false>), dim3(grid), dim3(BLOCK), 0, 0, col, val, x, y, a);
             else hipLaunchKernelGGL((k_tdm<V, IPT, true>), dim3(grid), dim3(BLOCK), 0, 0, col, val, x, y, a);
         };
         const float t = time_ms(L);
@@ -260,6 +296,15 @@ static void run(int rows_in, int cols, int npr, const char* only)
         fflush(stdout);
     };
     const int max_per_cu = sizeof(V) == 4 ? (IPT == 11 ? 7 : 8) : (IPT == 11 ? 4 : 7);
+    if (only && strstr(only, "nosort")) {
+        for (int bs : {18, 19}) {
+            const int bands = (cols + (1 << bs) - 1) >> bs;
+            for (int pc : {8, 6}) {
+                const double ideal_us = (double) pc * cus * ITEMS / bands / 262e3;
+                for (double f : {0.85, 1.0, 1.16, 1.35, 1.6}) for (int la : {0, 1, 2}) one(4, bs, (int) (ideal_us * f * 100.0 + 0.5), la, pc, 0);
+            }
+        }
+    }
     if (!only || strstr(only, "base")) one(2, 20, 256, 0, 8, 0);
     if (!only || strstr(only, "order")) for (int bs : {18, 19}) one(1, bs, 256, 0, max_per_cu, 0);
     // x bytes per band -> slot lengths around (resident nonzeros / bands) / 262 G gathers/s
